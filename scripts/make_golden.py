@@ -1,0 +1,110 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF (CPU) in the build container.
+
+The reference (fatchord/WaveRNN, mounted read-only at /root/reference) has no tests or golden vectors,
+so the fixtures pinning `oracle/` are outputs of the reference's own `WaveRNN.generate()` under a
+fixed seed.  /root/reference does not exist on the GPU box: this script runs only here, the .npz
+fixtures are committed.  Shims: stub `librosa`, alias `np.cumproduct`,
+configure `hparams`.  Nothing is written into the reference tree.
+
+    python scripts/make_golden.py
+"""
+import os, sys, types
+import numpy as np
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF = os.environ.get('WRNN_REFERENCE', '/root/reference')
+sys.path.insert(0, REF)
+lib = types.ModuleType('librosa'); lib.output = types.SimpleNamespace(write_wav=lambda *a, **k: None)
+sys.modules['librosa'] = lib
+if not hasattr(np, 'cumproduct'):
+    np.cumproduct = np.cumprod
+import torch
+from utils import hparams as hp
+hp.configure(os.path.join(REF, 'hparams.py'))
+from models.fatchord_version import WaveRNN          # the reference implementation
+WaveRNN.gen_display = lambda self, *a, **k: None
+
+from wavernn_amd.synthetic import random_state_dict, random_mel, SHIPPED
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+CASES = [
+    # name, mode, weight seed, mel seed, frames, batched, target, overlap, mu_law, sample seed
+    dict(name='raw_unbatched_24f', mode='RAW', wseed=11, mseed=101, frames=24, batched=False, target=11000, overlap=550, mu_law=True, seed=77),
+    dict(name='raw_batched_60f', mode='RAW', wseed=11, mseed=102, frames=60, batched=True, target=1100, overlap=55, mu_law=True, seed=78),
+    dict(name='mol_unbatched_24f', mode='MOL', wseed=12, mseed=103, frames=24, batched=False, target=11000, overlap=550, mu_law=True, seed=79),
+    dict(name='mol_batched_100f', mode='MOL', wseed=12, mseed=104, frames=100, batched=True, target=1100, overlap=55, mu_law=True, seed=80),
+    dict(name='mol_batched_ragged_53f', mode='MOL', wseed=13, mseed=105, frames=53, batched=True, target=2000, overlap=100, mu_law=False, seed=81),
+]
+
+
+def run_case(c):
+    sd_np = random_state_dict(c['wseed'], mode=c['mode'])
+    model = WaveRNN(**SHIPPED, mode=c['mode'])
+    missing = model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}, strict=True)
+    mel = random_mel(c['mseed'], c['frames'])
+    cap = {}
+    real_stack = torch.stack
+
+    def stack(tensors, *a, **k):
+        r = real_stack(tensors, *a, **k)
+        cap['raw'] = r
+        return r
+
+    # conditioning tensors the reference feeds the loop (for the upsample/fold oracle checks)
+    real_up = model.upsample.forward
+
+    def up(m):
+        a, b = real_up(m)
+        cap['mels_up'], cap['aux_up'] = a.detach().clone(), b.detach().clone()
+        return a, b
+    model.upsample.forward = up
+    torch.stack = stack
+    try:
+        torch.manual_seed(c['seed'])
+        out = model.generate(torch.tensor(mel).unsqueeze(0), '/tmp/_golden.wav', c['batched'], c['target'],
+                             c['overlap'], c['mu_law'])
+    finally:
+        torch.stack = real_stack
+    raw = cap['raw'].transpose(0, 1).contiguous().numpy()       # (B,T) float32, pre-decode (:243)
+    mels_up = cap['mels_up'][0].numpy()
+    aux_up = cap['aux_up'][0].numpy()
+    # keep fixtures small: conditioning is stored strided (every 97th upsampled sample) + full aux frames
+    np.savez_compressed(os.path.join(OUT, c['name'] + '.npz'),
+                        config=np.array(repr(c)), out=out.astype(np.float64), raw=raw.astype(np.float32),
+                        mels_up_strided=mels_up[::97].astype(np.float32), aux_up_strided=aux_up[::97].astype(np.float32),
+                        L=np.int64(mels_up.shape[0]))
+    print(c['name'], 'raw', raw.shape, 'out', out.shape, 'absmax', np.abs(out).max())
+
+
+def rng_kats():
+    """Known-answer vectors of torch's CPU generator for the RNG oracle."""
+    torch.manual_seed(5)
+    u = torch.empty(16).uniform_(0, 1).numpy()
+    torch.manual_seed(5)
+    u2 = torch.empty(16).uniform_(1e-5, 1 - 1e-5).numpy()
+    torch.manual_seed(5)
+    e = torch.empty(16).exponential_(1).numpy()
+    torch.manual_seed(9)
+    _ = torch.nn.GRUCell(512, 512); _ = torch.nn.GRUCell(544, 512)
+    after = torch.empty(8).uniform_(1e-5, 1 - 1e-5).numpy()
+    torch.manual_seed(21)
+    mix = [torch.empty(1, 3, 10).uniform_(1e-5, 1 - 1e-5).numpy().ravel(), torch.empty(1, 3).uniform_(1e-5, 1 - 1e-5).numpy().ravel(),
+           torch.empty(1, 3, 10).uniform_(1e-5, 1 - 1e-5).numpy().ravel(), torch.empty(1, 3).uniform_(1e-5, 1 - 1e-5).numpy().ravel()]
+    torch.manual_seed(22)
+    ex = torch.empty(3, 512).exponential_(1).numpy()
+    np.savez_compressed(os.path.join(OUT, 'rng_kats.npz'), uniform01_seed5=u, uniform_mol_seed5=u2, exp_seed5=e,
+                        after_grucell_ctors_seed9=after, mol_two_steps_seed21=np.concatenate(mix), exp_3x512_seed22=ex)
+    print('rng kats written')
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    rng_kats()
+    only = sys.argv[1:]
+    for c in CASES:
+        if only and c['name'] not in only:
+            continue
+        run_case(c)

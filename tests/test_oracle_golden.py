@@ -1,0 +1,86 @@
+"""Pins `oracle/` to the reference: every fixture under tests/golden was produced by running the
+reference's own `WaveRNN.generate()` (scripts/make_golden.py).  CPU-only."""
+import numpy as np
+import pytest
+
+from oracle import wavernn_oracle as O
+from oracle import c_oracle as C
+from wavernn_amd.synthetic import random_state_dict, random_mel
+from helpers import CASES, MOL_TOL, load_case
+
+
+def test_rng_known_answers(golden_dir):
+    k = np.load(golden_dir + '/rng_kats.npz')
+    assert np.array_equal(O.TorchCpuStream(5).uniform_(16, 0, 1), k['uniform01_seed5'])
+    assert np.array_equal(O.TorchCpuStream(5).uniform_(16, 1e-5, 1 - 1e-5), k['uniform_mol_seed5'])
+    assert np.array_equal(O.TorchCpuStream(5).exponential_(16), k['exp_seed5'])
+    s = O.TorchCpuStream(9)
+    s.skip(O.gru_cell_ctor_draws())
+    assert O.gru_cell_ctor_draws() == 3_201_024
+    assert np.array_equal(s.uniform_(8, 1e-5, 1 - 1e-5), k['after_grucell_ctors_seed9'])
+    # two MoL steps at B=3: (1,B,10) then (1,B) per step == one flat stream of 11*B per step
+    assert np.array_equal(O.TorchCpuStream(21).uniform_(66, 1e-5, 1 - 1e-5), k['mol_two_steps_seed21'])
+    assert np.array_equal(O.TorchCpuStream(22).exponential_(3 * 512).reshape(3, 512), k['exp_3x512_seed22'])
+    # SURVEY.md section 8c KATs (seed 5)
+    np.testing.assert_allclose(k['uniform01_seed5'][:3], [0.8302518725, 0.1261109114, 0.9074696898], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_conditioning_matches_reference(name):
+    cfg, g = load_case(name)
+    sd = random_state_dict(cfg['wseed'], mode=cfg['mode'])
+    mel = random_mel(cfg['mseed'], cfg['frames'])
+    m = O.pad_tensor(mel.T[None], 2, 'both')[0].T
+    mels_up, aux_up = O.upsample_network(sd, m)
+    assert mels_up.shape[0] == int(g['L']) == cfg['frames'] * 275
+    np.testing.assert_allclose(mels_up[::97], g['mels_up_strided'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(aux_up[::97], g['aux_up_strided'], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_c_oracle_matches_reference(name):
+    """C loop oracle, fed the numpy conditioning + MT19937 noise, vs the reference's pre-decode [B,T] tensor
+    and final float64 waveform.  RAW: bit-exact.  MoL: <= MOL_TOL."""
+    cfg, g = load_case(name)
+    sd = random_state_dict(cfg['wseed'], mode=cfg['mode'])
+    mel = random_mel(cfg['mseed'], cfg['frames'])
+    mels, aux, wave_len = O.conditioning(sd, mel, cfg['batched'], cfg['target'], cfg['overlap'])
+    B, T, _ = mels.shape
+    assert (B, T) == g['raw'].shape
+    noise = O.draw_noise(cfg['seed'], cfg['mode'], B, T)
+    raw = C.loop(sd, cfg['mode'], mels, aux, noise)
+    n_classes = 512 if cfg['mode'] == 'RAW' else 30
+    out = O.finish(raw.copy(), cfg['mode'], n_classes, wave_len, cfg['batched'], cfg['target'], cfg['overlap'], cfg['mu_law'])
+    assert out.dtype == np.float64 and out.shape == g['out'].shape
+    if cfg['mode'] == 'RAW':
+        assert np.array_equal(raw, g['raw'])
+        assert np.array_equal(out, g['out'])
+    else:
+        assert np.abs(raw - g['raw']).max() <= MOL_TOL
+        assert np.abs(out - g['out']).max() <= MOL_TOL
+
+
+@pytest.mark.parametrize('name', ['raw_batched_60f', 'mol_batched_ragged_53f'])
+def test_numpy_oracle_matches_reference(name):
+    cfg, g = load_case(name)
+    sd = random_state_dict(cfg['wseed'], mode=cfg['mode'])
+    mel = random_mel(cfg['mseed'], cfg['frames'])
+    out, raw = O.generate(sd, cfg['mode'], mel, cfg['batched'], cfg['target'], cfg['overlap'], cfg['mu_law'], cfg['seed'],
+                          return_raw=True)
+    if cfg['mode'] == 'RAW':
+        assert np.array_equal(raw, g['raw']) and np.array_equal(out, g['out'])
+    else:
+        assert np.abs(raw - g['raw']).max() <= MOL_TOL and np.abs(out - g['out']).max() <= MOL_TOL
+
+
+def test_fold_examples():
+    # SURVEY Appendix A.3 examples (target 11000, overlap 550)
+    assert O.num_folds(81 * 275, 11000, 550) == 2
+    assert O.num_folds(481 * 275, 11000, 550) == 12
+    assert O.num_folds(1001 * 275, 11000, 550) == 24
+    assert O.num_folds(800 * 275, 11000, 550) == 19       # exact fit, no padded fold
+    x = np.arange(10, dtype=np.float32).reshape(1, 10, 1) + 1
+    f = O.fold_with_overlap(x, 2, 1)                      # docstring example fatchord_version.py:309-317
+    assert f[:, :, 0].tolist() == [[1, 2, 3, 4], [4, 5, 6, 7], [7, 8, 9, 10]]
+    short = O.fold_with_overlap(np.ones((1, 5, 2), np.float32), 8, 2)   # L < target+2*overlap -> one padded fold
+    assert short.shape == (1, 12, 2) and short[0, 5:].sum() == 0
