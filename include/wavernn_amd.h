@@ -1,0 +1,147 @@
+/*
+ * wavernn_amd.h -- C ABI of the MI355X-native WaveRNN generate path (libwavernn_amd.so).
+ *
+ * Drop-in boundary for ONE hot path of fatchord/WaveRNN: the per-sample loop of
+ * `WaveRNN.generate()` (reference models/fatchord_version.py:169-264).  The reference has no FFI of its
+ * own (it is pure Python on PyTorch); these entry points are what a binding for that path binds, one per
+ * reference stage, and each cites the reference lines it replaces.  INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every `const float*` marked "device" is a HIP device pointer owned by the caller
+ *     (e.g. a torch tensor's data_ptr()); the library BORROWS it for the duration of the call.
+ *   - all functions return WRNN_OK (0) or a negative error code; wrnn_last_error() returns a message for the
+ *     calling thread's last failure.  Nothing here synchronises the device except the functions that say so.
+ *   - work is enqueued on the hipStream_t passed as `void* stream` (NULL = default stream).
+ *   - arithmetic type: float32 (same as the reference).  No CPU fallback exists: without a HIP device every
+ *     compute entry point fails with WRNN_ERR_NO_DEVICE.
+ */
+#ifndef WAVERNN_AMD_H
+#define WAVERNN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WRNN_ABI_VERSION 1
+
+enum {
+    WRNN_OK = 0,
+    WRNN_ERR_ARG = -1,        /* bad argument (shape, NULL pointer, unsupported dims) */
+    WRNN_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime failure */
+    WRNN_ERR_HIP = -3,        /* a HIP API call failed; see wrnn_last_error() */
+    WRNN_ERR_WORKSPACE = -4,  /* workspace too small */
+    WRNN_ERR_KERNEL = -5,     /* a kernel reported a failure (bounded spin expired, bad state) */
+    WRNN_ERR_RESIDENCY = -6   /* persistent grid cannot be co-resident on this device */
+};
+
+enum { WRNN_MODE_RAW = 0, WRNN_MODE_MOL = 1 };  /* reference: WaveRNN(mode='RAW'|'MOL'), fatchord_version.py:97-104 */
+
+/* Loop kernel selection. */
+enum {
+    WRNN_ALGO_AUTO = 0,     /* persistent chip-wide kernel when the device admits it, else stream */
+    WRNN_ALGO_STREAM = 1,   /* one workgroup per folded segment, weights streamed from L2/MALL each step */
+    WRNN_ALGO_PERSIST = 2   /* persistent cooperative kernel, weights stationary on-chip, all CUs per step */
+};
+
+/*
+ * Host-side view of the loop weights, exactly the tensors `WaveRNN.generate()` touches inside its loop
+ * (state_dict keys in comments; shapes for rnn_dims=H, fc_dims=F, feat_dims=M, aux_dims=A=res_out_dims/4,
+ * n_classes=C).  fatchord_version.py:115-123 (definition), :208-223 (use), :273-279 (GRU cell views).
+ * All pointers are HOST pointers to contiguous row-major float32.
+ */
+typedef struct wrnn_weights {
+    int32_t rnn_dims;    /* H: must be 512 in this build */
+    int32_t fc_dims;     /* F: must be 512 in this build */
+    int32_t feat_dims;   /* M: 80 */
+    int32_t aux_dims;    /* A: 32 */
+    int32_t n_classes;   /* C: 30 (MOL) or 2**bits (RAW); RAW needs C <= 512 and C % 64 == 0 */
+    int32_t mode;        /* WRNN_MODE_* */
+    const float *I_w, *I_b;                          /* I.weight (H,1+M+A), I.bias (H) */
+    const float *w_ih1, *w_hh1, *b_ih1, *b_hh1;      /* rnn1.weight_ih_l0 (3H,H), weight_hh_l0 (3H,H), biases (3H) */
+    const float *w_ih2, *w_hh2, *b_ih2, *b_hh2;      /* rnn2.weight_ih_l0 (3H,H+A), weight_hh_l0 (3H,H), biases (3H) */
+    const float *fc1_w, *fc1_b;                      /* fc1.weight (F,H+A), fc1.bias (F) */
+    const float *fc2_w, *fc2_b;                      /* fc2.weight (F,F+A), fc2.bias (F) */
+    const float *fc3_w, *fc3_b;                      /* fc3.weight (C,F), fc3.bias (C) */
+} wrnn_weights;
+
+/* Opaque device-resident weight pack (replaces the per-call `get_gru_cell` views, fatchord_version.py:178-179). */
+typedef struct wrnn_pack wrnn_pack;
+
+/*
+ * Geometry of one batched (folded) or unbatched generation -- the arguments of
+ * `fold_with_overlap(x, target, overlap)` (fatchord_version.py:293-340) without materialising the fold:
+ * segment b, step t reads the un-folded conditioning at position p = b*stride + t; positions p >= L are the
+ * reference's zero padding (:326-330).  Unbatched: B=1, T=L, stride=0.
+ */
+typedef struct wrnn_geometry {
+    int32_t B;        /* number of folded segments (num_folds) */
+    int32_t T;        /* steps per segment: target + 2*overlap (batched) or L (unbatched) */
+    int32_t stride;   /* target + overlap */
+    int32_t L;        /* un-folded conditioning length in samples (N*hop) */
+    int32_t hop;      /* samples per mel frame (aux is constant over a frame: Stretch2d, :57-61,:84) */
+    int32_t n_frames; /* rows of `aux` (= L / hop) */
+} wrnn_geometry;
+
+/* Optional test hooks (all may be NULL). */
+typedef struct wrnn_debug {
+    const float *force_x;  /* device [B,T]: teacher forcing -- value fed back as x_{t} instead of the sample */
+    float *logits;         /* device [T,B,C]: pre-sampling logits of every step (fc3 output, :223) */
+} wrnn_debug;
+
+const char *wrnn_last_error(void);
+int wrnn_abi_version(void);
+
+/* Number of compute units of HIP device `device` (or <0). */
+int wrnn_device_cus(int device);
+
+/* Upload + re-layout the loop weights for `device`.  Synchronous (uses its own stream and waits). */
+int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **out);
+void wrnn_pack_destroy(wrnn_pack *p);
+/* bytes of loop weights the reference streams per step (the W of SURVEY.md section 8d) */
+size_t wrnn_pack_weight_bytes(const wrnn_pack *p);
+
+/* Workspace (device bytes) wrnn_generate needs for this geometry. */
+size_t wrnn_workspace_bytes(const wrnn_pack *p, const wrnn_geometry *g);
+
+/*
+ * The loop: replaces fatchord_version.py:192-245 (state init, the `for i in range(seq_len)` body incl.
+ * sample_from_discretized_mix_logistic / softmax+Categorical, and the stack/transpose gather).
+ *
+ *   mels_up  device [L, M]          un-folded up-sampled mel  (`mels` of :186 before the fold)
+ *   aux      device [n_frames, 4A]  MelResNet output per FRAME (`aux` of :186 before Stretch2d repeats it)
+ *   noise    device, the sampling noise in the order the reference draws it:
+ *              MOL: [T, 11*B]: per step 10*B uniforms (segment-major, mixture-minor; distribution.py:106)
+ *                   followed by B uniforms (distribution.py:118), all U(1e-5, 1-1e-5)
+ *              RAW: [T, B, C] Exp(1) variates (Categorical.sample -> multinomial)
+ *   out      device [B, T]          the (B,T) tensor of :243 (samples in [-1,1]; RAW: 2*idx/(C-1)-1)
+ *
+ * Enqueues on `stream`; does not synchronise.  Call wrnn_status() after synchronising to learn whether
+ * the kernels completed (bounded spins never hang: they give up and report).
+ */
+int wrnn_generate(const wrnn_pack *p, const wrnn_geometry *g, const float *mels_up, const float *aux,
+                  const float *noise, float *out, void *workspace, size_t workspace_bytes, int algo,
+                  const wrnn_debug *dbg, void *stream);
+
+/* Synchronises `stream`, reads the kernel status words from `workspace`.  WRNN_OK or WRNN_ERR_KERNEL. */
+int wrnn_status(void *workspace, void *stream);
+
+/* Milliseconds the last wrnn_generate on this pack spent in its loop kernel(s) (HIP events on `stream`;
+ * synchronises).  <0 if unavailable. */
+float wrnn_last_loop_ms(const wrnn_pack *p);
+/* name of the loop kernel the last wrnn_generate launched ("wrnn_persist_kernel"/"wrnn_stream_kernel") */
+const char *wrnn_last_loop_kernel(const wrnn_pack *p);
+
+/* Self tests of the device primitives (MFMA fragment layout, inter-workgroup granule all-gather).
+ * Synchronous.  WRNN_OK or an error with a message. */
+int wrnn_selftest(int device, int which);
+/* microseconds per all-gather round measured by the last wrnn_selftest(device, 2) (<0 if none) */
+float wrnn_selftest_metric(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVERNN_AMD_H */

@@ -1,0 +1,167 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the oracle and against the
+committed golden vectors produced by the reference itself.
+
+Bars (BASELINE.json north_star): RAW ("bits", mu-law) = bit-exact class indices / identical float64 waveform;
+MoL = max-abs error <= MOL_TOL (1e-5) on samples in [-1, 1].  /root/reference is never read here.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASES, MOL_TOL, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    assert torch.cuda.is_available(), 'these tests need a HIP device'
+    from wavernn_amd import _lib
+    _lib.lib()          # fails loudly if the HIP extension is missing
+    return torch.device('cuda', 0)
+
+
+def _inputs(cfg):
+    from oracle import wavernn_oracle as O
+    from wavernn_amd.synthetic import random_state_dict, random_mel
+    sd = random_state_dict(cfg['wseed'], mode=cfg['mode'])
+    mel = random_mel(cfg['mseed'], cfg['frames'])
+    m = O.pad_tensor(mel.T[None], 2, 'both')[0].T
+    mels_up, aux_up = O.upsample_network(sd, m)
+    aux = np.ascontiguousarray(aux_up[::275])
+    L = mels_up.shape[0]
+    if cfg['batched']:
+        B = O.num_folds(L, cfg['target'], cfg['overlap'])
+        T, stride = cfg['target'] + 2 * cfg['overlap'], cfg['target'] + cfg['overlap']
+    else:
+        B, T, stride = 1, L, 0
+    noise = O.draw_noise(cfg['seed'], cfg['mode'], B, T)
+    if cfg['mode'] == 'MOL':
+        flat = np.concatenate([noise[0].reshape(T, B * 10), noise[1].reshape(T, B)], axis=1)
+    else:
+        flat = noise
+    return sd, mel, mels_up, aux, (B, T, stride), noise, np.ascontiguousarray(flat, np.float32)
+
+
+def test_device_selftests(gpu):
+    from wavernn_amd import _lib
+    L = _lib.lib()
+    assert L.wrnn_abi_version() == 1
+    assert L.wrnn_device_cus(0) > 0
+    _lib.check(L.wrnn_selftest(0, 1), 'mfma selftest')
+    print(L.wrnn_last_error().decode())
+    _lib.check(L.wrnn_selftest(0, 2), 'all-gather selftest')
+    print(L.wrnn_last_error().decode())
+
+
+@pytest.mark.parametrize('algo', ['stream', 'persist'])
+@pytest.mark.parametrize('name', CASES)
+def test_loop_matches_reference_golden(gpu, name, algo):
+    """Free-running loop kernel vs the reference's own pre-decode [B,T] tensor (golden) and vs the C oracle."""
+    from oracle import c_oracle as C
+    from wavernn_amd.engine import LoopEngine
+    cfg, g = load_case(name)
+    sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
+    eng = LoopEngine(sd, cfg['mode'], device=gpu)
+    out = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
+                  torch.from_numpy(flat).to(gpu), 275, algo=algo).cpu().numpy()
+    assert eng.last_loop_kernel() == ('wrnn_persist_kernel' if algo == 'persist' else 'wrnn_stream_kernel')
+    mels_f, aux_f, _ = __import__('oracle.wavernn_oracle', fromlist=['x']).conditioning(sd, mel, cfg['batched'], cfg['target'], cfg['overlap'])
+    ref = C.loop(sd, cfg['mode'], mels_f, aux_f, noise)
+    if cfg['mode'] == 'RAW':
+        bad = np.argwhere(out != g['raw'])
+        assert bad.size == 0, f'first divergence at (b,t)={bad[0]} of {out.shape}'
+        assert np.array_equal(out, ref)
+    else:
+        assert np.abs(out - g['raw']).max() <= MOL_TOL, np.abs(out - g['raw']).max()
+        assert np.abs(out - ref).max() <= MOL_TOL
+
+
+@pytest.mark.parametrize('algo', ['stream', 'persist'])
+@pytest.mark.parametrize('name', ['raw_batched_60f', 'mol_batched_100f'])
+def test_teacher_forced_logits(gpu, name, algo):
+    """Feed the reference's samples back (teacher forcing) and compare every step's fc3 logits with the C
+    oracle run the same way: isolates kernel arithmetic from chaotic divergence.  Tolerance 1e-4 abs on O(1) logits."""
+    from oracle import c_oracle as C, wavernn_oracle as O
+    from wavernn_amd.engine import LoopEngine
+    cfg, g = load_case(name)
+    sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
+    mels_f, aux_f, _ = O.conditioning(sd, mel, cfg['batched'], cfg['target'], cfg['overlap'])
+    _, ref_logits = C.loop(sd, cfg['mode'], mels_f, aux_f, noise, want_logits=True)     # free run == golden path
+    eng = LoopEngine(sd, cfg['mode'], device=gpu)
+    out, logits = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
+                          torch.from_numpy(flat).to(gpu), 275, algo=algo, force_x=torch.from_numpy(g['raw']),
+                          want_logits=True)
+    err = np.abs(logits.cpu().numpy() - ref_logits).max()
+    assert err <= 1e-4, err
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_generate_end_to_end(gpu, name, tmp_path):
+    """`WaveRNN.generate()` drop-in (PyTorch-ROCm upsample + HIP loop + host unfold) vs the reference's returned
+    float64 waveform under the same `torch.manual_seed`."""
+    from wavernn_amd.model import WaveRNN
+    from wavernn_amd.synthetic import random_state_dict, random_mel, SHIPPED
+    cfg, g = load_case(name)
+    model = WaveRNN(**SHIPPED, mode=cfg['mode'])
+    sd = random_state_dict(cfg['wseed'], mode=cfg['mode'])
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(gpu)
+    mel = random_mel(cfg['mseed'], cfg['frames'])
+    torch.manual_seed(cfg['seed'])
+    wav = tmp_path / 'o.wav'
+    out = model.generate(torch.tensor(mel).unsqueeze(0), wav, cfg['batched'], cfg['target'], cfg['overlap'], cfg['mu_law'])
+    assert model.training and out.dtype == np.float64 and out.shape == g['out'].shape and wav.exists()
+    if cfg['mode'] == 'RAW':
+        assert np.array_equal(out, g['out']), f'{np.count_nonzero(out != g["out"])} samples differ'
+    else:
+        assert np.abs(out - g['out']).max() <= MOL_TOL
+    # generator side effect equals the reference's: the next CPU draw continues the same stream
+    from oracle import wavernn_oracle as O
+    B, T = g['raw'].shape
+    st = O.TorchCpuStream(cfg['seed'])
+    st.skip(O.gru_cell_ctor_draws() + (T * B * 11 if cfg['mode'] == 'MOL' else 2 * T * B * 512))
+    assert np.array_equal(torch.empty(4).uniform_(0, 1).numpy(), st.uniform_(4, 0, 1))
+
+
+@pytest.mark.parametrize('mode', ['MOL', 'RAW'])
+def test_full_size_properties(gpu, mode):
+    """BASELINE config 2 geometry (B=12, T=12100): persistent and stream kernels agree, runs are deterministic,
+    samples stay in [-1,1] (RAW: on the 512-level grid)."""
+    from wavernn_amd.engine import LoopEngine
+    from wavernn_amd.synthetic import random_state_dict
+    sd = random_state_dict(0, mode=mode)
+    rs = np.random.RandomState(3)
+    N, hop, target, overlap = 481, 275, 11000, 550
+    L = N * hop
+    B, T, stride = 12, target + 2 * overlap, target + overlap
+    mels_up = torch.from_numpy(rs.uniform(0, 1, (L, 80)).astype(np.float32)).to(gpu)
+    aux = torch.from_numpy(rs.uniform(-1, 1, (N, 128)).astype(np.float32)).to(gpu)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    if mode == 'MOL':
+        noise = torch.empty(T, 11 * B).uniform_(1e-5, 1 - 1e-5, generator=g).to(gpu)
+    else:
+        noise = torch.empty(T, B, 512).exponential_(1, generator=g).to(gpu)
+    eng = LoopEngine(sd, mode, device=gpu)
+    a = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='persist').cpu().numpy()
+    ms = eng.last_loop_ms()
+    b = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='persist').cpu().numpy()
+    s = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='stream').cpu().numpy()
+    print(f'{mode} persistent loop {ms:.1f} ms for {B}x{T} segment-steps; stream {eng.last_loop_ms():.1f} ms')
+    assert np.array_equal(a, b), 'persistent kernel is not deterministic'
+    assert np.abs(a).max() <= 1.0
+    if mode == 'RAW':
+        lv = (a + 1.0) * 511.0 / 2.0
+        assert np.abs(lv - np.round(lv)).max() < 1e-3
+        bad = np.argwhere(a != s)
+        assert bad.size == 0, f'persist vs stream first divergence at {bad[0]}'
+    else:
+        assert np.abs(a - s).max() <= MOL_TOL
+
+
+def test_product_fails_loudly_without_extension(gpu, monkeypatch):
+    from wavernn_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'SO_PATH', '/nonexistent/libwavernn_amd.so')
+    with pytest.raises(_lib.WrnnError):
+        _lib.lib()

@@ -1,0 +1,94 @@
+"""ctypes binding of libwavernn_amd.so (the C ABI declared in include/wavernn_amd.h).
+
+The library holds the HIP kernels; there is NO CPU fallback.  If the shared object is missing, or no HIP
+device is present, the product path raises -- loudly -- instead of computing anything on the host.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+SO_PATH = os.path.join(CSRC, 'libwavernn_amd.so')
+
+WRNN_OK = 0
+MODE_RAW, MODE_MOL = 0, 1
+ALGO_AUTO, ALGO_STREAM, ALGO_PERSIST = 0, 1, 2
+ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'persist': ALGO_PERSIST}
+
+#: every symbol include/wavernn_amd.h declares
+EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_create', 'wrnn_pack_destroy',
+           'wrnn_pack_weight_bytes', 'wrnn_workspace_bytes', 'wrnn_generate', 'wrnn_status', 'wrnn_last_loop_ms',
+           'wrnn_last_loop_kernel', 'wrnn_selftest', 'wrnn_selftest_metric']
+
+
+class Weights(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('rnn_dims', 'fc_dims', 'feat_dims', 'aux_dims', 'n_classes', 'mode')] + \
+               [(n, ctypes.c_void_p) for n in ('I_w', 'I_b', 'w_ih1', 'w_hh1', 'b_ih1', 'b_hh1', 'w_ih2', 'w_hh2',
+                                               'b_ih2', 'b_hh2', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'fc3_w', 'fc3_b')]
+
+
+class Geometry(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('B', 'T', 'stride', 'L', 'hop', 'n_frames')]
+
+
+class Debug(ctypes.Structure):
+    _fields_ = [('force_x', ctypes.c_void_p), ('logits', ctypes.c_void_p)]
+
+
+class WrnnError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 into csrc/libwavernn_amd.so (hipcc cross-compiles without a GPU)."""
+    cmd = [os.path.join(CSRC, 'build.sh')]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise WrnnError('building libwavernn_amd.so failed')
+    global _lib
+    _lib = None
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises WrnnError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise WrnnError(f'{SO_PATH} not found: run `python -c "import __graft_entry__ as g; g.build()"` '
+                        f'(or wavernn_amd/csrc/build.sh).  There is no CPU fallback.')
+    L = ctypes.CDLL(SO_PATH)
+    L.wrnn_last_error.restype = ctypes.c_char_p
+    L.wrnn_abi_version.restype = ctypes.c_int
+    L.wrnn_device_cus.argtypes = [ctypes.c_int]
+    L.wrnn_pack_create.argtypes = [ctypes.POINTER(Weights), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.wrnn_pack_destroy.argtypes = [ctypes.c_void_p]
+    L.wrnn_pack_destroy.restype = None
+    L.wrnn_pack_weight_bytes.argtypes = [ctypes.c_void_p]
+    L.wrnn_pack_weight_bytes.restype = ctypes.c_size_t
+    L.wrnn_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.POINTER(Geometry)]
+    L.wrnn_workspace_bytes.restype = ctypes.c_size_t
+    L.wrnn_generate.argtypes = [ctypes.c_void_p, ctypes.POINTER(Geometry), ctypes.c_void_p, ctypes.c_void_p,
+                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                ctypes.POINTER(Debug), ctypes.c_void_p]
+    L.wrnn_status.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.wrnn_last_loop_ms.argtypes = [ctypes.c_void_p]
+    L.wrnn_last_loop_ms.restype = ctypes.c_float
+    L.wrnn_last_loop_kernel.argtypes = [ctypes.c_void_p]
+    L.wrnn_last_loop_kernel.restype = ctypes.c_char_p
+    L.wrnn_selftest.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.wrnn_selftest_metric.restype = ctypes.c_float
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != WRNN_OK:
+        raise WrnnError(f'{what} failed (rc={rc}): {lib().wrnn_last_error().decode()}')

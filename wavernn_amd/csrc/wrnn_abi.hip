@@ -1,0 +1,335 @@
+// wrnn_abi.hip -- host side of the C ABI declared in include/wavernn_amd.h.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+
+#include "../../include/wavernn_amd.h"
+#include "wrnn_device.h"
+
+namespace wrnn {
+hipError_t launch_cond(const CondArgs &a, int n_cus, hipStream_t stream);
+hipError_t launch_stream(const LoopArgs &args, int mode, hipStream_t stream);
+hipError_t launch_persist(const LoopArgs &args, int U, int mode, hipStream_t stream);
+size_t persist_lds_bytes();
+int selftest_mfma(char *msg, size_t n);
+int selftest_allgather(int n_cus, char *msg, size_t n, float *us_per_round);
+}  // namespace wrnn
+
+using namespace wrnn;
+
+static thread_local char g_err[512] = "";
+static void set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return WRNN_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+struct wrnn_pack {
+    int device, n_cus, C, mode;
+    size_t weight_bytes;
+    char *dev;          // one allocation
+    size_t dev_bytes;
+    // device pointers into `dev`
+    const float *I_w0, *I_b, *I_cT;
+    const float *w_ih1, *w_hh1, *b_ih1, *b_hh1, *w_ih2, *w_hh2, *b_ih2, *b_hh2;
+    const float *fc1_w, *fc1_b, *fc2_w, *fc2_b, *fc3_w, *fc3_b;
+    const float *w_ih1T, *w_hh1T, *w_ih2T, *w_hh2T, *fc1T, *fc2T, *fc3T, *c2_wT, *c3_wT, *c4_wT;
+    hipEvent_t ev0, ev1;
+    bool timed;
+    const char *last_kernel;
+};
+
+extern "C" const char *wrnn_last_error(void) { return g_err; }
+extern "C" int wrnn_abi_version(void) { return WRNN_ABI_VERSION; }
+
+extern "C" int wrnn_device_cus(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) {
+        set_err("no HIP device %d (count %d)", device, n);
+        return WRNN_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return WRNN_ERR_NO_DEVICE;
+    return prop.multiProcessorCount;
+}
+
+namespace {
+struct Builder {
+    std::vector<float> host;
+    size_t add(const float *src, size_t n)
+    {
+        size_t off = (host.size() + 63) / 64 * 64;   // 256-byte alignment
+        host.resize(off + n);
+        if (src) memcpy(host.data() + off, src, n * sizeof(float));
+        return off;
+    }
+    // dst[k][r] = src[r][col0 + k], src is [rows][ld]
+    size_t add_T(const float *src, int rows, int ld, int col0, int ncols)
+    {
+        size_t off = add(nullptr, (size_t)ncols * rows);
+        float *d = host.data() + off;
+        for (int r = 0; r < rows; ++r)
+            for (int k = 0; k < ncols; ++k) d[(size_t)k * rows + r] = src[(size_t)r * ld + col0 + k];
+        return off;
+    }
+};
+}  // namespace
+
+extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **out)
+{
+    if (!w || !out) { set_err("NULL argument"); return WRNN_ERR_ARG; }
+    if (w->rnn_dims != H || w->fc_dims != H || w->feat_dims != MEL || w->aux_dims != AUX) {
+        set_err("this build supports rnn_dims=fc_dims=512, feat_dims=80, aux_dims=32 (got %d,%d,%d,%d)",
+                w->rnn_dims, w->fc_dims, w->feat_dims, w->aux_dims);
+        return WRNN_ERR_ARG;
+    }
+    const int C = w->n_classes;
+    if (w->mode == WRNN_MODE_MOL) {
+        if (C != 30) { set_err("MOL needs n_classes == 30"); return WRNN_ERR_ARG; }
+    } else if (w->mode == WRNN_MODE_RAW) {
+        if (C < 2 || C > H) { set_err("RAW needs 2 <= n_classes <= 512"); return WRNN_ERR_ARG; }
+    } else { set_err("unknown mode %d", w->mode); return WRNN_ERR_ARG; }
+    const float *const *ptrs = &w->I_w;
+    for (int i = 0; i < 16; ++i)
+        if (!ptrs[i]) { set_err("NULL weight pointer #%d", i); return WRNN_ERR_ARG; }
+    const int cus = wrnn_device_cus(device);
+    if (cus < 0) return cus;
+    HIPCHK(hipSetDevice(device));
+
+    const int KI = 1 + MEL + AUX, K2 = H + AUX;
+    Builder b;
+    std::vector<float> col0(H);
+    for (int r = 0; r < H; ++r) col0[r] = w->I_w[(size_t)r * KI];
+    const size_t o_I_w0 = b.add(col0.data(), H), o_I_b = b.add(w->I_b, H);
+    const size_t o_I_cT = b.add_T(w->I_w, H, KI, 1, KCOND);
+    const size_t o_w_ih1 = b.add(w->w_ih1, (size_t)3 * H * H), o_w_hh1 = b.add(w->w_hh1, (size_t)3 * H * H);
+    const size_t o_b_ih1 = b.add(w->b_ih1, 3 * H), o_b_hh1 = b.add(w->b_hh1, 3 * H);
+    const size_t o_w_ih2 = b.add(w->w_ih2, (size_t)3 * H * K2), o_w_hh2 = b.add(w->w_hh2, (size_t)3 * H * H);
+    const size_t o_b_ih2 = b.add(w->b_ih2, 3 * H), o_b_hh2 = b.add(w->b_hh2, 3 * H);
+    const size_t o_fc1_w = b.add(w->fc1_w, (size_t)H * K2), o_fc1_b = b.add(w->fc1_b, H);
+    const size_t o_fc2_w = b.add(w->fc2_w, (size_t)H * K2), o_fc2_b = b.add(w->fc2_b, H);
+    const size_t o_fc3_w = b.add(w->fc3_w, (size_t)C * H), o_fc3_b = b.add(w->fc3_b, C);
+    const size_t o_w_ih1T = b.add_T(w->w_ih1, 3 * H, H, 0, H), o_w_hh1T = b.add_T(w->w_hh1, 3 * H, H, 0, H);
+    const size_t o_w_ih2T = b.add_T(w->w_ih2, 3 * H, K2, 0, H), o_w_hh2T = b.add_T(w->w_hh2, 3 * H, H, 0, H);
+    const size_t o_fc1T = b.add_T(w->fc1_w, H, K2, 0, H), o_fc2T = b.add_T(w->fc2_w, H, K2, 0, H);
+    const size_t o_fc3T = b.add_T(w->fc3_w, C, H, 0, H);
+    const size_t o_c2_wT = b.add_T(w->w_ih2, 3 * H, K2, H, AUX);
+    const size_t o_c3_wT = b.add_T(w->fc1_w, H, K2, H, AUX), o_c4_wT = b.add_T(w->fc2_w, H, K2, H, AUX);
+    b.add(nullptr, 64);   // tail padding so vector loads past the last array stay inside the allocation
+
+    wrnn_pack *p = new wrnn_pack();
+    p->device = device; p->n_cus = cus; p->C = C; p->mode = w->mode;
+    p->dev_bytes = b.host.size() * sizeof(float);
+    // W of SURVEY.md section 8(d): every loop parameter the reference touches per step
+    p->weight_bytes = sizeof(float) * ((size_t)H * KI + H + 2 * ((size_t)3 * H * H) + (size_t)3 * H * K2 + (size_t)3 * H * H +
+                                       4 * 3 * H + 2 * ((size_t)H * K2 + H) + (size_t)C * H + C);
+    hipError_t e = hipMalloc((void **)&p->dev, p->dev_bytes);
+    if (e != hipSuccess) { set_err("hipMalloc(%zu) failed: %s", p->dev_bytes, hipGetErrorString(e)); delete p; return WRNN_ERR_HIP; }
+    e = hipMemcpy(p->dev, b.host.data(), p->dev_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_err("hipMemcpy failed: %s", hipGetErrorString(e)); hipFree(p->dev); delete p; return WRNN_ERR_HIP; }
+    const float *base = (const float *)p->dev;
+    p->I_w0 = base + o_I_w0; p->I_b = base + o_I_b; p->I_cT = base + o_I_cT;
+    p->w_ih1 = base + o_w_ih1; p->w_hh1 = base + o_w_hh1; p->b_ih1 = base + o_b_ih1; p->b_hh1 = base + o_b_hh1;
+    p->w_ih2 = base + o_w_ih2; p->w_hh2 = base + o_w_hh2; p->b_ih2 = base + o_b_ih2; p->b_hh2 = base + o_b_hh2;
+    p->fc1_w = base + o_fc1_w; p->fc1_b = base + o_fc1_b; p->fc2_w = base + o_fc2_w; p->fc2_b = base + o_fc2_b;
+    p->fc3_w = base + o_fc3_w; p->fc3_b = base + o_fc3_b;
+    p->w_ih1T = base + o_w_ih1T; p->w_hh1T = base + o_w_hh1T; p->w_ih2T = base + o_w_ih2T; p->w_hh2T = base + o_w_hh2T;
+    p->fc1T = base + o_fc1T; p->fc2T = base + o_fc2T; p->fc3T = base + o_fc3T;
+    p->c2_wT = base + o_c2_wT; p->c3_wT = base + o_c3_wT; p->c4_wT = base + o_c4_wT;
+    hipEventCreate(&p->ev0);
+    hipEventCreate(&p->ev1);
+    p->timed = false;
+    p->last_kernel = "";
+    *out = p;
+    return WRNN_OK;
+}
+
+extern "C" void wrnn_pack_destroy(wrnn_pack *p)
+{
+    if (!p) return;
+    hipEventDestroy(p->ev0);
+    hipEventDestroy(p->ev1);
+    hipFree(p->dev);
+    delete p;
+}
+
+extern "C" size_t wrnn_pack_weight_bytes(const wrnn_pack *p) { return p ? p->weight_bytes : 0; }
+
+namespace {
+struct WsLayout {
+    size_t status, gran, c2f, c3f, c4f, cI, total;
+};
+size_t al(size_t x) { return (x + 255) / 256 * 256; }
+WsLayout ws_layout(const wrnn_geometry *g)
+{
+    WsLayout l;
+    size_t o = 0;
+    l.status = o; o = al(o + STATUS_WORDS * sizeof(unsigned));
+    l.gran = o;   o = al(o + (size_t)NGRAN * SEG * H * sizeof(u64));
+    l.c2f = o;    o = al(o + (size_t)(g->n_frames + 1) * 3 * H * sizeof(float));
+    l.c3f = o;    o = al(o + (size_t)(g->n_frames + 1) * H * sizeof(float));
+    l.c4f = o;    o = al(o + (size_t)(g->n_frames + 1) * H * sizeof(float));
+    l.cI = o;     o = al(o + (size_t)g->T * g->B * H * sizeof(float));
+    l.total = o;
+    return l;
+}
+int check_geometry(const wrnn_geometry *g)
+{
+    if (!g) { set_err("NULL geometry"); return WRNN_ERR_ARG; }
+    if (g->B < 1 || g->T < 1 || g->L < 1 || g->hop < 1 || g->n_frames < 1 || g->stride < 0) {
+        set_err("bad geometry B=%d T=%d stride=%d L=%d hop=%d n_frames=%d", g->B, g->T, g->stride, g->L, g->hop, g->n_frames);
+        return WRNN_ERR_ARG;
+    }
+    if ((long)g->n_frames * g->hop < g->L) { set_err("n_frames*hop < L"); return WRNN_ERR_ARG; }
+    if ((double)g->B * g->stride + g->T > 2.0e9) { set_err("geometry overflows int32"); return WRNN_ERR_ARG; }
+    return WRNN_OK;
+}
+}  // namespace
+
+extern "C" size_t wrnn_workspace_bytes(const wrnn_pack *p, const wrnn_geometry *g)
+{
+    if (!p || check_geometry(g) != WRNN_OK) return 0;
+    return ws_layout(g).total;
+}
+
+extern "C" int wrnn_generate(const wrnn_pack *pc, const wrnn_geometry *g, const float *mels_up, const float *aux,
+                             const float *noise, float *out, void *workspace, size_t workspace_bytes, int algo,
+                             const wrnn_debug *dbg, void *stream_)
+{
+    wrnn_pack *p = const_cast<wrnn_pack *>(pc);
+    if (!p || !mels_up || !aux || !noise || !out || !workspace) { set_err("NULL argument"); return WRNN_ERR_ARG; }
+    int rc = check_geometry(g);
+    if (rc != WRNN_OK) return rc;
+    const WsLayout l = ws_layout(g);
+    if (workspace_bytes < l.total) { set_err("workspace %zu < required %zu", workspace_bytes, l.total); return WRNN_ERR_WORKSPACE; }
+    if (((uintptr_t)workspace & 255) != 0) { set_err("workspace must be 256-byte aligned"); return WRNN_ERR_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipSetDevice(p->device));
+    char *ws = (char *)workspace;
+
+    HIPCHK(hipMemsetAsync(ws + l.status, 0, STATUS_WORDS * sizeof(unsigned), stream));
+
+    CondArgs c;
+    c.mels_up = mels_up; c.aux = aux; c.I_cT = p->I_cT; c.I_b = p->I_b; c.c2_wT = p->c2_wT; c.b_ih2 = p->b_ih2;
+    c.c3_wT = p->c3_wT; c.fc1_b = p->fc1_b; c.c4_wT = p->c4_wT; c.fc2_b = p->fc2_b;
+    c.cI = (float *)(ws + l.cI); c.c2f = (float *)(ws + l.c2f); c.c3f = (float *)(ws + l.c3f); c.c4f = (float *)(ws + l.c4f);
+    c.B = g->B; c.T = g->T; c.stride = g->stride; c.L = g->L; c.hop = g->hop; c.NF = g->n_frames;
+    HIPCHK(launch_cond(c, p->n_cus, stream));
+
+    LoopArgs a;
+    memset(&a, 0, sizeof a);
+    a.I_w0 = p->I_w0; a.w_ih1 = p->w_ih1; a.w_hh1 = p->w_hh1; a.b_ih1 = p->b_ih1; a.b_hh1 = p->b_hh1;
+    a.w_ih2 = p->w_ih2; a.w_hh2 = p->w_hh2; a.b_hh2 = p->b_hh2; a.fc1_w = p->fc1_w; a.fc2_w = p->fc2_w;
+    a.fc3_w = p->fc3_w; a.fc3_b = p->fc3_b;
+    a.w_ih1T = p->w_ih1T; a.w_hh1T = p->w_hh1T; a.w_ih2T = p->w_ih2T; a.w_hh2T = p->w_hh2T;
+    a.fc1T = p->fc1T; a.fc2T = p->fc2T; a.fc3T = p->fc3T;
+    a.cI = c.cI; a.c2f = c.c2f; a.c3f = c.c3f; a.c4f = c.c4f;
+    a.noise = noise; a.force_x = dbg ? dbg->force_x : nullptr; a.out = out; a.dbg_logits = dbg ? dbg->logits : nullptr;
+    a.gran = (u64 *)(ws + l.gran); a.status = (unsigned *)(ws + l.status);
+    a.Btot = g->B; a.T = g->T; a.stride = g->stride; a.L = g->L; a.hop = g->hop; a.NF = g->n_frames; a.C = p->C;
+
+    // kernel choice
+    int U = 0;
+    const char *envu = getenv("WRNN_PERSIST_U");
+    if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_PERSIST) {
+        const bool shape_ok = (p->mode == WRNN_MODE_MOL) || (p->C == H);
+        if (shape_ok) {
+            if (envu && (atoi(envu) == 2 || atoi(envu) == 4)) U = atoi(envu);
+            else if (p->n_cus >= H / 2) U = 2;
+            else if (p->n_cus >= H / 4) U = 4;
+        }
+        if (U != 0 && p->n_cus < H / U) U = 0;
+        if (U == 0 && algo == WRNN_ALGO_PERSIST) {
+            set_err("persistent kernel needs >= 128 CUs and (MOL or RAW with 512 classes); device has %d CUs, C=%d", p->n_cus, p->C);
+            return WRNN_ERR_RESIDENCY;
+        }
+    } else if (algo != WRNN_ALGO_STREAM) { set_err("unknown algo %d", algo); return WRNN_ERR_ARG; }
+
+    HIPCHK(hipEventRecord(p->ev0, stream));
+    if (U != 0) {
+        p->last_kernel = "wrnn_persist_kernel";
+        for (int b0 = 0; b0 < g->B; b0 += SEG) {
+            a.b0 = b0;
+            a.nb = (g->B - b0 < SEG) ? (g->B - b0) : SEG;
+            HIPCHK(hipMemsetAsync(ws + l.gran, 0, (size_t)NGRAN * SEG * H * sizeof(u64), stream));
+            hipError_t e = launch_persist(a, U, p->mode, stream);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                if (algo == WRNN_ALGO_AUTO && b0 == 0) {
+                    fprintf(stderr, "[wavernn_amd] persistent launch refused (%s); using the stream kernel\n", hipGetErrorString(e));
+                    U = 0;
+                    break;
+                }
+                set_err("persistent cooperative launch failed: %s", hipGetErrorString(e));
+                return e == hipErrorCooperativeLaunchTooLarge ? WRNN_ERR_RESIDENCY : WRNN_ERR_HIP;
+            }
+        }
+    }
+    if (U == 0) {
+        p->last_kernel = "wrnn_stream_kernel";
+        a.b0 = 0;
+        a.nb = g->B;
+        HIPCHK(launch_stream(a, p->mode, stream));
+    }
+    HIPCHK(hipEventRecord(p->ev1, stream));
+    p->timed = true;
+    return WRNN_OK;
+}
+
+extern "C" int wrnn_status(void *workspace, void *stream)
+{
+    if (!workspace) { set_err("NULL workspace"); return WRNN_ERR_ARG; }
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    unsigned st[STATUS_WORDS];
+    HIPCHK(hipMemcpy(st, workspace, sizeof st, hipMemcpyDeviceToHost));
+    if (st[0] != 0 || st[1] != 0) {
+        set_err("loop kernel gave up: code 0x%x (layer %u) workgroup %u step %u thread %u", st[1], st[1] & 0xff, st[2], st[3], st[4]);
+        return WRNN_ERR_KERNEL;
+    }
+    return WRNN_OK;
+}
+
+extern "C" float wrnn_last_loop_ms(const wrnn_pack *p)
+{
+    if (!p || !p->timed) return -1.f;
+    if (hipEventSynchronize(p->ev1) != hipSuccess) return -1.f;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, p->ev0, p->ev1) != hipSuccess) return -1.f;
+    return ms;
+}
+
+extern "C" const char *wrnn_last_loop_kernel(const wrnn_pack *p) { return p ? p->last_kernel : ""; }
+
+static float g_selftest_metric = -1.f;
+extern "C" float wrnn_selftest_metric(void) { return g_selftest_metric; }
+
+extern "C" int wrnn_selftest(int device, int which)
+{
+    const int cus = wrnn_device_cus(device);
+    if (cus < 0) return cus;
+    HIPCHK(hipSetDevice(device));
+    char msg[400] = "";
+    int rc;
+    if (which == 1) rc = selftest_mfma(msg, sizeof msg);
+    else if (which == 2) rc = selftest_allgather(cus, msg, sizeof msg, &g_selftest_metric);
+    else { set_err("unknown selftest %d", which); return WRNN_ERR_ARG; }
+    if (rc != 0) { set_err("selftest %d failed: %s", which, msg); return WRNN_ERR_KERNEL; }
+    set_err("selftest %d ok: %s", which, msg);
+    return WRNN_OK;
+}

@@ -1,0 +1,95 @@
+// wrnn_cond.hip -- hoisted conditioning projections (run once per generate call, before the loop).
+//
+// In the reference every step concatenates conditioning onto the recurrent input and multiplies the whole
+// thing (fatchord_version.py:208-209, :213-214, :217-218, :220-221).  The conditioning columns of those four
+// matrices do not depend on the recurrence, so they are computed here for all steps / frames:
+//   cI [T][B][H]   = I.bias + I.weight[:,1:81] . m_t + I.weight[:,81:113] . a1_t         (per sample)
+//   c2f[NF+1][3H]  = rnn2.bias_ih + rnn2.weight_ih[:,H:H+A] . a2                          (per FRAME)
+//   c3f[NF+1][H]   = fc1.bias + fc1.weight[:,H:H+A] . a3 ;  c4f likewise with fc2 / a4
+// aux is constant over a mel frame (Stretch2d, :57-61,:84), so c2f/c3f/c4f are frame tables; row NF is the
+// zero-conditioning row the fold's zero padding selects (:326-330).  The fold itself (:336-338) is never
+// materialised: segment b, step t reads position p = b*stride + t.
+#include "wrnn_device.h"
+
+namespace wrnn {
+
+
+constexpr int CR = 8;   // (t,b) rows per iteration
+
+// thread r owns output row r of the I layer and keeps its 112 weights in VGPRs; the 112-long conditioning
+// vectors of CR (t,b) rows are staged in LDS and broadcast-read (ds_read_b128).
+__global__ __launch_bounds__(H) void wrnn_cond_sample_kernel(const CondArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float in[CR][KCOND];
+    const int r = threadIdx.x;
+    float wreg[KCOND];
+#pragma unroll
+    for (int k = 0; k < KCOND; ++k) wreg[k] = a.I_cT[k * H + r];
+    const float bias = a.I_b[r];
+    const long rows = (long)a.T * a.B;
+    for (long base = (long)blockIdx.x * CR; base < rows; base += (long)gridDim.x * CR) {
+        __syncthreads();
+        for (int q = r; q < CR * KCOND; q += H) {
+            const int rr = q / KCOND, k = q % KCOND;
+            const long row = base + rr;
+            float val = 0.f;
+            if (row < rows) {
+                const int t = (int)(row / a.B), b = (int)(row % a.B);
+                const int p = b * a.stride + t;
+                if (p < a.L) val = (k < MEL) ? a.mels_up[(size_t)p * MEL + k] : a.aux[(size_t)(p / a.hop) * 4 * AUX + (k - MEL)];
+            }
+            in[rr][k] = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < CR; ++rr) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < KCOND; k += 4) {
+                const float4 x = *reinterpret_cast<const float4 *>(&in[rr][k]);
+                acc = fmaf(wreg[k + 0], x.x, acc);
+                acc = fmaf(wreg[k + 1], x.y, acc);
+                acc = fmaf(wreg[k + 2], x.z, acc);
+                acc = fmaf(wreg[k + 3], x.w, acc);
+            }
+            if (base + rr < rows) a.cI[(size_t)(base + rr) * H + r] = acc + bias;
+        }
+    }
+}
+
+// one block per frame (block NF = zero-conditioning row)
+__global__ __launch_bounds__(H) void wrnn_cond_frame_kernel(const CondArgs a)
+{
+    __shared__ float ax[4 * AUX];
+    const int f = blockIdx.x, r = threadIdx.x;
+    if (r < 4 * AUX) ax[r] = (f < a.NF) ? a.aux[(size_t)f * 4 * AUX + r] : 0.f;
+    __syncthreads();
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, y3 = 0.f, y4 = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < AUX; ++k) {
+        g0 = fmaf(a.c2_wT[k * 3 * H + r], ax[AUX + k], g0);
+        g1 = fmaf(a.c2_wT[k * 3 * H + H + r], ax[AUX + k], g1);
+        g2 = fmaf(a.c2_wT[k * 3 * H + 2 * H + r], ax[AUX + k], g2);
+        y3 = fmaf(a.c3_wT[k * H + r], ax[2 * AUX + k], y3);
+        y4 = fmaf(a.c4_wT[k * H + r], ax[3 * AUX + k], y4);
+    }
+    a.c2f[(size_t)f * 3 * H + r] = g0 + a.b_ih2[r];
+    a.c2f[(size_t)f * 3 * H + H + r] = g1 + a.b_ih2[H + r];
+    a.c2f[(size_t)f * 3 * H + 2 * H + r] = g2 + a.b_ih2[2 * H + r];
+    a.c3f[(size_t)f * H + r] = y3 + a.fc1_b[r];
+    a.c4f[(size_t)f * H + r] = y4 + a.fc2_b[r];
+}
+
+hipError_t launch_cond(const CondArgs &a, int n_cus, hipStream_t stream)
+{
+    hipLaunchKernelGGL(wrnn_cond_frame_kernel, dim3(a.NF + 1), dim3(H), 0, stream, a);
+    const long rows = (long)a.T * a.B;
+    long blocks = (rows + CR - 1) / CR;
+    const long cap = (long)n_cus * 4;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wrnn_cond_sample_kernel, dim3((unsigned)blocks), dim3(H), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace wrnn

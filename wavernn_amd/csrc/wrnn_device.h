@@ -1,0 +1,235 @@
+// wrnn_device.h -- shared device-side definitions of the MI355X (gfx950) WaveRNN loop kernels.
+//
+// The arithmetic restated here is the reference's per-step dataflow (fatchord/WaveRNN
+// models/fatchord_version.py:203-237, utils/distribution.py:102-121, ATen gru_cell); see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wrnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+constexpr int H = 512;        // rnn_dims == fc_dims (this build)
+constexpr int MEL = 80;       // feat_dims
+constexpr int AUX = 32;       // aux_dims = res_out_dims / 4
+constexpr int KCOND = MEL + AUX;   // conditioning inputs of the I layer (112)
+constexpr int SEG = 16;       // segments per persistent launch group (= MFMA N)
+constexpr int LDA = 516;      // padded row stride (floats) of the LDS activation tiles
+constexpr int NGRAN = 5;      // granule buffers: h1, h2, y1, y2, (RAW) logits
+constexpr int STATUS_WORDS = 16;
+
+// Everything the loop kernels read.  All pointers are device pointers.
+struct LoopArgs {
+    // raw row-major weights (persistent kernel gathers its MFMA A-fragments from these once)
+    const float *I_w0;                  // [H]            column 0 of I.weight (the x_{t-1} tap)
+    const float *w_ih1, *w_hh1;         // [3H,H]
+    const float *b_ih1, *b_hh1;         // [3H]
+    const float *w_ih2;                 // [3H,H+AUX] (only the first H columns are used in-loop)
+    const float *w_hh2;                 // [3H,H]
+    const float *b_hh2;                 // [3H]   (b_ih2 is folded into c2f)
+    const float *fc1_w, *fc2_w;         // [H,H+AUX]
+    const float *fc3_w, *fc3_b;         // [C,H], [C]
+    // k-major (transposed) copies for the stream kernel: [K][rows]
+    const float *w_ih1T, *w_hh1T, *w_ih2T, *w_hh2T;   // [H][3H]
+    const float *fc1T, *fc2T;                         // [H][H]
+    const float *fc3T;                                // [H][C]
+    // hoisted conditioning (wrnn_cond kernels)
+    const float *cI;                    // [T][Btot][H]   b_I + W_I[:,1:] . [m_t, a1_t]
+    const float *c2f, *c3f, *c4f;       // [NF+1][3H], [NF+1][H], [NF+1][H]  per-frame aux projections + bias
+    const float *noise;                 // MOL [T][11*Btot]; RAW [T][Btot][C]
+    const float *force_x;               // optional [Btot][T]
+    float *out;                         // [Btot][T]
+    float *dbg_logits;                  // optional [T][Btot][C]
+    u64 *gran;                          // [NGRAN][SEG][H] {tag,value} granules (persistent kernel)
+    unsigned *status;                   // [STATUS_WORDS]: 0 abort flag, 1 code, 2 wg, 3 step, 4 detail
+    int Btot, b0, nb, T, stride, L, hop, NF, C;
+};
+
+
+// arguments of the hoisted-conditioning kernels (wrnn_cond.hip)
+struct CondArgs {
+    const float *mels_up;   // [L][MEL]
+    const float *aux;       // [NF][4*AUX]
+    const float *I_cT;      // [KCOND][H]   transposed I.weight[:,1:]
+    const float *I_b;       // [H]
+    const float *c2_wT;     // [AUX][3H]    transposed rnn2.weight_ih[:,H:]
+    const float *b_ih2;     // [3H]
+    const float *c3_wT, *fc1_b;   // [AUX][H], [H]
+    const float *c4_wT, *fc2_b;   // [AUX][H], [H]
+    float *cI, *c2f, *c3f, *c4f;
+    int B, T, stride, L, hop, NF;
+};
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ATen CPU gru_cell algebra (what nn.GRUCell runs at fatchord_version.py:210,214):
+// r = sig(gh_r + gi_r), z = sig(gh_z + gi_z), n = tanh(gi_n + gh_n * r), h' = (h - n) * z + n
+__device__ __forceinline__ float gru_update(float gi_r, float gi_z, float gi_n, float gh_r, float gh_z,
+                                            float gh_n, float h)
+{
+    const float r = sigmoid_f(gh_r + gi_r);
+    const float z = sigmoid_f(gh_z + gi_z);
+    const float n = tanhf(gi_n + gh_n * r);
+    return (h - n) * z + n;
+}
+
+// utils/distribution.py:106-108  logit_probs - log(-log(u))
+__device__ __forceinline__ float mol_gumbel(float lp, float u) { return lp - logf(-logf(u)); }
+
+// utils/distribution.py:113-121  x = clamp(mean + exp(max(ls, ln 1e-14)) * (log u - log(1-u)), -1, 1)
+__device__ __forceinline__ float mol_sample(float mean, float ls, float u)
+{
+    const float lsmin = -32.23619130191664f;   // float(np.log(1e-14))
+    ls = fmaxf(ls, lsmin);
+    float x = mean + expf(ls) * (logf(u) - logf(1.0f - u));
+    x = fmaxf(x, -1.0f);
+    return fminf(x, 1.0f);
+}
+
+// frame of conditioning position p (Stretch2d repeats each frame `hop` times; p >= L is the fold's zero pad)
+__device__ __forceinline__ int cond_frame(int b, int t, int stride, int L, int hop, int NF)
+{
+    const int p = b * stride + t;
+    return (p < L) ? (p / hop) : NF;
+}
+
+__device__ __forceinline__ u64 ld_agent(const u64 *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(u64 *p, u64 v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ld_agent32(const unsigned *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// record the first failure and raise the abort flag every spinning workgroup polls
+__device__ __forceinline__ void report_failure(unsigned *status, unsigned code, unsigned wg, unsigned step,
+                                               unsigned detail)
+{
+    if (atomicCAS(status + 1, 0u, code) == 0u) {
+        status[2] = wg;
+        status[3] = step;
+        status[4] = detail;
+    }
+    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MFMA building blocks (v_mfma_f32_16x16x4_f32: exact f32, D = A(16x4) * B(4x16) + C).
+// Lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; D reg v holds D[(l>>4)*4+v][l&15].
+// A workgroup is NW = 4 waves (one per SIMD, so each wave may keep up to 512 VGPRs); wave w owns the
+// K chunk [128w, 128w+128): 32 MFMAs per tile.  A fragments (weights) live in VGPRs for the whole kernel;
+// B fragments (activations, [seg][k] rows of stride LDA in LDS) are read with ds_read_b128: lane reads
+// act[j][kbase + 16r + 4(l>>4) .. +3], r = 0..7, so MFMA (r,e) contracts k = kbase + 16r + 4(l>>4) + e.
+// Two accumulators (even / odd r) hide the 40-cycle dependent-accumulator latency behind the 32-cycle issue.
+// ---------------------------------------------------------------------------------------------------
+constexpr int NW = 4;               // waves per workgroup
+constexpr int NT = NW * 64;         // threads per workgroup; thread tid owns activation columns 2tid, 2tid+1
+constexpr int KCH = H / NW;         // K chunk per wave (128)
+constexpr int AF = KCH / 4;         // A-fragment registers per tile (32)
+
+__device__ __forceinline__ void load_afrag(float (&a)[AF], const float *W, int ld, int row, bool valid,
+                                           int kbase_lane /* = KCH*w + 4*(l>>4) */)
+{
+#pragma unroll
+    for (int r = 0; r < AF / 4; ++r) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) v = *reinterpret_cast<const float4 *>(W + (size_t)row * ld + kbase_lane + 16 * r);
+        a[4 * r + 0] = v.x; a[4 * r + 1] = v.y; a[4 * r + 2] = v.z; a[4 * r + 3] = v.w;
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma_tile(const float (&a)[AF], const float *act_lane /* act + j*LDA + kbase_lane */)
+{
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < AF / 4; r += 2) {
+        const float4 b0 = *reinterpret_cast<const float4 *>(act_lane + 16 * r);
+        const float4 b1 = *reinterpret_cast<const float4 *>(act_lane + 16 * (r + 1));
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 0], b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 4], b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 1], b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 5], b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 2], b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 6], b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 3], b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 7], b1.w, acc1, 0, 0, 0);
+    }
+    return acc0 + acc1;
+}
+
+// partial tile of wave w -> part[(w*2+slot)*256 + i*16 + j]
+__device__ __forceinline__ void store_partial(float *part, int w, int slot, int lane, f32x4 acc)
+{
+    float *p = part + (w * 2 + slot) * 256 + ((lane >> 4) * 4) * 16 + (lane & 15);
+    p[0] = acc[0]; p[16] = acc[1]; p[32] = acc[2]; p[48] = acc[3];
+}
+
+__device__ __forceinline__ float reduce_partial(const float *part, int slot, int i, int j)
+{
+    float s = part[(0 * 2 + slot) * 256 + i * 16 + j];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s += part[(w * 2 + slot) * 256 + i * 16 + j];
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Inter-workgroup exchange: 8-byte {f32 value, tag} granules (value in the low dword), ONE relaxed
+// agent-scope (sc1, write-through) store per granule, sc1 polling loads, no fences (MI355X guide,
+// Guideline 16 form R2: the data is its own flag).  Layout per layer: G[seg][hidden index], 4 KB per segment.
+// Sweep: thread tid = (row r = tid>>4, c = tid&15) reads the whole row r of the layer with 16
+// buffer_load_dwordx4 sc1 (SGPR descriptor + one VGPR offset + immediates; lanes c = 0..15 cover 256
+// contiguous bytes per load), i.e. granule pairs (i*16+c)*2, +1 for i = 0..15, and writes the values to the
+// same columns of an LDS tile row.  Bounded spin; every 8-byte half carries its own tag.
+// ---------------------------------------------------------------------------------------------------
+constexpr unsigned SPIN_LIMIT = 4000000u;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ void publish(u64 *G, unsigned tag, int j, int k, float val)
+{
+    st_agent(G + j * H + k, ((u64)tag << 32) | (u64)__float_as_uint(val));
+}
+
+// column (float index) of piece i owned by thread-in-row c: 2 floats
+__device__ __forceinline__ int own_col(int i, int c) { return (i * 16 + c) * 2; }
+
+__device__ __forceinline__ bool sweep(__amdgpu_buffer_rsrc_t rs, int layer, unsigned tag, int nb, int tid,
+                                      float *dst, unsigned *status)
+{
+    const int r = tid >> 4, c = tid & 15;
+    if (r >= nb) return true;
+    const int voff = r * (H * 8) + c * 16;
+    const int soff = layer * (SEG * H * 8);
+    u32x4 x[16];
+    unsigned spins = 0;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * 256, soff, 16 /* sc1 */);
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ok &= (x[i].y == tag) & (x[i].w == tag);
+        if (ok) break;
+        ++spins;
+        if ((spins & 255u) == 0u) {
+            if (spins > SPIN_LIMIT || ld_agent32(status) != 0u) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        *reinterpret_cast<float2 *>(dst + r * LDA + own_col(i, c)) = make_float2(__uint_as_float(x[i].x), __uint_as_float(x[i].z));
+    return true;
+}
+
+}  // namespace wrnn

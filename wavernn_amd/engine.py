@@ -1,0 +1,110 @@
+"""LoopEngine: the Python face of the C ABI for the autoregressive loop (include/wavernn_amd.h).
+
+PyTorch is used only for device memory and streams; all computation happens in libwavernn_amd.so.
+"""
+import ctypes
+import numpy as np
+import torch
+
+from . import _lib
+
+LOOP_KEYS = dict(I_w='I.weight', I_b='I.bias', w_ih1='rnn1.weight_ih_l0', w_hh1='rnn1.weight_hh_l0',
+                 b_ih1='rnn1.bias_ih_l0', b_hh1='rnn1.bias_hh_l0', w_ih2='rnn2.weight_ih_l0', w_hh2='rnn2.weight_hh_l0',
+                 b_ih2='rnn2.bias_ih_l0', b_hh2='rnn2.bias_hh_l0', fc1_w='fc1.weight', fc1_b='fc1.bias',
+                 fc2_w='fc2.weight', fc2_b='fc2.bias', fc3_w='fc3.weight', fc3_b='fc3.bias')
+
+
+def _as_host_f32(v):
+    if isinstance(v, torch.Tensor):
+        v = v.detach().to('cpu', torch.float32).numpy()
+    return np.ascontiguousarray(v, dtype=np.float32)
+
+
+class LoopEngine:
+    """Device-resident weight pack + `run()` = one call of `wrnn_generate`.
+
+    state_dict: mapping with the reference's loop keys (LOOP_KEYS values), torch tensors or numpy arrays.
+    """
+
+    def __init__(self, state_dict, mode, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.WrnnError('wavernn_amd needs a HIP device (torch.cuda.is_available() is False); '
+                                 'there is no CPU fallback')
+        self.lib = _lib.lib()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.mode = mode
+        host = {k: _as_host_f32(state_dict[v]) for k, v in LOOP_KEYS.items()}
+        w = _lib.Weights()
+        w.rnn_dims = host['w_hh1'].shape[1]
+        w.fc_dims = host['fc1_w'].shape[0]
+        w.aux_dims = host['w_ih2'].shape[1] - w.rnn_dims
+        w.feat_dims = host['I_w'].shape[1] - 1 - w.aux_dims
+        w.n_classes = host['fc3_w'].shape[0]
+        if mode not in ('RAW', 'MOL'):
+            raise RuntimeError("Unknown model mode value - ", mode)
+        w.mode = _lib.MODE_MOL if mode == 'MOL' else _lib.MODE_RAW
+        for k, a in host.items():
+            setattr(w, k, a.ctypes.data)
+        self.n_classes = int(w.n_classes)
+        self.feat_dims, self.aux_dims = int(w.feat_dims), int(w.aux_dims)
+        pack = ctypes.c_void_p()
+        _lib.check(self.lib.wrnn_pack_create(ctypes.byref(w), self.device.index or 0, ctypes.byref(pack)), 'wrnn_pack_create')
+        self._pack = pack
+        self._ws = None
+        self.n_cus = self.lib.wrnn_device_cus(self.device.index or 0)
+
+    def __del__(self):
+        try:
+            if getattr(self, '_pack', None):
+                self.lib.wrnn_pack_destroy(self._pack)
+                self._pack = None
+        except Exception:
+            pass
+
+    @property
+    def weight_bytes(self):
+        return int(self.lib.wrnn_pack_weight_bytes(self._pack))
+
+    def run(self, mels_up, aux, B, T, stride, noise, hop, algo='auto', force_x=None, want_logits=False, check=True):
+        """mels_up (L,feat) / aux (n_frames,4*aux_dims) / noise: float32 CUDA tensors.  Returns out (B,T) CUDA
+        [and logits (T,B,C)].  Enqueues on the current stream; `check=True` synchronises and raises if a kernel
+        gave up."""
+        for name, t_ in (('mels_up', mels_up), ('aux', aux), ('noise', noise)):
+            if not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()):
+                raise ValueError(f'{name} must be a contiguous float32 CUDA tensor')
+        L = mels_up.shape[0]
+        if mels_up.shape[1] != self.feat_dims or aux.shape[1] != 4 * self.aux_dims:
+            raise ValueError('conditioning shape mismatch')
+        need = T * 11 * B if self.mode == 'MOL' else T * B * self.n_classes
+        if noise.numel() != need:
+            raise ValueError(f'noise has {noise.numel()} elements, expected {need}')
+        g = _lib.Geometry(B, T, stride, L, hop, aux.shape[0])
+        nbytes = int(self.lib.wrnn_workspace_bytes(self._pack, ctypes.byref(g)))
+        if nbytes == 0:
+            raise _lib.WrnnError('bad geometry: ' + self.lib.wrnn_last_error().decode())
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        out = torch.empty(B, T, dtype=torch.float32, device=self.device)
+        dbg = _lib.Debug(None, None)
+        logits = None
+        if force_x is not None:
+            force_x = force_x.to(self.device, torch.float32).contiguous()
+            assert force_x.shape == (B, T)
+            dbg.force_x = force_x.data_ptr()
+        if want_logits:
+            logits = torch.empty(T, B, self.n_classes, dtype=torch.float32, device=self.device)
+            dbg.logits = logits.data_ptr()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.wrnn_generate(self._pack, ctypes.byref(g), mels_up.data_ptr(), aux.data_ptr(), noise.data_ptr(),
+                                    out.data_ptr(), self._ws.data_ptr(), nbytes, _lib.ALGOS[algo], ctypes.byref(dbg), stream)
+        _lib.check(rc, 'wrnn_generate')
+        if check:
+            _lib.check(self.lib.wrnn_status(self._ws.data_ptr(), stream), 'loop kernel')
+        return (out, logits) if want_logits else out
+
+    def last_loop_ms(self):
+        return float(self.lib.wrnn_last_loop_ms(self._pack))
+
+    def last_loop_kernel(self):
+        return self.lib.wrnn_last_loop_kernel(self._pack).decode()

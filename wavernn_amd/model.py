@@ -1,0 +1,243 @@
+"""`WaveRNN`: drop-in for the reference class of the same name (fatchord/WaveRNN models/fatchord_version.py:92-435)
+whose `generate()` runs the per-sample loop on the MI355X-native kernels.
+
+Same constructor signature, same parameter / buffer names (so the reference's `.pyt` checkpoints load with
+`load()`), same `generate(mels, save_path, batched, target, overlap, mu_law) -> np.ndarray[float64]`
+contract and side effects (eval at entry, train at exit, RNG consumption, WAV written).  What differs:
+the loop (reference :192-245) is ONE call into libwavernn_amd.so, conditioning is never folded in memory, and
+the model must live on a HIP device -- there is no CPU path here (use the reference for that).
+"""
+from pathlib import Path
+from typing import Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import fold as _fold
+from .dsp import save_wav
+from .engine import LoopEngine, LOOP_KEYS
+from .rng import draw_noise
+
+
+class ResBlock(nn.Module):
+    """1x1 conv -> BN -> ReLU -> 1x1 conv -> BN, plus skip (reference :13-28)."""
+
+    def __init__(self, dims):
+        super().__init__()
+        self.conv1 = nn.Conv1d(dims, dims, kernel_size=1, bias=False)
+        self.conv2 = nn.Conv1d(dims, dims, kernel_size=1, bias=False)
+        self.batch_norm1 = nn.BatchNorm1d(dims)
+        self.batch_norm2 = nn.BatchNorm1d(dims)
+
+    def forward(self, x):
+        y = F.relu(self.batch_norm1(self.conv1(x)))
+        return x + self.batch_norm2(self.conv2(y))
+
+
+class MelResNet(nn.Module):
+    """k=2*pad+1 conv (no padding) -> BN -> ReLU -> res blocks -> 1x1 conv (reference :31-48)."""
+
+    def __init__(self, res_blocks, in_dims, compute_dims, res_out_dims, pad):
+        super().__init__()
+        self.conv_in = nn.Conv1d(in_dims, compute_dims, kernel_size=2 * pad + 1, bias=False)
+        self.batch_norm = nn.BatchNorm1d(compute_dims)
+        self.layers = nn.ModuleList([ResBlock(compute_dims) for _ in range(res_blocks)])
+        self.conv_out = nn.Conv1d(compute_dims, res_out_dims, kernel_size=1)
+
+    def forward(self, x):
+        x = F.relu(self.batch_norm(self.conv_in(x)))
+        for layer in self.layers:
+            x = layer(x)
+        return self.conv_out(x)
+
+
+class Stretch2d(nn.Module):
+    """nearest-neighbour repeat along width (x_scale) and height (y_scale) (reference :51-61)."""
+
+    def __init__(self, x_scale, y_scale):
+        super().__init__()
+        self.x_scale, self.y_scale = x_scale, y_scale
+
+    def forward(self, x):
+        return x.repeat_interleave(self.y_scale, dim=2).repeat_interleave(self.x_scale, dim=3)
+
+
+class UpsampleNetwork(nn.Module):
+    """aux = MelResNet(m) repeated hop times; mel = 3 x (repeat by s, box FIR of 2s+1 taps), trimmed (reference :64-89)."""
+
+    def __init__(self, feat_dims, upsample_scales, compute_dims, res_blocks, res_out_dims, pad):
+        super().__init__()
+        self.total_scale = int(np.prod(upsample_scales))
+        self.indent = pad * self.total_scale
+        self.resnet = MelResNet(res_blocks, feat_dims, compute_dims, res_out_dims, pad)
+        self.resnet_stretch = Stretch2d(self.total_scale, 1)
+        self.up_layers = nn.ModuleList()
+        for scale in upsample_scales:
+            conv = nn.Conv2d(1, 1, kernel_size=(1, 2 * scale + 1), padding=(0, scale), bias=False)
+            conv.weight.data.fill_(1. / (2 * scale + 1))
+            self.up_layers.append(Stretch2d(scale, 1))
+            self.up_layers.append(conv)
+
+    def aux_frames(self, m):
+        """(b, feat, N+2*pad) -> (b, res_out, N): the frame-rate aux features, before Stretch2d."""
+        return self.resnet(m)
+
+    def upsample_mel(self, m):
+        """(b, feat, N+2*pad) -> (b, N*hop, feat)."""
+        m = m.unsqueeze(1)
+        for f in self.up_layers:
+            m = f(m)
+        return m.squeeze(1)[:, :, self.indent:-self.indent].transpose(1, 2)
+
+    def forward(self, m):
+        aux = self.resnet_stretch(self.aux_frames(m).unsqueeze(1)).squeeze(1)
+        return self.upsample_mel(m), aux.transpose(1, 2)
+
+
+class WaveRNN(nn.Module):
+    def __init__(self, rnn_dims, fc_dims, bits, pad, upsample_factors, feat_dims, compute_dims, res_out_dims,
+                 res_blocks, hop_length, sample_rate, mode='RAW'):
+        super().__init__()
+        self.mode = mode
+        self.pad = pad
+        if self.mode == 'RAW':
+            self.n_classes = 2 ** bits
+        elif self.mode == 'MOL':
+            self.n_classes = 30
+        else:
+            RuntimeError("Unknown model mode value - ", self.mode)   # constructed, not raised: reference quirk (:104)
+        self.rnn_dims = rnn_dims
+        self.aux_dims = res_out_dims // 4
+        self.hop_length = hop_length
+        self.sample_rate = sample_rate
+
+        self.upsample = UpsampleNetwork(feat_dims, upsample_factors, compute_dims, res_blocks, res_out_dims, pad)
+        self.I = nn.Linear(feat_dims + self.aux_dims + 1, rnn_dims)
+        self.rnn1 = nn.GRU(rnn_dims, rnn_dims, batch_first=True)
+        self.rnn2 = nn.GRU(rnn_dims + self.aux_dims, rnn_dims, batch_first=True)
+        self.fc1 = nn.Linear(rnn_dims + self.aux_dims, fc_dims)
+        self.fc2 = nn.Linear(fc_dims + self.aux_dims, fc_dims)
+        self.fc3 = nn.Linear(fc_dims, self.n_classes)
+        self.register_buffer('step', torch.zeros(1, dtype=torch.long))
+        self.num_params()
+
+        #: 'cpu' = consume torch's global CPU generator exactly like the reference's CPU run (parity);
+        #: 'device' = device Philox generator (what the reference does when it runs on a GPU)
+        self.noise_source = 'cpu'
+        #: 'auto' | 'persist' | 'stream'
+        self.loop_algo = 'auto'
+        self._engine = None
+        self._engine_key = None
+        self.last_loop_ms = None
+        self.last_loop_kernel = None
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, x, mels):
+        """Teacher-forced training forward (reference :131-167); plain PyTorch, not part of the hot path."""
+        self.step += 1
+        bsize = x.size(0)
+        device = x.device
+        h1 = torch.zeros(1, bsize, self.rnn_dims, device=device)
+        h2 = torch.zeros(1, bsize, self.rnn_dims, device=device)
+        mels, aux = self.upsample(mels)
+        d = self.aux_dims
+        a1, a2, a3, a4 = (aux[:, :, d * i:d * (i + 1)] for i in range(4))
+        x = self.I(torch.cat([x.unsqueeze(-1), mels, a1], dim=2))
+        res = x
+        x, _ = self.rnn1(x, h1)
+        x = x + res
+        res = x
+        x, _ = self.rnn2(torch.cat([x, a2], dim=2), h2)
+        x = x + res
+        x = F.relu(self.fc1(torch.cat([x, a3], dim=2)))
+        x = F.relu(self.fc2(torch.cat([x, a4], dim=2)))
+        return self.fc3(x)
+
+    # ------------------------------------------------------------------------------------------------
+    def _loop_engine(self):
+        sd = {k: v for k, v in self.state_dict().items() if k in LOOP_KEYS.values()}
+        key = tuple((k, v.data_ptr(), v._version, str(v.device)) for k, v in sorted(sd.items()))
+        if self._engine is None or key != self._engine_key:
+            dev = next(self.parameters()).device
+            self._engine = LoopEngine(sd, self.mode, device=dev)
+            self._engine_key = key
+        return self._engine
+
+    def conditioning(self, mels):
+        """Pre-loop stage (reference :183-186) without the Stretch2d repeat of aux and without the fold:
+        returns mels_up (L, feat), aux frames (N, res_out), wave_len."""
+        device = next(self.parameters()).device
+        mels = torch.as_tensor(mels, device=device)
+        wave_len = (mels.size(-1) - 1) * self.hop_length
+        m = _fold.pad_tensor(mels.transpose(1, 2), pad=self.pad, side='both').transpose(1, 2)
+        mels_up = self.upsample.upsample_mel(m)[0].contiguous()
+        aux = self.upsample.aux_frames(m)[0].transpose(0, 1).contiguous()
+        return mels_up, aux, wave_len
+
+    def generate(self, mels, save_path: Union[str, Path], batched, target, overlap, mu_law):
+        self.eval()
+        device = next(self.parameters()).device
+        if device.type != 'cuda':
+            raise RuntimeError('wavernn_amd.WaveRNN.generate needs the model on a HIP device (model.to("cuda")); '
+                               'there is no CPU path in this package')
+        if self.mode not in ('RAW', 'MOL'):
+            raise RuntimeError("Unknown model mode value - ", self.mode)
+        mu_law = mu_law if self.mode == 'RAW' else False
+
+        with torch.no_grad():
+            mels_up, aux, wave_len = self.conditioning(mels)
+            L = mels_up.size(0)
+            if batched:
+                B, _ = _fold.fold_geometry(L, target, overlap)
+                T, stride = target + 2 * overlap, target + overlap
+            else:
+                B, T, stride = 1, L, 0
+            noise = draw_noise(self.mode, B, T, self.n_classes, self.rnn_dims, self.aux_dims, device, self.noise_source)
+            eng = self._loop_engine()
+            out = eng.run(mels_up, aux, B, T, stride, noise, self.hop_length, algo=self.loop_algo)
+            self.last_loop_ms = eng.last_loop_ms()
+            self.last_loop_kernel = eng.last_loop_kernel()
+
+        output = out.cpu().numpy().astype(np.float64)
+        if mu_law:
+            output = _fold.decode_mu_law(output, self.n_classes, False)
+        if batched:
+            output = _fold.xfade_and_unfold(output, target, overlap)
+        else:
+            output = output[0]
+        output = _fold.finish_waveform(output, wave_len, self.hop_length)
+        save_wav(output, save_path, self.sample_rate)
+        self.train()
+        return output
+
+    # -- API parity helpers (reference :281-435) -------------------------------------------------------
+    def pad_tensor(self, x, pad, side='both'):
+        return _fold.pad_tensor(x, pad, side)
+
+    def fold_with_overlap(self, x, target, overlap):
+        return _fold.fold_with_overlap(x, target, overlap)
+
+    def xfade_and_unfold(self, y, target, overlap):
+        return _fold.xfade_and_unfold(y, target, overlap)
+
+    def get_step(self):
+        return self.step.data.item()
+
+    def log(self, path, msg):
+        with open(path, 'a') as f:
+            print(msg, file=f)
+
+    def load(self, path: Union[str, Path]):
+        device = next(self.parameters()).device
+        self.load_state_dict(torch.load(path, map_location=device), strict=False)
+
+    def save(self, path: Union[str, Path]):
+        torch.save(self.state_dict(), path)
+
+    def num_params(self, print_out=True):
+        n = sum(int(np.prod(p.size())) for p in self.parameters() if p.requires_grad) / 1_000_000
+        if print_out:
+            print('Trainable Parameters: %.3fM' % n)
+        return n
