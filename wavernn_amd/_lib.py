@@ -64,6 +64,9 @@ def lib():
     if not os.path.exists(SO_PATH):
         raise WrnnError(f'{SO_PATH} not found: run `python -c "import __graft_entry__ as g; g.build()"` '
                         f'(or wavernn_amd/csrc/build.sh).  There is no CPU fallback.')
+    # torch bundles its own libamdhip64; load it FIRST so this library binds to the same HIP runtime instance
+    # (two HIP runtimes in one process do not see each other's devices / pointers).
+    import torch  # noqa: F401
     L = ctypes.CDLL(SO_PATH)
     L.wrnn_last_error.restype = ctypes.c_char_p
     L.wrnn_abi_version.restype = ctypes.c_int
