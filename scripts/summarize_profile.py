@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Condense a scripts/gpu_profile.sh run (gpurun_out/prof_<tag>_*) into profiles/<tag>_*.csv|md (tracked).
+
+    python scripts/summarize_profile.py r01a
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(ROOT, 'gpurun_out')
+dst = os.path.join(ROOT, 'profiles')
+os.makedirs(dst, exist_ok=True)
+OURS = ('wrnn',)
+
+# 1) kernel-trace --stats summary: keep the top rows verbatim (names shortened)
+stats = os.path.join(src, f'prof_{tag}_stats', 'stats_kernel_stats.csv')
+rows = list(csv.reader(open(stats)))
+with open(os.path.join(dst, f'{tag}_kernel_stats.csv'), 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(rows[0])
+    for r in rows[1:13]:
+        r[0] = r[0][:96]
+        w.writerow(r)
+
+# 2) PMC passes: per (kernel, counter) mean over dispatches
+pmc = collections.OrderedDict()
+meta = {}
+for d in sorted(glob.glob(os.path.join(src, f'prof_{tag}_pmc_*', 'pmc_counter_collection.csv'))):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(d)):
+        if any(o in r['Kernel_Name'] for o in OURS):
+            k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+            acc[(k, r['Counter_Name'])].append(float(r['Counter_Value']))
+            meta[k] = dict(vgpr=r['VGPR_Count'], agpr=r['Accum_VGPR_Count'], sgpr=r['SGPR_Count'],
+                           lds=r['LDS_Block_Size'], grid=r['Grid_Size'], wg=r['Workgroup_Size'])
+    for (k, c), v in acc.items():
+        pmc.setdefault(k, {})[c] = (sum(v) / len(v), len(v))
+with open(os.path.join(dst, f'{tag}_pmc.csv'), 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['kernel', 'counter', 'mean_per_dispatch', 'dispatches'])
+    for k, cs in pmc.items():
+        for c, (m, n) in cs.items():
+            w.writerow([k, c, f'{m:.6g}', n])
+
+# 3) derived figures for the loop kernel
+lines = [f'# rocprofv3 summary `{tag}`', '', 'Source: `scripts/gpu_profile.sh` on one MI355X (separate `--pmc` passes); '
+         'raw CSVs condensed by `scripts/summarize_profile.py`.', '']
+bench = os.path.join(src, f'bench_{tag}.log')
+if os.path.exists(bench):
+    for ln in open(bench):
+        if ln.startswith('{'):
+            b = json.loads(ln)
+            lines += ['## bench line', '', '```json', json.dumps(b, indent=1), '```', '']
+for k, cs in pmc.items():
+    g = lambda c: cs.get(c, (None,))[0]
+    lines += [f'## {k}', '', f'launch geometry / registers: {meta[k]}', '']
+    if g('FETCH_SIZE') is not None and g('WRITE_SIZE') is not None:
+        lines.append(f'* fabric-side traffic per dispatch: FETCH_SIZE {g("FETCH_SIZE") / 1e6:.3f} GB (KB counter; gfx950 may '
+                     f'under-count wide reads 2x), WRITE_SIZE {g("WRITE_SIZE") / 1e6:.3f} GB')
+    if g('SQ_LDS_BANK_CONFLICT') is not None and g('SQ_LDS_IDX_ACTIVE'):
+        lines.append(f'* LDS bank-conflict rate SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = '
+                     f'{g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE"):.4f}')
+    if g('SQ_WAVE_CYCLES'):
+        wc = g('SQ_WAVE_CYCLES')
+        for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY'):
+            if g(c) is not None:
+                lines.append(f'* {c} / SQ_WAVE_CYCLES = {g(c) / wc:.3f}')
+        if g('SQ_VALU_MFMA_BUSY_CYCLES') is not None:
+            lines.append(f'* MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_WAVE_CYCLES) = '
+                         f'{g("SQ_VALU_MFMA_BUSY_CYCLES") / (4 * wc):.3f}  (one wave per SIMD)')
+    if g('TCC_HIT_sum') is not None:
+        lines.append(f'* L2 hit rate = {g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")):.4f}')
+    lines.append('')
+open(os.path.join(dst, f'{tag}_summary.md'), 'w').write('\n'.join(lines))
+print('\n'.join(lines))
