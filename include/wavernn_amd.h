@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WRNN_ABI_VERSION 1
+#define WRNN_ABI_VERSION 2
 
 enum {
     WRNN_OK = 0,
@@ -42,9 +42,11 @@ enum { WRNN_MODE_RAW = 0, WRNN_MODE_MOL = 1 };  /* reference: WaveRNN(mode='RAW'
 
 /* Loop kernel selection. */
 enum {
-    WRNN_ALGO_AUTO = 0,     /* persistent chip-wide kernel when the device admits it, else stream */
+    WRNN_ALGO_AUTO = 0,     /* clustered persistent kernel when the device admits it, else stream */
     WRNN_ALGO_STREAM = 1,   /* one workgroup per folded segment, weights streamed from L2/MALL each step */
-    WRNN_ALGO_PERSIST = 2   /* persistent cooperative kernel, weights stationary on-chip, all CUs per step */
+    WRNN_ALGO_PERSIST = 2,  /* chip-wide persistent kernel: one cooperative launch per group of <= 16 segments */
+    WRNN_ALGO_CLUSTER = 3   /* clustered persistent kernel: 1, 2 or 4 independent CU clusters, each with a full
+                               on-chip copy of the weights, all groups of <= 16 segments in ONE launch */
 };
 
 /*
@@ -126,14 +128,34 @@ int wrnn_generate(const wrnn_pack *p, const wrnn_geometry *g, const float *mels_
                   const float *noise, float *out, void *workspace, size_t workspace_bytes, int algo,
                   const wrnn_debug *dbg, void *stream);
 
+/*
+ * The same loop over an explicit SEGMENT TABLE: segment b, step t reads conditioning position
+ * p = seg_pos[b] + t; positions p >= seg_lim[b] are zero padding.  This is `fold_with_overlap`
+ * (fatchord_version.py:293-340) applied to SEVERAL utterances whose un-folded conditioning was concatenated
+ * (every utterance must start on a frame boundary: offset % hop == 0): utterance u at sample offset o_u with
+ * L_u samples contributes segments with seg_pos = o_u + i*(target+overlap), seg_lim = o_u + L_u.  It is what
+ * lets one launch serve a whole corpus shard (BASELINE config 4) -- the reference calls generate() once per
+ * utterance (gen_wavernn.py:26-35).  seg_pos / seg_lim are HOST arrays of n_segments int32.
+ *   mels_up device [L, M], aux device [n_frames, 4A] (concatenated), noise/out as in wrnn_generate with
+ *   B = n_segments.
+ */
+int wrnn_generate_segments(const wrnn_pack *p, int32_t n_segments, int32_t T, const int32_t *seg_pos,
+                           const int32_t *seg_lim, int32_t L, int32_t hop, int32_t n_frames,
+                           const float *mels_up, const float *aux, const float *noise, float *out,
+                           void *workspace, size_t workspace_bytes, int algo, const wrnn_debug *dbg, void *stream);
+size_t wrnn_workspace_bytes_segments(const wrnn_pack *p, int32_t n_segments, int32_t T, int32_t n_frames);
+
 /* Synchronises `stream`, reads the kernel status words from `workspace`.  WRNN_OK or WRNN_ERR_KERNEL. */
 int wrnn_status(void *workspace, void *stream);
 
 /* Milliseconds the last wrnn_generate on this pack spent in its loop kernel(s) (HIP events on `stream`;
  * synchronises).  <0 if unavailable. */
 float wrnn_last_loop_ms(const wrnn_pack *p);
-/* name of the loop kernel the last wrnn_generate launched ("wrnn_persist_kernel"/"wrnn_stream_kernel") */
+/* name of the loop kernel the last wrnn_generate launched
+ * ("wrnn_cluster_kernel" / "wrnn_persist_kernel" / "wrnn_stream_kernel") */
 const char *wrnn_last_loop_kernel(const wrnn_pack *p);
+/* how that kernel split the chip: hidden units per workgroup and number of independent clusters (0,0 = stream) */
+int wrnn_last_loop_split(const wrnn_pack *p, int *units_per_wg, int *clusters);
 
 /* Self tests of the device primitives (MFMA fragment layout, inter-workgroup granule all-gather).
  * Synchronous.  WRNN_OK or an error with a message. */

@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Loop-kernel timing sweep on one MI355X: every kernel split x segment count, short T (timing only, no parity).
+
+    python scripts/gpu_perf_probe.py [--T 1500] [--out gpurun_out/probe.json]
+"""
+import argparse, json, os, sys, time
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from wavernn_amd.engine import LoopEngine
+from wavernn_amd.synthetic import random_state_dict
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--T', type=int, default=1500)
+ap.add_argument('--mode', default='MOL')
+ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'probe.json'))
+ap.add_argument('--B', default='12,16,32,48,64,96,128,192,256')
+ap.add_argument('--variants', default='persist,u2,u4,u8,u8nl16')
+args = ap.parse_args()
+
+dev = torch.device('cuda', 0)
+mode, T, hop = args.mode, args.T, 275
+sd = random_state_dict(0, mode=mode)
+eng = LoopEngine(sd, mode, device=dev)
+rs = np.random.RandomState(3)
+VARS = {'persist': ('persist', {}), 'u2': ('cluster', {'WRNN_CLUSTER_U': '2'}), 'u4': ('cluster', {'WRNN_CLUSTER_U': '4'}),
+        'u8': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '8'}),
+        'u8nl16': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '16'}), 'auto': ('auto', {})}
+rows = []
+for B in [int(x) for x in args.B.split(',')]:
+    stride = 64
+    L = (B * stride + T + hop - 1) // hop * hop
+    N = L // hop
+    mels_up = torch.from_numpy(rs.uniform(0, 1, (L, 80)).astype(np.float32)).to(dev)
+    aux = torch.from_numpy(rs.uniform(-1, 1, (N, 128)).astype(np.float32)).to(dev)
+    if mode == 'MOL':
+        noise = torch.empty(T, 11 * B, device=dev).uniform_(1e-5, 1 - 1e-5)
+    else:
+        noise = torch.empty(T, B, 512, device=dev).exponential_(1)
+    ref = None
+    for v in args.variants.split(','):
+        algo, env = VARS[v]
+        if mode == 'RAW' and v.startswith('u8'):
+            continue
+        if v == 'persist' and B > 64:
+            continue
+        for k in ('WRNN_CLUSTER_U', 'WRNN_CLUSTER_NL'):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            out = eng.run(mels_up, aux, B, T, stride, noise, hop, algo=algo)
+            out = eng.run(mels_up, aux, B, T, stride, noise, hop, algo=algo)
+            ms = eng.last_loop_ms()
+            o = out.cpu().numpy()
+            if ref is None:
+                ref = o
+            err = float(np.abs(o - ref).max())
+            groups = (B + 15) // 16
+            u, ncl = eng.last_loop_split()
+            rounds = 1 if algo == 'persist' and False else max(1, -(-groups // max(ncl, 1)))
+            if algo == 'persist':
+                rounds = groups
+            row = dict(variant=v, B=B, T=T, ms=round(ms, 3), us_per_group_step=round(ms * 1e3 / (T * rounds), 3),
+                       seg_steps_per_s=round(B * T / (ms * 1e-3)), split=[u, ncl], max_dev_vs_first=err)
+        except Exception as e:
+            row = dict(variant=v, B=B, error=str(e)[:200])
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+json.dump(rows, open(args.out, 'w'), indent=0)

@@ -13,3 +13,27 @@ def load_case(name):
     g = np.load(os.path.join(GOLDEN, name + '.npz'))
     cfg = ast.literal_eval(str(g['config']))
     return cfg, g
+
+
+def oracle_loop_fn(sd, mode):
+    """CPU stand-in for the HIP loop with the `generate_corpus(loop_fn=...)` signature -- TEST ONLY: lets the
+    sharding / all-gather / unfold host logic run under gloo on a box without a GPU."""
+    import torch
+    from oracle import c_oracle as C
+
+    def fn(mels_up, aux, seg_pos, seg_lim, T, noise, hop):
+        mu, au, nz = mels_up.cpu().numpy(), aux.cpu().numpy(), noise.cpu().numpy()
+        n = len(seg_pos)
+        mels_f = np.zeros((n, T, mu.shape[1]), np.float32)
+        aux_f = np.zeros((n, T, au.shape[1]), np.float32)
+        for b in range(n):
+            p = int(seg_pos[b]) + np.arange(T)
+            ok = p < int(seg_lim[b])
+            mels_f[b, ok] = mu[p[ok]]
+            aux_f[b, ok] = au[p[ok] // hop]
+        if mode == 'MOL':
+            nzo = (np.ascontiguousarray(nz[:, :10 * n].reshape(T, n, 10)), np.ascontiguousarray(nz[:, 10 * n:]))
+        else:
+            nzo = np.ascontiguousarray(nz.reshape(T, n, -1))
+        return torch.from_numpy(C.loop(sd, mode, mels_f, aux_f, nzo))
+    return fn

@@ -43,10 +43,31 @@ def _inputs(cfg):
     return sd, mel, mels_up, aux, (B, T, stride), noise, np.ascontiguousarray(flat, np.float32)
 
 
+#: loop-kernel variants: name -> (algo, environment overrides read by the C ABI at call time)
+VARIANTS = {
+    'stream': ('stream', {}),
+    'persist': ('persist', {}),
+    'cluster-u2': ('cluster', {'WRNN_CLUSTER_U': '2'}),
+    'cluster-u4': ('cluster', {'WRNN_CLUSTER_U': '4'}),
+    'cluster-u8': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '8'}),
+    'cluster-u8-nl16': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '16'}),
+}
+KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'persist': 'wrnn_persist_kernel', 'cluster': 'wrnn_cluster_kernel'}
+
+
+def _select(monkeypatch, variant):
+    algo, env = VARIANTS[variant]
+    for k in ('WRNN_CLUSTER_U', 'WRNN_CLUSTER_NL'):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    return algo
+
+
 def test_device_selftests(gpu):
     from wavernn_amd import _lib
     L = _lib.lib()
-    assert L.wrnn_abi_version() == 1
+    assert L.wrnn_abi_version() == 2
     assert L.wrnn_device_cus(0) > 0
     _lib.check(L.wrnn_selftest(0, 1), 'mfma selftest')
     print(L.wrnn_last_error().decode())
@@ -54,18 +75,23 @@ def test_device_selftests(gpu):
     print(L.wrnn_last_error().decode())
 
 
-@pytest.mark.parametrize('algo', ['stream', 'persist'])
+@pytest.mark.parametrize('variant', list(VARIANTS))
 @pytest.mark.parametrize('name', CASES)
-def test_loop_matches_reference_golden(gpu, name, algo):
+def test_loop_matches_reference_golden(gpu, name, variant, monkeypatch):
     """Free-running loop kernel vs the reference's own pre-decode [B,T] tensor (golden) and vs the C oracle."""
     from oracle import c_oracle as C
     from wavernn_amd.engine import LoopEngine
     cfg, g = load_case(name)
+    if cfg['mode'] == 'RAW' and variant.startswith('cluster-u8'):
+        pytest.skip('the U = 8 split exists for MOL only')
+    algo = _select(monkeypatch, variant)
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     eng = LoopEngine(sd, cfg['mode'], device=gpu)
     out = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
                   torch.from_numpy(flat).to(gpu), 275, algo=algo).cpu().numpy()
-    assert eng.last_loop_kernel() == ('wrnn_persist_kernel' if algo == 'persist' else 'wrnn_stream_kernel')
+    assert eng.last_loop_kernel() == KERNEL_NAME[algo]
+    if algo == 'cluster':
+        assert eng.last_loop_split()[0] == int(VARIANTS[variant][1]['WRNN_CLUSTER_U'])
     mels_f, aux_f, _ = __import__('oracle.wavernn_oracle', fromlist=['x']).conditioning(sd, mel, cfg['batched'], cfg['target'], cfg['overlap'])
     ref = C.loop(sd, cfg['mode'], mels_f, aux_f, noise)
     if cfg['mode'] == 'RAW':
@@ -77,14 +103,17 @@ def test_loop_matches_reference_golden(gpu, name, algo):
         assert np.abs(out - ref).max() <= MOL_TOL
 
 
-@pytest.mark.parametrize('algo', ['stream', 'persist'])
+@pytest.mark.parametrize('variant', ['stream', 'persist', 'cluster-u4', 'cluster-u8'])
 @pytest.mark.parametrize('name', ['raw_batched_60f', 'mol_batched_100f'])
-def test_teacher_forced_logits(gpu, name, algo):
+def test_teacher_forced_logits(gpu, name, variant, monkeypatch):
     """Feed the reference's samples back (teacher forcing) and compare every step's fc3 logits with the C
     oracle run the same way: isolates kernel arithmetic from chaotic divergence.  Tolerance 1e-4 abs on O(1) logits."""
     from oracle import c_oracle as C, wavernn_oracle as O
     from wavernn_amd.engine import LoopEngine
     cfg, g = load_case(name)
+    if cfg['mode'] == 'RAW' and variant.startswith('cluster-u8'):
+        pytest.skip('the U = 8 split exists for MOL only')
+    algo = _select(monkeypatch, variant)
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     mels_f, aux_f, _ = O.conditioning(sd, mel, cfg['batched'], cfg['target'], cfg['overlap'])
     _, ref_logits = C.loop(sd, cfg['mode'], mels_f, aux_f, noise, want_logits=True)     # free run == golden path
@@ -124,9 +153,68 @@ def test_generate_end_to_end(gpu, name, tmp_path):
     assert np.array_equal(torch.empty(4).uniform_(0, 1).numpy(), st.uniform_(4, 0, 1))
 
 
+@pytest.mark.parametrize('variant', ['cluster-u2', 'cluster-u4', 'cluster-u8', 'cluster-u8-nl16', 'persist'])
+@pytest.mark.parametrize('mode', ['MOL', 'RAW'])
+def test_many_segments_all_clusters(gpu, mode, variant, monkeypatch):
+    """45 folded segments = 3 groups of 15: every cluster of the 2- and 4-cluster splits runs a group (and cluster 0
+    of the 2-cluster split runs two, one after the other) -- against the C oracle.  RAW bit-exact, MoL <= MOL_TOL."""
+    from oracle import c_oracle as C, wavernn_oracle as O
+    from wavernn_amd.engine import LoopEngine
+    if mode == 'RAW' and variant.startswith('cluster-u8'):
+        pytest.skip('the U = 8 split exists for MOL only')
+    cfg = dict(mode=mode, wseed=31, mseed=131, frames=100, batched=True, target=550, overlap=55, seed=91)
+    algo = _select(monkeypatch, variant)
+    sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
+    assert (B, T) == (45, 660)
+    mels_f, aux_f, _ = O.conditioning(sd, mel, True, cfg['target'], cfg['overlap'])
+    ref = C.loop(sd, mode, mels_f, aux_f, noise)
+    eng = LoopEngine(sd, mode, device=gpu)
+    out = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
+                  torch.from_numpy(flat).to(gpu), 275, algo=algo).cpu().numpy()
+    if mode == 'RAW':
+        bad = np.argwhere(out != ref)
+        assert bad.size == 0, f'first divergence at (b,t)={bad[0]}'
+    else:
+        assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
+
+
+@pytest.mark.parametrize('variant', ['stream', 'cluster-u4', 'cluster-u8'])
+def test_segment_table_several_utterances(gpu, variant, monkeypatch):
+    """`run_segments`: three utterances of different length, conditioning concatenated, ONE launch -- every utterance's
+    segments must equal that utterance generated alone (C oracle on its own folded conditioning)."""
+    from oracle import c_oracle as C, wavernn_oracle as O
+    from wavernn_amd.engine import LoopEngine
+    from wavernn_amd.synthetic import random_state_dict, random_mel
+    from wavernn_amd.batch import plan_utterances, pack_noise
+    algo = _select(monkeypatch, variant)
+    mode, target, overlap, hop = 'MOL', 550, 55, 275
+    sd = random_state_dict(41, mode=mode)
+    frames = [23, 40, 31]
+    ups, auxs, refs, noises = [], [], [], []
+    for u, n in enumerate(frames):
+        mel = random_mel(500 + u, n)
+        m = O.pad_tensor(mel.T[None], 2, 'both')[0].T
+        mu, au = O.upsample_network(sd, m)
+        ups.append(mu)
+        auxs.append(np.ascontiguousarray(au[::hop]))
+        mels_f, aux_f, _ = O.conditioning(sd, mel, True, target, overlap)
+        nz = O.draw_noise(700 + u, mode, mels_f.shape[0], mels_f.shape[1])
+        noises.append(nz)
+        refs.append(C.loop(sd, mode, mels_f, aux_f, nz))
+    plan = plan_utterances([n * hop for n in frames], target, overlap)
+    assert plan.n_segments == sum(r.shape[0] for r in refs)
+    flat = pack_noise(mode, plan, [np.concatenate([a.reshape(plan.T, -1), b.reshape(plan.T, -1)], axis=1) for a, b in noises])
+    eng = LoopEngine(sd, mode, device=gpu)
+    out = eng.run_segments(torch.from_numpy(np.concatenate(ups)).to(gpu), torch.from_numpy(np.concatenate(auxs)).to(gpu),
+                           plan.seg_pos, plan.seg_lim, plan.T, torch.from_numpy(flat).to(gpu), hop, algo=algo).cpu().numpy()
+    for u, ref in enumerate(refs):
+        got = out[plan.first[u]:plan.first[u] + plan.folds[u]]
+        assert np.abs(got - ref).max() <= MOL_TOL, (u, np.abs(got - ref).max())
+
+
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_full_size_properties(gpu, mode):
-    """BASELINE config 2 geometry (B=12, T=12100): persistent and stream kernels agree, runs are deterministic,
+    """BASELINE config 2 geometry (B=12, T=12100): cluster and stream kernels agree, runs are deterministic,
     samples stay in [-1,1] (RAW: on the 512-level grid)."""
     from wavernn_amd.engine import LoopEngine
     from wavernn_amd.synthetic import random_state_dict
@@ -143,11 +231,11 @@ def test_full_size_properties(gpu, mode):
     else:
         noise = torch.empty(T, B, 512).exponential_(1, generator=g).to(gpu)
     eng = LoopEngine(sd, mode, device=gpu)
-    a = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='persist').cpu().numpy()
-    ms = eng.last_loop_ms()
-    b = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='persist').cpu().numpy()
+    a = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='cluster').cpu().numpy()
+    ms, split = eng.last_loop_ms(), eng.last_loop_split()
+    b = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='cluster').cpu().numpy()
     s = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='stream').cpu().numpy()
-    print(f'{mode} persistent loop {ms:.1f} ms for {B}x{T} segment-steps; stream {eng.last_loop_ms():.1f} ms')
+    print(f'{mode} cluster loop (split {split}) {ms:.1f} ms for {B}x{T} segment-steps; stream {eng.last_loop_ms():.1f} ms')
     assert np.array_equal(a, b), 'persistent kernel is not deterministic'
     assert np.abs(a).max() <= 1.0
     if mode == 'RAW':

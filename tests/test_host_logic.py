@@ -1,0 +1,134 @@
+"""CPU tests of the host side: C-ABI exports, fold / cross-fade helpers against the reference's golden waveforms,
+the corpus segment table, noise packing and the private-generator noise stream."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASES, ROOT, load_case
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """The shared object loads without a GPU and exports every function include/wavernn_amd.h declares."""
+    from wavernn_amd import _lib
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, 'include', 'wavernn_amd.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(wrnn_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert L.wrnn_abi_version() == 2
+    # no GPU here: compute entry points must fail loudly, never fall back to the host
+    if not torch.cuda.is_available():
+        assert L.wrnn_device_cus(0) < 0
+        assert b'no HIP device' in L.wrnn_last_error()
+
+
+def test_engine_refuses_to_run_without_a_device():
+    from wavernn_amd import _lib
+    from wavernn_amd.engine import LoopEngine
+    from wavernn_amd.synthetic import random_state_dict
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_lib.WrnnError):
+        LoopEngine(random_state_dict(1), 'MOL')
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_post_loop_host_path_matches_reference(name):
+    """decode_mu_law -> xfade_and_unfold -> tail fade on the reference's own [B,T] tensor == its returned waveform."""
+    from wavernn_amd import fold as F
+    cfg, g = load_case(name)
+    y = g['raw'].astype(np.float64)
+    n_classes = 512 if cfg['mode'] == 'RAW' else 30
+    if cfg['mode'] == 'RAW' and cfg['mu_law']:
+        y = F.decode_mu_law(y, n_classes, False)
+    y = F.xfade_and_unfold(y, cfg['target'], cfg['overlap']) if cfg['batched'] else y[0]
+    wave_len = (cfg['frames'] - 1) * 275
+    out = F.finish_waveform(y, wave_len, 275)
+    assert out.dtype == np.float64 and np.array_equal(out, g['out'])
+
+
+def test_fold_helpers_match_the_oracle():
+    from oracle import wavernn_oracle as O
+    from wavernn_amd import fold as F
+    rs = np.random.RandomState(0)
+    for L, tg, ov in [(22275, 11000, 550), (132275, 11000, 550), (700, 1100, 55), (14575, 2000, 100), (1155 * 3 + 55, 1100, 55)]:
+        x = rs.randn(1, L, 3).astype(np.float32)
+        ref = O.fold_with_overlap(x, tg, ov)
+        got = F.fold_with_overlap(torch.from_numpy(x), tg, ov).numpy()
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+        assert F.fold_geometry(L, tg, ov)[0] == O.num_folds(L, tg, ov) == ref.shape[0]
+    with pytest.raises(ValueError):                       # reference quirk: wave_len < 20*hop
+        F.finish_waveform(np.zeros(5000), 5000, 275)
+
+
+def test_segment_table_and_shards():
+    from wavernn_amd.batch import plan_utterances, shard_bounds
+    from wavernn_amd import fold as F
+    lens = [23 * 275, 40 * 275, 31 * 275, 2 * 275]
+    plan = plan_utterances(lens, 550, 55)
+    assert plan.T == 660 and plan.stride == 605
+    assert list(plan.folds) == [F.fold_geometry(L, 550, 55)[0] for L in lens]
+    assert plan.n_segments == plan.folds.sum() and plan.offsets[1] == lens[0]
+    for u in range(len(lens)):
+        s = slice(plan.first[u], plan.first[u] + plan.folds[u])
+        assert np.array_equal(plan.seg_pos[s], plan.offsets[u] + np.arange(plan.folds[u]) * 605)
+        assert (plan.seg_lim[s] == plan.offsets[u] + lens[u]).all() and (plan.seg_utt[s] == u).all()
+        assert plan.offsets[u] % 275 == 0                 # every utterance starts on a frame boundary
+    for world in (1, 2, 3, 8, 64):
+        b = shard_bounds(plan.n_segments, world)
+        assert b[0][0] == 0 and b[-1][1] == plan.n_segments
+        assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        sizes = [h - l for l, h in b]
+        assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize('mode', ['MOL', 'RAW'])
+def test_pack_noise_layout(mode):
+    from wavernn_amd.batch import plan_utterances, pack_noise
+    plan = plan_utterances([23 * 275, 40 * 275, 31 * 275], 550, 55)
+    T, C = plan.T, 8
+    rs = np.random.RandomState(1)
+    per = [rs.rand(T, 11 * int(b)).astype(np.float32) if mode == 'MOL' else rs.rand(T, int(b), C).astype(np.float32) for b in plan.folds]
+    full = pack_noise(mode, plan, per)
+    n = plan.n_segments
+    for s in range(n):
+        u = int(plan.seg_utt[s]); i = s - int(plan.first[u]); Bu = int(plan.folds[u])
+        if mode == 'MOL':
+            assert np.array_equal(full[:, 10 * s:10 * s + 10], per[u][:, 10 * i:10 * i + 10])
+            assert np.array_equal(full[:, 10 * n + s], per[u][:, 10 * Bu + i])
+        else:
+            assert np.array_equal(full[:, s], per[u][:, i])
+    # a block that starts and ends inside utterances, torch path
+    lo, hi = 2, n - 1
+    part = pack_noise(mode, plan, [torch.from_numpy(p) for p in per], lo, hi).numpy()
+    if mode == 'MOL':
+        assert np.array_equal(part[:, :10 * (hi - lo)], full[:, 10 * lo:10 * hi])
+        assert np.array_equal(part[:, 10 * (hi - lo):], full[:, 10 * n + lo:10 * n + hi])
+    else:
+        assert np.array_equal(part, full[:, lo:hi])
+
+
+@pytest.mark.parametrize('mode', ['MOL', 'RAW'])
+def test_private_generator_equals_global_stream(mode):
+    """draw_noise(generator=g) == the reference's global-generator consumption (GRUCell ctors + per-step draws),
+    which tests/test_oracle_golden.py pins to the reference."""
+    from oracle import wavernn_oracle as O
+    from wavernn_amd.rng import draw_noise, gru_cell_ctor_draws
+    assert gru_cell_ctor_draws(512, 32) == O.gru_cell_ctor_draws() == 3_201_024
+    B, T = 3, 5
+    torch.manual_seed(77)
+    a = draw_noise(mode, B, T, 512, 512, 32, 'cpu')
+    b = draw_noise(mode, B, T, 512, 512, 32, 'cpu', generator=torch.Generator().manual_seed(77))
+    assert torch.equal(a, b)
+    ref = O.draw_noise(77, mode, B, T)
+    if mode == 'MOL':
+        ref = np.concatenate([ref[0].reshape(T, B * 10), ref[1].reshape(T, B)], axis=1)
+    assert np.array_equal(a.numpy().reshape(ref.shape), ref)

@@ -13,13 +13,14 @@ SO_PATH = os.path.join(CSRC, 'libwavernn_amd.so')
 
 WRNN_OK = 0
 MODE_RAW, MODE_MOL = 0, 1
-ALGO_AUTO, ALGO_STREAM, ALGO_PERSIST = 0, 1, 2
-ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'persist': ALGO_PERSIST}
+ALGO_AUTO, ALGO_STREAM, ALGO_PERSIST, ALGO_CLUSTER = 0, 1, 2, 3
+ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'persist': ALGO_PERSIST, 'cluster': ALGO_CLUSTER}
 
 #: every symbol include/wavernn_amd.h declares
 EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_create', 'wrnn_pack_destroy',
-           'wrnn_pack_weight_bytes', 'wrnn_workspace_bytes', 'wrnn_generate', 'wrnn_status', 'wrnn_last_loop_ms',
-           'wrnn_last_loop_kernel', 'wrnn_selftest', 'wrnn_selftest_metric']
+           'wrnn_pack_weight_bytes', 'wrnn_workspace_bytes', 'wrnn_workspace_bytes_segments', 'wrnn_generate',
+           'wrnn_generate_segments', 'wrnn_status', 'wrnn_last_loop_ms', 'wrnn_last_loop_kernel',
+           'wrnn_last_loop_split', 'wrnn_selftest', 'wrnn_selftest_metric']
 
 
 class Weights(ctypes.Structure):
@@ -81,6 +82,13 @@ def lib():
     L.wrnn_generate.argtypes = [ctypes.c_void_p, ctypes.POINTER(Geometry), ctypes.c_void_p, ctypes.c_void_p,
                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                 ctypes.POINTER(Debug), ctypes.c_void_p]
+    L.wrnn_workspace_bytes_segments.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    L.wrnn_workspace_bytes_segments.restype = ctypes.c_size_t
+    L.wrnn_generate_segments.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                         ctypes.POINTER(Debug), ctypes.c_void_p]
+    L.wrnn_last_loop_split.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.wrnn_status.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.wrnn_last_loop_ms.argtypes = [ctypes.c_void_p]
     L.wrnn_last_loop_ms.restype = ctypes.c_float

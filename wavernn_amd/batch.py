@@ -1,0 +1,183 @@
+"""Corpus-level batched generation: many utterances -> one segment table -> shards over ranks -> all-gather.
+
+The reference generates one utterance per `WaveRNN.generate()` call (gen_wavernn.py:26-35, :56-65): each call
+folds ITS mel into `num_folds` overlapping segments (models/fatchord_version.py:293-340), runs them as one batch
+and cross-fades them back (:342-405).  Folded segments are independent from step 0 (zero initial state,
+:194-196; no cross-segment term in :201-241), so the segments of SEVERAL utterances can share one launch, and a
+corpus can be cut into contiguous blocks of segments, one block per GPU (BASELINE config
+4).  This module is the host logic for that:
+
+  plan_utterances   the segment table (`seg_pos`, `seg_lim`) over the concatenated conditioning
+  shard_bounds      contiguous, balanced blocks of segments per rank (no data-path collective inside the loop)
+  pack_noise        per-utterance reference noise streams -> the launch's [T, 11*n] / [T, n, C] layout
+  generate_corpus   upsample (PyTorch) -> loop (libwavernn_amd.so) on this rank's block -> all_gather of the
+                    [n_r, T] audio (RCCL over xGMI when the process group is `nccl`) -> per-utterance unfold
+
+Results do not depend on the number of ranks: every segment's noise is addressed by (utterance seed, step, fold
+index) exactly as the single-utterance reference call would draw it.
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import fold as _fold
+
+
+@dataclass
+class Plan:
+    target: int
+    overlap: int
+    T: int                    # steps per segment = target + 2*overlap
+    stride: int               # target + overlap
+    lengths: List[int]        # un-folded conditioning length (samples) of every utterance
+    offsets: np.ndarray       # sample offset of every utterance in the concatenated conditioning
+    folds: np.ndarray         # segments per utterance (num_folds of fold_with_overlap)
+    first: np.ndarray         # index of every utterance's first segment
+    seg_pos: np.ndarray       # int32 [n_segments]: conditioning position of step 0
+    seg_lim: np.ndarray       # int32 [n_segments]: first position that is zero padding (the utterance's end)
+    seg_utt: np.ndarray       # int32 [n_segments]: owning utterance
+
+    @property
+    def n_segments(self):
+        return int(self.seg_pos.shape[0])
+
+    @property
+    def total_len(self):
+        return int(sum(self.lengths))
+
+
+def plan_utterances(lengths: Sequence[int], target: int, overlap: int) -> Plan:
+    """Segment table for utterances whose un-folded conditioning (lengths[u] samples each) is concatenated."""
+    lengths = [int(x) for x in lengths]
+    if not lengths or min(lengths) < 1:
+        raise ValueError('need at least one non-empty utterance')
+    stride, T = target + overlap, target + 2 * overlap
+    folds = np.array([_fold.fold_geometry(L, target, overlap)[0] for L in lengths], dtype=np.int64)
+    # reference quirk: an input shorter than one window still makes one zero-padded fold (:322-330)
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
+    first = np.concatenate([[0], np.cumsum(folds)[:-1]]).astype(np.int64)
+    if offsets[-1] + lengths[-1] + T >= 2 ** 31:
+        raise ValueError('concatenated conditioning exceeds int32 positions; split the corpus')
+    seg_pos, seg_lim, seg_utt = [], [], []
+    for u, (L, nf) in enumerate(zip(lengths, folds)):
+        seg_pos.append(offsets[u] + np.arange(nf, dtype=np.int64) * stride)
+        seg_lim.append(np.full(nf, offsets[u] + L, dtype=np.int64))
+        seg_utt.append(np.full(nf, u, dtype=np.int64))
+    return Plan(target, overlap, T, stride, lengths, offsets, folds, first,
+                np.concatenate(seg_pos).astype(np.int32), np.concatenate(seg_lim).astype(np.int32),
+                np.concatenate(seg_utt).astype(np.int32))
+
+
+def shard_bounds(n_segments: int, world: int):
+    """[(lo, hi)] * world: contiguous blocks whose sizes differ by at most one (block r = segments [lo, hi))."""
+    return [((r * n_segments) // world, ((r + 1) * n_segments) // world) for r in range(world)]
+
+
+def pack_noise(mode: str, plan: Plan, per_utt, lo: int = 0, hi: Optional[int] = None):
+    """Arrange per-utterance noise into the layout `wrnn_generate_segments` reads for segments [lo, hi).
+
+    per_utt[u] is utterance u's noise exactly as the reference draws it for that utterance alone: MOL
+    (T, 11*B_u) = per step 10*B_u mixture uniforms (segment-major) then B_u logistic uniforms; RAW (T, B_u, C).
+    Entries for utterances without a segment in [lo, hi) may be None.  numpy in -> numpy out, torch in -> torch out.
+    """
+    hi = plan.n_segments if hi is None else hi
+    n = hi - lo
+    utts = [u for u in range(len(plan.lengths)) if plan.first[u] < hi and plan.first[u] + plan.folds[u] > lo]
+    sample = per_utt[utts[0]]
+    is_torch = isinstance(sample, torch.Tensor)
+    cat = (lambda xs, d: torch.cat(xs, dim=d)) if is_torch else (lambda xs, d: np.concatenate(xs, axis=d))
+    mix, logi, raw = [], [], []
+    for u in utts:
+        Bu, f0 = int(plan.folds[u]), int(plan.first[u])
+        a, b = max(lo, f0) - f0, min(hi, f0 + Bu) - f0          # this utterance's segments [a, b) are in the block
+        z = per_utt[u]
+        if mode == 'MOL':
+            z = z.reshape(plan.T, 11 * Bu)
+            mix.append(z[:, 10 * a:10 * b])
+            logi.append(z[:, 10 * Bu + a:10 * Bu + b])
+        else:
+            raw.append(z.reshape(plan.T, Bu, -1)[:, a:b])
+    out = cat(mix + logi, 1) if mode == 'MOL' else cat(raw, 1)
+    assert out.shape[0] == plan.T and (out.shape[1] == 11 * n if mode == 'MOL' else out.shape[1] == n)
+    return out.contiguous() if is_torch else np.ascontiguousarray(out)
+
+
+def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bool, seeds: Sequence[int],
+                    group=None, loop_fn=None, return_segments=False):
+    """Generate every utterance of `mels` (each (1, feat, N_u) or (feat, N_u)) with `model` (a `wavernn_amd.WaveRNN`),
+    batched, sharding the folded segments over the ranks of `group` (None = single process).
+
+    seeds[u] plays the role of `torch.manual_seed(seeds[u])` before the reference's `generate()` call for utterance u
+    (parity noise: the CPU MT19937 stream incl. the GRUCell constructor draws).  Returns the list of float64 waveforms
+    (on every rank), equal to per-utterance `generate(mel_u, ..., batched=True, target, overlap, mu_law)` calls.
+
+    loop_fn(mels_up, aux, seg_pos, seg_lim, T, noise, hop) -> (n, T) tensor replaces the HIP loop (tests inject a CPU
+    stand-in to exercise the sharding / gather logic under gloo); the default is the model's LoopEngine.
+    """
+    import torch.distributed as dist
+    from .rng import draw_noise
+    world = dist.get_world_size(group) if group is not None else 1
+    rank = dist.get_rank(group) if group is not None else 0
+    device = next(model.parameters()).device
+    mode = model.mode
+    mu_law = mu_law if mode == 'RAW' else False
+    hop = model.hop_length
+    was_training = model.training
+    model.eval()
+    mels = [torch.as_tensor(m) for m in mels]
+    mels = [m.unsqueeze(0) if m.dim() == 2 else m for m in mels]
+    frames = [int(m.size(-1)) for m in mels]
+    plan = plan_utterances([n * hop for n in frames], target, overlap)
+    lo, hi = shard_bounds(plan.n_segments, world)[rank]
+    n_max = max(h - l for l, h in shard_bounds(plan.n_segments, world))
+
+    out_local = torch.zeros(n_max, plan.T, dtype=torch.float32, device=device)
+    if hi > lo:
+        mine = [u for u in range(len(mels)) if plan.first[u] < hi and plan.first[u] + plan.folds[u] > lo]
+        with torch.no_grad():
+            ups, auxs, noise = [], [], [None] * len(mels)
+            local_off, off = {}, 0
+            for u in mine:                                   # only the utterances this block touches
+                mu, au, _ = model.conditioning(mels[u])
+                ups.append(mu)
+                auxs.append(au)
+                local_off[u] = off
+                off += mu.size(0)
+                g = torch.Generator(device='cpu').manual_seed(int(seeds[u]))
+                noise[u] = draw_noise(mode, int(plan.folds[u]), plan.T, model.n_classes, model.rnn_dims, model.aux_dims,
+                                      'cpu', 'cpu', generator=g)
+            mels_up, aux = torch.cat(ups).contiguous(), torch.cat(auxs).contiguous()
+            # this block's segment table, rebased onto the conditioning of the utterances it touches
+            rebase = np.array([local_off[int(u)] - int(plan.offsets[int(u)]) for u in plan.seg_utt[lo:hi]], dtype=np.int64)
+            seg_pos = (plan.seg_pos[lo:hi].astype(np.int64) + rebase).astype(np.int32)
+            seg_lim = (plan.seg_lim[lo:hi].astype(np.int64) + rebase).astype(np.int32)
+            nz = pack_noise(mode, plan, noise, lo, hi).to(device)
+            if loop_fn is None:
+                eng = model._loop_engine()
+                res = eng.run_segments(mels_up, aux, seg_pos, seg_lim, plan.T, nz, hop, algo=model.loop_algo)
+                model.last_loop_ms, model.last_loop_kernel = eng.last_loop_ms(), eng.last_loop_kernel()
+            else:
+                res = loop_fn(mels_up, aux, seg_pos, seg_lim, plan.T, nz, hop)
+            out_local[:hi - lo] = res
+    if world > 1:
+        gathered = [torch.empty_like(out_local) for _ in range(world)]
+        dist.all_gather(gathered, out_local, group=group)    # the ONE collective of the path: finished audio only
+        parts = [gathered[r][:h - l] for r, (l, h) in enumerate(shard_bounds(plan.n_segments, world))]
+        segs = torch.cat(parts)
+    else:
+        segs = out_local[:plan.n_segments]
+    segs = segs.cpu().numpy().astype(np.float64)
+    if was_training:
+        model.train()
+    if return_segments:
+        return segs, plan
+    outs = []
+    for u, n in enumerate(frames):
+        y = segs[plan.first[u]:plan.first[u] + plan.folds[u]].copy()
+        if mu_law:
+            y = _fold.decode_mu_law(y, model.n_classes, False)
+        y = _fold.xfade_and_unfold(y, target, overlap)
+        outs.append(_fold.finish_waveform(y, (n - 1) * hop, hop))
+    return outs

@@ -15,6 +15,8 @@ namespace wrnn {
 hipError_t launch_cond(const CondArgs &a, int n_cus, hipStream_t stream);
 hipError_t launch_stream(const LoopArgs &args, int mode, hipStream_t stream);
 hipError_t launch_persist(const LoopArgs &args, int U, int mode, hipStream_t stream);
+hipError_t launch_cluster(const LoopArgs &args, int U, int ncl, int mode, int nl, hipStream_t stream);
+int cluster_count(int U, int n_cus);
 size_t persist_lds_bytes();
 int selftest_mfma(char *msg, size_t n);
 int selftest_allgather(int n_cus, char *msg, size_t n, float *us_per_round);
@@ -52,6 +54,7 @@ struct wrnn_pack {
     hipEvent_t ev0, ev1;
     bool timed;
     const char *last_kernel;
+    int last_U, last_ncl;
 };
 
 extern "C" const char *wrnn_last_error(void) { return g_err; }
@@ -156,6 +159,7 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     hipEventCreate(&p->ev1);
     p->timed = false;
     p->last_kernel = "";
+    p->last_U = 0; p->last_ncl = 0;
     *out = p;
     return WRNN_OK;
 }
@@ -173,19 +177,21 @@ extern "C" size_t wrnn_pack_weight_bytes(const wrnn_pack *p) { return p ? p->wei
 
 namespace {
 struct WsLayout {
-    size_t status, gran, c2f, c3f, c4f, cI, total;
+    size_t status, gran, segs, c2f, c3f, c4f, cI, total;
 };
+constexpr size_t GRAN_BYTES = (size_t)MAXCL * NGRAN * SEG * H * sizeof(u64);
 size_t al(size_t x) { return (x + 255) / 256 * 256; }
-WsLayout ws_layout(const wrnn_geometry *g)
+WsLayout ws_layout(int B, int T, int n_frames)
 {
     WsLayout l;
     size_t o = 0;
     l.status = o; o = al(o + STATUS_WORDS * sizeof(unsigned));
-    l.gran = o;   o = al(o + (size_t)NGRAN * SEG * H * sizeof(u64));
-    l.c2f = o;    o = al(o + (size_t)(g->n_frames + 1) * 3 * H * sizeof(float));
-    l.c3f = o;    o = al(o + (size_t)(g->n_frames + 1) * H * sizeof(float));
-    l.c4f = o;    o = al(o + (size_t)(g->n_frames + 1) * H * sizeof(float));
-    l.cI = o;     o = al(o + (size_t)g->T * g->B * H * sizeof(float));
+    l.gran = o;   o = al(o + GRAN_BYTES);
+    l.segs = o;   o = al(o + (size_t)2 * B * sizeof(int));
+    l.c2f = o;    o = al(o + (size_t)(n_frames + 1) * 3 * H * sizeof(float));
+    l.c3f = o;    o = al(o + (size_t)(n_frames + 1) * H * sizeof(float));
+    l.c4f = o;    o = al(o + (size_t)(n_frames + 1) * H * sizeof(float));
+    l.cI = o;     o = al(o + (size_t)T * B * H * sizeof(float));
     l.total = o;
     return l;
 }
@@ -200,23 +206,46 @@ int check_geometry(const wrnn_geometry *g)
     if ((double)g->B * g->stride + g->T > 2.0e9) { set_err("geometry overflows int32"); return WRNN_ERR_ARG; }
     return WRNN_OK;
 }
+int check_segments(int B, int T, const int32_t *seg_pos, const int32_t *seg_lim, int L, int hop, int n_frames)
+{
+    if (B < 1 || T < 1 || L < 1 || hop < 1 || n_frames < 1 || !seg_pos || !seg_lim) {
+        set_err("bad segment table B=%d T=%d L=%d hop=%d n_frames=%d", B, T, L, hop, n_frames);
+        return WRNN_ERR_ARG;
+    }
+    if ((long)n_frames * hop < L) { set_err("n_frames*hop < L"); return WRNN_ERR_ARG; }
+    for (int b = 0; b < B; ++b) {
+        if (seg_pos[b] < 0 || seg_lim[b] < 0 || seg_lim[b] > L || (double)seg_pos[b] + T > 2.0e9) {
+            set_err("segment %d: pos=%d lim=%d outside [0,%d]", b, seg_pos[b], seg_lim[b], L);
+            return WRNN_ERR_ARG;
+        }
+    }
+    return WRNN_OK;
+}
 }  // namespace
 
 extern "C" size_t wrnn_workspace_bytes(const wrnn_pack *p, const wrnn_geometry *g)
 {
     if (!p || check_geometry(g) != WRNN_OK) return 0;
-    return ws_layout(g).total;
+    return ws_layout(g->B, g->T, g->n_frames).total;
 }
 
-extern "C" int wrnn_generate(const wrnn_pack *pc, const wrnn_geometry *g, const float *mels_up, const float *aux,
-                             const float *noise, float *out, void *workspace, size_t workspace_bytes, int algo,
-                             const wrnn_debug *dbg, void *stream_)
+extern "C" size_t wrnn_workspace_bytes_segments(const wrnn_pack *p, int32_t n_segments, int32_t T, int32_t n_frames)
+{
+    if (!p || n_segments < 1 || T < 1 || n_frames < 1) return 0;
+    return ws_layout(n_segments, T, n_frames).total;
+}
+
+extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T, const int32_t *seg_pos,
+                                      const int32_t *seg_lim, int32_t L, int32_t hop, int32_t n_frames,
+                                      const float *mels_up, const float *aux, const float *noise, float *out,
+                                      void *workspace, size_t workspace_bytes, int algo, const wrnn_debug *dbg,
+                                      void *stream_)
 {
     wrnn_pack *p = const_cast<wrnn_pack *>(pc);
     if (!p || !mels_up || !aux || !noise || !out || !workspace) { set_err("NULL argument"); return WRNN_ERR_ARG; }
-    int rc = check_geometry(g);
+    int rc = check_segments(B, T, seg_pos, seg_lim, L, hop, n_frames);
     if (rc != WRNN_OK) return rc;
-    const WsLayout l = ws_layout(g);
+    const WsLayout l = ws_layout(B, T, n_frames);
     if (workspace_bytes < l.total) { set_err("workspace %zu < required %zu", workspace_bytes, l.total); return WRNN_ERR_WORKSPACE; }
     if (((uintptr_t)workspace & 255) != 0) { set_err("workspace must be 256-byte aligned"); return WRNN_ERR_ARG; }
     hipStream_t stream = (hipStream_t)stream_;
@@ -224,12 +253,17 @@ extern "C" int wrnn_generate(const wrnn_pack *pc, const wrnn_geometry *g, const 
     char *ws = (char *)workspace;
 
     HIPCHK(hipMemsetAsync(ws + l.status, 0, STATUS_WORDS * sizeof(unsigned), stream));
+    // segment table -> device (pageable source: the runtime stages it before returning)
+    HIPCHK(hipMemcpyAsync(ws + l.segs, seg_pos, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(ws + l.segs + (size_t)B * sizeof(int), seg_lim, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
+    const int *d_pos = (const int *)(ws + l.segs), *d_lim = d_pos + B;
 
     CondArgs c;
     c.mels_up = mels_up; c.aux = aux; c.I_cT = p->I_cT; c.I_b = p->I_b; c.c2_wT = p->c2_wT; c.b_ih2 = p->b_ih2;
     c.c3_wT = p->c3_wT; c.fc1_b = p->fc1_b; c.c4_wT = p->c4_wT; c.fc2_b = p->fc2_b;
     c.cI = (float *)(ws + l.cI); c.c2f = (float *)(ws + l.c2f); c.c3f = (float *)(ws + l.c3f); c.c4f = (float *)(ws + l.c4f);
-    c.B = g->B; c.T = g->T; c.stride = g->stride; c.L = g->L; c.hop = g->hop; c.NF = g->n_frames;
+    c.seg_pos = d_pos; c.seg_lim = d_lim;
+    c.B = B; c.T = T; c.hop = hop; c.NF = n_frames;
     HIPCHK(launch_cond(c, p->n_cus, stream));
 
     LoopArgs a;
@@ -242,54 +276,102 @@ extern "C" int wrnn_generate(const wrnn_pack *pc, const wrnn_geometry *g, const 
     a.cI = c.cI; a.c2f = c.c2f; a.c3f = c.c3f; a.c4f = c.c4f;
     a.noise = noise; a.force_x = dbg ? dbg->force_x : nullptr; a.out = out; a.dbg_logits = dbg ? dbg->logits : nullptr;
     a.gran = (u64 *)(ws + l.gran); a.status = (unsigned *)(ws + l.status);
-    a.Btot = g->B; a.T = g->T; a.stride = g->stride; a.L = g->L; a.hop = g->hop; a.NF = g->n_frames; a.C = p->C;
+    a.seg_pos = d_pos; a.seg_lim = d_lim;
+    a.Btot = B; a.T = T; a.hop = hop; a.NF = n_frames; a.C = p->C;
+    a.NG = (B + SEG - 1) / SEG;
 
-    // kernel choice
-    int U = 0;
-    const char *envu = getenv("WRNN_PERSIST_U");
-    if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_PERSIST) {
-        const bool shape_ok = (p->mode == WRNN_MODE_MOL) || (p->C == H);
+    // ---- kernel choice --------------------------------------------------------------------------------
+    // cluster: clustered persistent kernel (all groups in one launch); persist: the chip-wide kernel, one launch
+    // per 16-segment group; stream: one workgroup per segment.  auto = cluster where the device admits it.
+    const bool shape_ok = (p->mode == WRNN_MODE_MOL) || (p->C == H);
+    enum { K_STREAM, K_PERSIST, K_CLUSTER } kind = K_STREAM;
+    int U = 0, ncl = 0;
+    if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_CLUSTER) {
+        if (shape_ok && (double)a.NG * T < 4.0e9) {
+            const char *envu = getenv("WRNN_CLUSTER_U");
+            const int want = envu ? atoi(envu) : 0;
+            // default split: as many clusters as there are groups to keep busy (fewer, larger clusters have the
+            // shorter per-step MFMA chain; more, smaller clusters run more groups at once)
+            const int umax = (p->mode == WRNN_MODE_MOL) ? 8 : 4;          // the U = 8 split exists for MOL only
+            const int first = a.NG >= 3 ? umax : (a.NG == 2 ? 4 : 2);
+            const int pref[3] = {first, 4, umax};
+            if ((want == 2 || want == 4 || want == 8) && want <= umax) { U = want; ncl = cluster_count(U, p->n_cus); }
+            for (int i = 0; i < 3 && ncl < 1; ++i) { U = pref[i]; ncl = cluster_count(U, p->n_cus); }
+            if (ncl >= 1) kind = K_CLUSTER;
+        }
+        if (kind != K_CLUSTER && algo == WRNN_ALGO_CLUSTER) {
+            set_err("cluster kernel needs >= 64 CUs and (MOL or RAW with 512 classes); device has %d CUs, C=%d", p->n_cus, p->C);
+            return WRNN_ERR_RESIDENCY;
+        }
+    } else if (algo == WRNN_ALGO_PERSIST) {
+        const char *envu = getenv("WRNN_PERSIST_U");
         if (shape_ok) {
             if (envu && (atoi(envu) == 2 || atoi(envu) == 4)) U = atoi(envu);
             else if (p->n_cus >= H / 2) U = 2;
             else if (p->n_cus >= H / 4) U = 4;
         }
         if (U != 0 && p->n_cus < H / U) U = 0;
-        if (U == 0 && algo == WRNN_ALGO_PERSIST) {
+        if (U == 0) {
             set_err("persistent kernel needs >= 128 CUs and (MOL or RAW with 512 classes); device has %d CUs, C=%d", p->n_cus, p->C);
             return WRNN_ERR_RESIDENCY;
         }
+        kind = K_PERSIST;
     } else if (algo != WRNN_ALGO_STREAM) { set_err("unknown algo %d", algo); return WRNN_ERR_ARG; }
 
     HIPCHK(hipEventRecord(p->ev0, stream));
-    if (U != 0) {
+    if (kind == K_CLUSTER) {
+        p->last_kernel = "wrnn_cluster_kernel";
+        p->last_U = U; p->last_ncl = ncl;
+        HIPCHK(hipMemsetAsync(ws + l.gran, 0, GRAN_BYTES, stream));
+        const char *envn = getenv("WRNN_CLUSTER_NL");
+        hipError_t e = launch_cluster(a, U, ncl, p->mode, envn ? atoi(envn) : 0, stream);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (algo == WRNN_ALGO_AUTO) {
+                fprintf(stderr, "[wavernn_amd] cluster launch refused (%s); using the stream kernel\n", hipGetErrorString(e));
+                kind = K_STREAM;
+            } else {
+                set_err("cluster cooperative launch failed: %s", hipGetErrorString(e));
+                return e == hipErrorCooperativeLaunchTooLarge ? WRNN_ERR_RESIDENCY : WRNN_ERR_HIP;
+            }
+        }
+    } else if (kind == K_PERSIST) {
         p->last_kernel = "wrnn_persist_kernel";
-        for (int b0 = 0; b0 < g->B; b0 += SEG) {
+        p->last_U = U; p->last_ncl = 1;
+        for (int b0 = 0; b0 < B; b0 += SEG) {
             a.b0 = b0;
-            a.nb = (g->B - b0 < SEG) ? (g->B - b0) : SEG;
+            a.nb = (B - b0 < SEG) ? (B - b0) : SEG;
             HIPCHK(hipMemsetAsync(ws + l.gran, 0, (size_t)NGRAN * SEG * H * sizeof(u64), stream));
             hipError_t e = launch_persist(a, U, p->mode, stream);
             if (e != hipSuccess) {
                 (void)hipGetLastError();
-                if (algo == WRNN_ALGO_AUTO && b0 == 0) {
-                    fprintf(stderr, "[wavernn_amd] persistent launch refused (%s); using the stream kernel\n", hipGetErrorString(e));
-                    U = 0;
-                    break;
-                }
                 set_err("persistent cooperative launch failed: %s", hipGetErrorString(e));
                 return e == hipErrorCooperativeLaunchTooLarge ? WRNN_ERR_RESIDENCY : WRNN_ERR_HIP;
             }
         }
     }
-    if (U == 0) {
+    if (kind == K_STREAM) {
         p->last_kernel = "wrnn_stream_kernel";
+        p->last_U = 0; p->last_ncl = 0;
         a.b0 = 0;
-        a.nb = g->B;
+        a.nb = B;
         HIPCHK(launch_stream(a, p->mode, stream));
     }
     HIPCHK(hipEventRecord(p->ev1, stream));
     p->timed = true;
     return WRNN_OK;
+}
+
+extern "C" int wrnn_generate(const wrnn_pack *pc, const wrnn_geometry *g, const float *mels_up, const float *aux,
+                             const float *noise, float *out, void *workspace, size_t workspace_bytes, int algo,
+                             const wrnn_debug *dbg, void *stream_)
+{
+    int rc = check_geometry(g);
+    if (rc != WRNN_OK) return rc;
+    std::vector<int32_t> pos(g->B), lim(g->B, g->L);
+    for (int b = 0; b < g->B; ++b) pos[b] = b * g->stride;
+    return wrnn_generate_segments(pc, g->B, g->T, pos.data(), lim.data(), g->L, g->hop, g->n_frames, mels_up, aux,
+                                  noise, out, workspace, workspace_bytes, algo, dbg, stream_);
 }
 
 extern "C" int wrnn_status(void *workspace, void *stream)
@@ -315,6 +397,14 @@ extern "C" float wrnn_last_loop_ms(const wrnn_pack *p)
 }
 
 extern "C" const char *wrnn_last_loop_kernel(const wrnn_pack *p) { return p ? p->last_kernel : ""; }
+
+extern "C" int wrnn_last_loop_split(const wrnn_pack *p, int *units_per_wg, int *clusters)
+{
+    if (!p) { set_err("NULL pack"); return WRNN_ERR_ARG; }
+    if (units_per_wg) *units_per_wg = p->last_U;
+    if (clusters) *clusters = p->last_ncl;
+    return WRNN_OK;
+}
 
 static float g_selftest_metric = -1.f;
 extern "C" float wrnn_selftest_metric(void) { return g_selftest_metric; }

@@ -8,7 +8,7 @@
 //   c3f[NF+1][H]   = fc1.bias + fc1.weight[:,H:H+A] . a3 ;  c4f likewise with fc2 / a4
 // aux is constant over a mel frame (Stretch2d, :57-61,:84), so c2f/c3f/c4f are frame tables; row NF is the
 // zero-conditioning row the fold's zero padding selects (:326-330).  The fold itself (:336-338) is never
-// materialised: segment b, step t reads position p = b*stride + t.
+// materialised: segment b, step t reads position p = seg_pos[b] + t (see LoopArgs).
 #include "wrnn_device.h"
 
 namespace wrnn {
@@ -35,8 +35,8 @@ __global__ __launch_bounds__(H) void wrnn_cond_sample_kernel(const CondArgs a)
             float val = 0.f;
             if (row < rows) {
                 const int t = (int)(row / a.B), b = (int)(row % a.B);
-                const int p = b * a.stride + t;
-                if (p < a.L) val = (k < MEL) ? a.mels_up[(size_t)p * MEL + k] : a.aux[(size_t)(p / a.hop) * 4 * AUX + (k - MEL)];
+                const int p = a.seg_pos[b] + t;
+                if (p < a.seg_lim[b]) val = (k < MEL) ? a.mels_up[(size_t)p * MEL + k] : a.aux[(size_t)(p / a.hop) * 4 * AUX + (k - MEL)];
             }
             in[rr][k] = val;
         }

@@ -18,6 +18,7 @@ constexpr int KCOND = MEL + AUX;   // conditioning inputs of the I layer (112)
 constexpr int SEG = 16;       // segments per persistent launch group (= MFMA N)
 constexpr int LDA = 516;      // padded row stride (floats) of the LDS activation tiles
 constexpr int NGRAN = 5;      // granule buffers: h1, h2, y1, y2, (RAW) logits
+constexpr int MAXCL = 4;      // cluster kernel: at most 4 independent clusters per chip
 constexpr int STATUS_WORDS = 16;
 
 // Everything the loop kernels read.  All pointers are device pointers.
@@ -42,9 +43,15 @@ struct LoopArgs {
     const float *force_x;               // optional [Btot][T]
     float *out;                         // [Btot][T]
     float *dbg_logits;                  // optional [T][Btot][C]
-    u64 *gran;                          // [NGRAN][SEG][H] {tag,value} granules (persistent kernel)
+    u64 *gran;                          // [MAXCL][NGRAN][SEG][H] {tag,value} granules (persistent / cluster kernels)
     unsigned *status;                   // [STATUS_WORDS]: 0 abort flag, 1 code, 2 wg, 3 step, 4 detail
-    int Btot, b0, nb, T, stride, L, hop, NF, C;
+    // segment table: segment b, step t reads conditioning position p = seg_pos[b] + t; p >= seg_lim[b] is the
+    // fold's zero padding (fatchord_version.py:326-330).  One utterance: seg_pos[b] = b*(target+overlap),
+    // seg_lim[b] = L.  Several utterances: positions in the concatenated conditioning (each utterance starts
+    // on a frame boundary).
+    const int *seg_pos, *seg_lim;       // [Btot]
+    int Btot, b0, nb, T, hop, NF, C;
+    int NG;                             // cluster kernel: number of <= SEG-segment groups the Btot segments form
 };
 
 
@@ -59,7 +66,8 @@ struct CondArgs {
     const float *c3_wT, *fc1_b;   // [AUX][H], [H]
     const float *c4_wT, *fc2_b;   // [AUX][H], [H]
     float *cI, *c2f, *c3f, *c4f;
-    int B, T, stride, L, hop, NF;
+    const int *seg_pos, *seg_lim;       // [B] (see LoopArgs)
+    int B, T, hop, NF;
 };
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -89,10 +97,10 @@ __device__ __forceinline__ float mol_sample(float mean, float ls, float u)
 }
 
 // frame of conditioning position p (Stretch2d repeats each frame `hop` times; p >= L is the fold's zero pad)
-__device__ __forceinline__ int cond_frame(int b, int t, int stride, int L, int hop, int NF)
+__device__ __forceinline__ int cond_frame(const int *seg_pos, const int *seg_lim, int b, int t, int hop, int NF)
 {
-    const int p = b * stride + t;
-    return (p < L) ? (p / hop) : NF;
+    const int p = seg_pos[b] + t;
+    return (p < seg_lim[b]) ? (p / hop) : NF;
 }
 
 __device__ __forceinline__ u64 ld_agent(const u64 *p)

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_persist_kernel(const LoopArgs a)
         }
         float c2r = 0, c2z = 0, c2n = 0, c3v = 0, c4v = 0;
         if (is_pw) {
-            const int f = cond_frame(b0 + pj, t, a.stride, a.L, a.hop, a.NF);
+            const int f = cond_frame(a.seg_pos, a.seg_lim, b0 + pj, t, a.hop, a.NF);
             c2r = a.c2f[(size_t)f * 3 * H + prow];
             c2z = a.c2f[(size_t)f * 3 * H + H + prow];
             c2n = a.c2f[(size_t)f * 3 * H + 2 * H + prow];

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(SNT) void wrnn_stream_kernel(const LoopArgs a)
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
-        const int f = cond_frame(b, t, a.stride, a.L, a.hop, a.NF);
+        const int f = cond_frame(a.seg_pos, a.seg_lim, b, t, a.hop, a.NF);
         const float xi = fmaf(wi0, xs, a.cI[((size_t)t * Btot + b) * H + tid]);
         v[tid] = xi;
         __syncthreads();

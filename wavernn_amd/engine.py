@@ -66,22 +66,38 @@ class LoopEngine:
         return int(self.lib.wrnn_pack_weight_bytes(self._pack))
 
     def run(self, mels_up, aux, B, T, stride, noise, hop, algo='auto', force_x=None, want_logits=False, check=True):
-        """mels_up (L,feat) / aux (n_frames,4*aux_dims) / noise: float32 CUDA tensors.  Returns out (B,T) CUDA
-        [and logits (T,B,C)].  Enqueues on the current stream; `check=True` synchronises and raises if a kernel
-        gave up."""
+        """One utterance: segment b reads conditioning position b*stride + t (`fold_with_overlap` geometry,
+        reference :293-340; unbatched: B=1, T=L, stride=0).  See `run_segments`."""
+        L = mels_up.shape[0]
+        seg_pos = np.arange(B, dtype=np.int32) * np.int32(stride)
+        seg_lim = np.full(B, L, dtype=np.int32)
+        return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo=algo, force_x=force_x,
+                                 want_logits=want_logits, check=check)
+
+    def run_segments(self, mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='auto', force_x=None,
+                     want_logits=False, check=True):
+        """mels_up (L,feat) / aux (n_frames,4*aux_dims) / noise: float32 CUDA tensors; seg_pos / seg_lim: host
+        int32 arrays (B,) -- segment b, step t reads position seg_pos[b]+t, zero conditioning from seg_lim[b] on
+        (several utterances: concatenated conditioning).  Returns out (B,T) CUDA [and logits (T,B,C)].
+        Enqueues on the current stream; `check=True` synchronises and raises if a kernel gave up."""
         for name, t_ in (('mels_up', mels_up), ('aux', aux), ('noise', noise)):
             if not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()):
                 raise ValueError(f'{name} must be a contiguous float32 CUDA tensor')
+        seg_pos = np.ascontiguousarray(seg_pos, dtype=np.int32)
+        seg_lim = np.ascontiguousarray(seg_lim, dtype=np.int32)
+        B = int(seg_pos.shape[0])
+        if seg_lim.shape != (B,) or B < 1:
+            raise ValueError('seg_pos / seg_lim must be 1-D int32 arrays of equal, non-zero length')
         L = mels_up.shape[0]
         if mels_up.shape[1] != self.feat_dims or aux.shape[1] != 4 * self.aux_dims:
             raise ValueError('conditioning shape mismatch')
         need = T * 11 * B if self.mode == 'MOL' else T * B * self.n_classes
         if noise.numel() != need:
             raise ValueError(f'noise has {noise.numel()} elements, expected {need}')
-        g = _lib.Geometry(B, T, stride, L, hop, aux.shape[0])
-        nbytes = int(self.lib.wrnn_workspace_bytes(self._pack, ctypes.byref(g)))
+        n_frames = int(aux.shape[0])
+        nbytes = int(self.lib.wrnn_workspace_bytes_segments(self._pack, B, T, n_frames))
         if nbytes == 0:
-            raise _lib.WrnnError('bad geometry: ' + self.lib.wrnn_last_error().decode())
+            raise _lib.WrnnError('bad geometry')
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -96,12 +112,19 @@ class LoopEngine:
             logits = torch.empty(T, B, self.n_classes, dtype=torch.float32, device=self.device)
             dbg.logits = logits.data_ptr()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self.lib.wrnn_generate(self._pack, ctypes.byref(g), mels_up.data_ptr(), aux.data_ptr(), noise.data_ptr(),
-                                    out.data_ptr(), self._ws.data_ptr(), nbytes, _lib.ALGOS[algo], ctypes.byref(dbg), stream)
-        _lib.check(rc, 'wrnn_generate')
+        rc = self.lib.wrnn_generate_segments(self._pack, B, T, seg_pos.ctypes.data, seg_lim.ctypes.data, L, hop, n_frames,
+                                             mels_up.data_ptr(), aux.data_ptr(), noise.data_ptr(), out.data_ptr(),
+                                             self._ws.data_ptr(), self._ws.numel(), _lib.ALGOS[algo], ctypes.byref(dbg), stream)
+        _lib.check(rc, 'wrnn_generate_segments')
         if check:
             _lib.check(self.lib.wrnn_status(self._ws.data_ptr(), stream), 'loop kernel')
         return (out, logits) if want_logits else out
+
+    def last_loop_split(self):
+        """(hidden units per workgroup, independent clusters) of the last loop kernel; (0, 0) for the stream kernel."""
+        u, c = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self.lib.wrnn_last_loop_split(self._pack, ctypes.byref(u), ctypes.byref(c)), 'wrnn_last_loop_split')
+        return u.value, c.value
 
     def last_loop_ms(self):
         return float(self.lib.wrnn_last_loop_ms(self._pack))
