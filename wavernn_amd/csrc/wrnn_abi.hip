@@ -297,7 +297,13 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
             const int pref[3] = {first, 4, umax};
             if ((want == 2 || want == 4 || want == 8) && want <= umax) { U = want; ncl = cluster_count(U, p->n_cus); }
             for (int i = 0; i < 3 && ncl < 1; ++i) { U = pref[i]; ncl = cluster_count(U, p->n_cus); }
-            if (ncl >= 1) kind = K_CLUSTER;
+            if (ncl >= 1) {
+                kind = K_CLUSTER;
+                // balance: the launch takes `rounds` group-runs per cluster however the segments are cut, so cut
+                // them into rounds*ncl groups (smaller groups = fewer granule rows per sweep, every cluster busy)
+                const int rounds = (a.NG + ncl - 1) / ncl;
+                a.NG = rounds * ncl < B ? rounds * ncl : B;
+            }
         }
         if (kind != K_CLUSTER && algo == WRNN_ALGO_CLUSTER) {
             set_err("cluster kernel needs >= 64 CUs and (MOL or RAW with 512 classes); device has %d CUs, C=%d", p->n_cus, p->C);
