@@ -1,18 +1,21 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the MI355X-native WaveRNN generate path (BASELINE.json metric).
 
-A "step" is ONE full pass of the hot path over one utterance of synthetic input: BASELINE config 2 --
-MoL WaveRNN (ljspeech.wavernn.mol hparams, random-init weights), a 481-frame (~6 s) random mel spectrogram,
-batched generation with target=11000 overlap=550 -> B=12 folded segments x T=12100 autoregressive steps.
-Timed region (inputs already resident in HBM): up-sample network -> hoisted conditioning -> the persistent
-loop kernel -> [N>1: RCCL all-gather of the [B,T] audio] -> D2H -> cross-fade/unfold on the host.  The WAV
-write is excluded (the CPU baseline excludes it too).
+A "step" is ONE full pass of the hot path over one batch of synthetic input.  Workload (BASELINE config 2 -- MoL
+WaveRNN, ljspeech.wavernn.mol hparams, random-init weights, batched generation target=11000 overlap=550 -- as
+one GPU's share of a serving batch / of config 4's corpus): `--utterances` random mels of `--frames` frames per
+GPU (default 8 x 641 frames = 8 x 8 s of audio -> 8 x 16 = 128 folded segments x T=12100 autoregressive steps).
+Timed region (mels already resident in HBM): up-sample network (PyTorch-ROCm) -> hoisted conditioning ->
+the persistent loop kernel (ONE launch for all segments) -> [N>1: RCCL all-gather of the [n,T] audio] -> D2H ->
+cross-fade/unfold on the host.  The WAV write is excluded (the CPU baseline excludes it too).  Sampling noise is
+drawn on the device (Philox), as the reference does when it runs on a GPU; `--parity-noise` uses the host
+MT19937 stream of the parity tests instead (adds ~25 M host RNG draws per pass).
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-value = useful audio samples per second over all ranks = N * K * wave_len / max-over-ranks(time).
+value = useful audio samples per second over all ranks = N * K * sum(wave_len) / max-over-ranks(time).
 """
 import argparse
 import json
@@ -28,18 +31,18 @@ sys.path.insert(0, ROOT)
 
 SAMPLE_RATE = 22050
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); measured-achievable 6290 GB/s
+MFMA_F32_PEAK_TF = 157.3    # v_mfma_f32_16x16x4_f32 dense peak (same guide)
 
 
-def cpu_baseline(sd, mode, frames, target, overlap, steps_sample):
+def cpu_baseline(sd, mode, frames, target, overlap, budget_s):
     """The oracle's C restatement ("port") timed on this box's host cores on a bounded sample of the same
-    workload: the same B segments, the first `steps_sample` of the T steps."""
+    workload: ONE of the utterances (its B segments), the first `ts` of the T steps (~budget_s of CPU work)."""
     from oracle import wavernn_oracle as O, c_oracle as C
     from wavernn_amd.synthetic import random_mel
     mel = random_mel(1234, frames)
     mels, aux, wave_len = O.conditioning(sd, mel, True, target, overlap)
     B, T, _ = mels.shape
-    ts = min(steps_sample, T)
-    noise = O.draw_noise(77, mode, B, ts)
+    noise = O.draw_noise(77, mode, B, min(T, 4000))
     # pick the OpenMP width that is fastest on this host (the layer-by-layer barriers make very wide teams slower)
     ncpu = os.cpu_count() or 1
     best = None
@@ -54,28 +57,29 @@ def cpu_baseline(sd, mode, frames, target, overlap, steps_sample):
         if best is None or d < best[1]:
             best = (nt, d)
     cores = best[0]
-    ts = max(40, min(ts, int(15.0 / (best[1] / 40))))        # bound the sample to ~15 s of CPU work
-    noise = (noise[0][:ts], noise[1][:ts])
+    ts = int(max(40, min(noise[1].shape[0], budget_s / (best[1] / 40))))     # ~budget_s of CPU work
     t0 = time.perf_counter()
-    C.loop(sd, mode, mels[:, :ts], aux[:, :ts], noise, nthreads=cores)
+    C.loop(sd, mode, mels[:, :ts], aux[:, :ts], (noise[0][:ts], noise[1][:ts]), nthreads=cores)
     dt = time.perf_counter() - t0
     seg_steps_per_s = B * ts / dt
     useful = seg_steps_per_s * wave_len / (B * T)          # same useful/raw ratio as the full workload
     return dict(value=round(useful, 1), unit='audio samples/s', cores=cores, kind='port',
-                sample=f'oracle/wrnn_oracle.c (OpenMP, {cores} of {ncpu} host threads; fastest of 8/16/32/64), B={B} segments x first {ts} of {T} steps '
-                       f'({dt:.1f} s); {seg_steps_per_s:.0f} segment-steps/s',
+                sample=f'oracle/wrnn_oracle.c (OpenMP, {cores} of {ncpu} host threads; fastest of 8/16/32/64), one utterance '
+                       f'of the batch: B={B} segments x first {ts} of {T} steps ({dt:.1f} s); {seg_steps_per_s:.0f} segment-steps/s',
                 realtime_factor=round(useful / SAMPLE_RATE, 4))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--frames', type=int, default=481)
-    ap.add_argument('--algo', default='auto', choices=['auto', 'persist', 'stream'])
+    ap.add_argument('--utterances', type=int, default=8, help='utterances per GPU')
+    ap.add_argument('--frames', type=int, default=641, help='mel frames per utterance')
+    ap.add_argument('--algo', default='auto', choices=['auto', 'cluster', 'persist', 'stream'])
+    ap.add_argument('--parity-noise', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=600)
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -86,16 +90,17 @@ def main():
         raise SystemExit('bench.py needs a HIP device: the product path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    dist = None
+    import torch.distributed as dist
+    group = None
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        group = dist.group.WORLD
 
     from wavernn_amd.model import WaveRNN
     from wavernn_amd.synthetic import random_state_dict, random_mel, SHIPPED
-    from wavernn_amd import fold as F
-    from wavernn_amd.rng import draw_noise
+    from wavernn_amd.batch import generate_corpus, plan_utterances
+    from wavernn_amd import _lib
 
     mode, target, overlap, hop = 'MOL', 11000, 550, 275
     sd = random_state_dict(0, mode=mode)
@@ -104,28 +109,20 @@ def main():
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
     model.loop_algo = args.algo
-    # every rank synthesises its own utterance (weak scaling: fixed work per GPU)
-    mel = torch.from_numpy(random_mel(1234 + rank, args.frames)).unsqueeze(0).to(dev)
+    # the whole job's batch: `utterances` per rank (weak scaling: fixed work per GPU); rank r's share is the r-th block
+    n_utt = args.utterances * world
+    mels = [torch.from_numpy(random_mel(1234 + u, args.frames)).unsqueeze(0).to(dev) for u in range(n_utt)]
+    seeds = [77 + u for u in range(n_utt)]
+    plan = plan_utterances([args.frames * hop] * n_utt, target, overlap)
+    wave_total = n_utt * (args.frames - 1) * hop
     eng = model._loop_engine()
+    noise_source = 'cpu' if args.parity_noise else 'device'
 
     def one_pass():
-        with torch.no_grad():
-            mels_up, aux, wave_len = model.conditioning(mel)
-            L = mels_up.size(0)
-            B, _ = F.fold_geometry(L, target, overlap)
-            T, stride = target + 2 * overlap, target + overlap
-            noise = draw_noise(mode, B, T, 30, 512, 32, dev, 'cpu')     # parity-mode noise (host MT19937 stream)
-            out = eng.run(mels_up, aux, B, T, stride, noise, hop, algo=args.algo, check=False)
-            if world > 1:
-                gathered = [torch.empty_like(out) for _ in range(world)]
-                dist.all_gather(gathered, out)                          # RCCL all-gather of the finished audio
-                out = gathered[rank]
-            y = out.cpu().numpy().astype(np.float64)
-            from wavernn_amd import _lib
-            _lib.check(eng.lib.wrnn_status(eng._ws.data_ptr(), torch.cuda.current_stream().cuda_stream), 'loop kernel')
-        y = F.xfade_and_unfold(y, target, overlap)
-        y = F.finish_waveform(y, wave_len, hop)
-        return y, B, T, wave_len
+        outs = generate_corpus(model, mels, target, overlap, True, seeds, group=group, noise_source=noise_source,
+                               finish='own', check=False)
+        _lib.check(eng.lib.wrnn_status(eng._ws.data_ptr(), torch.cuda.current_stream().cuda_stream), 'loop kernel')
+        return outs
 
     def fence():
         torch.cuda.synchronize()
@@ -139,7 +136,7 @@ def main():
     loop_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        y, B, T, wave_len = one_pass()
+        one_pass()
         loop_ms.append(eng.last_loop_ms())
     fence()
     dt = time.perf_counter() - t0
@@ -149,37 +146,61 @@ def main():
         dt = float(tt.item())
 
     if rank == 0:
-        value = world * args.steps * wave_len / dt
+        T = plan.T
+        n_local = plan.n_segments // world                   # segments this GPU's launch advances
+        value = args.steps * wave_total / dt
         W = eng.weight_bytes
-        bytes_per_launch = (W + B * 836) * T            # (W + B*836 B) per batch step x T steps
         kms = float(np.mean(loop_ms))
+        # unit = one batch step (all segments resident on the GPU advance one sample);
+        # algorithmic bytes per batch step = W + n*836; one launch = T batch steps
+        bytes_per_launch = (W + n_local * 836) * T
         achieved = bytes_per_launch / (kms * 1e-3) / 1e9
+        flops_per_launch = 2.0 * (W / 4.0) * n_local * T     # 2 flops per weight per segment-step
+        tf = flops_per_launch / (kms * 1e-3) / 1e12
+        u_per_wg, ncl = eng.last_loop_split()
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get('kernel') == eng.last_loop_kernel() and tj.get('segments') == n_local and tj.get('T') == T:
+                traffic = tj.get('bytes_per_launch')
         res = {
             'metric': 'audio samples/sec (real-time factor @22.05 kHz), MoL WaveRNN batched generate',
             'value': round(value, 1), 'unit': 'audio samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'realtime_factor': round(value / SAMPLE_RATE, 2),
-            'config': {'workload': f'BASELINE config 2: MoL WaveRNN (rnn/fc 512, random-init weights), one {args.frames}-frame '
-                                   f'random mel per GPU, batched fold target={target} overlap={overlap} -> B={B} segments x '
-                                   f'T={T} steps, wave_len={wave_len}', 'kernel': eng.last_loop_kernel(),
-                       'segment_steps_per_s': round(world * B * T * args.steps / dt, 1), 'noise': 'host MT19937 stream (parity mode)',
-                       'parallelism': f'{world} x (1 process per GPU, independent utterances, RCCL all-gather of audio)'},
+            'config': {'workload': f'BASELINE config 2 (MoL WaveRNN, rnn/fc 512, random-init weights, batched fold target={target} '
+                                   f'overlap={overlap}) on a batch of {args.utterances} random {args.frames}-frame mels per GPU '
+                                   f'-> {n_local} folded segments x T={T} steps in one launch per GPU, '
+                                   f'{wave_total // world} output samples per GPU per step',
+                       'kernel': eng.last_loop_kernel(), 'units_per_workgroup': u_per_wg, 'clusters': ncl,
+                       'segment_steps_per_s': round(plan.n_segments * T * args.steps / dt, 1),
+                       'noise': 'host MT19937 stream (parity mode)' if args.parity_noise else 'device Philox (as the reference on a GPU)',
+                       'parallelism': f'{world} x (1 process per GPU, contiguous block of the segment table, RCCL all-gather of audio)'},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'kernel': eng.last_loop_kernel(), 'kernel_ms': round(kms, 3),
                          'algorithmic_bytes_per_launch': bytes_per_launch,
-                         'note': 'weight-streaming-equivalent bandwidth (W + B*836 B per batch step); weights are '
-                                 'on-chip resident so true HBM traffic is far lower (DESIGN.md)'},
+                         'note': 'weight-streaming-equivalent bandwidth, SURVEY.md 8(d): (W + n*836 B) per batch step x T steps '
+                                 '/ kernel time (HIP events on the launch stream); the weights are on-chip resident, so this '
+                                 'is a latency figure of merit, not HBM traffic (DESIGN.md)'},
+            'roofline_mfma': {'bound': 'mfma', 'achieved': round(tf, 3), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
+                              'frac': round(tf / MFMA_F32_PEAK_TF, 5),
+                              'note': 'useful f32 FLOPs of the loop (2 x 3.83 M weights per segment-step) / kernel time vs the '
+                                      'dense f32 MFMA peak'},
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                res['cpu_baseline'] = cpu_baseline(sd, mode, args.frames, target, overlap, args.cpu_steps)
+                res['cpu_baseline'] = cpu_baseline(sd, mode, args.frames, target, overlap, args.cpu_seconds)
             except Exception as e:   # the baseline is a report, never a reason to lose the GPU number
                 res['cpu_baseline'] = {'error': repr(e)}
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    # the C-ABI pack must go before the HIP runtime tears down at interpreter exit
+    del eng
+    model._engine = None
 
 
 if __name__ == '__main__':

@@ -104,14 +104,18 @@ def pack_noise(mode: str, plan: Plan, per_utt, lo: int = 0, hi: Optional[int] = 
     return out.contiguous() if is_torch else np.ascontiguousarray(out)
 
 
-def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bool, seeds: Sequence[int],
-                    group=None, loop_fn=None, return_segments=False):
+def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bool, seeds: Optional[Sequence[int]] = None,
+                    group=None, loop_fn=None, return_segments=False, noise_source='cpu', finish='all', check=True):
     """Generate every utterance of `mels` (each (1, feat, N_u) or (feat, N_u)) with `model` (a `wavernn_amd.WaveRNN`),
     batched, sharding the folded segments over the ranks of `group` (None = single process).
 
     seeds[u] plays the role of `torch.manual_seed(seeds[u])` before the reference's `generate()` call for utterance u
     (parity noise: the CPU MT19937 stream incl. the GRUCell constructor draws).  Returns the list of float64 waveforms
     (on every rank), equal to per-utterance `generate(mel_u, ..., batched=True, target, overlap, mu_law)` calls.
+
+    noise_source='device' draws the block's noise from the device generator instead (what the reference does when it
+    runs on a GPU; not comparable with a CPU run; `seeds` unused).  finish='all': every rank unfolds every utterance;
+    'own': a rank unfolds only the utterances whose first segment lies in its block (None elsewhere in the list).
 
     loop_fn(mels_up, aux, seg_pos, seg_lim, T, noise, hop) -> (n, T) tensor replaces the HIP loop (tests inject a CPU
     stand-in to exercise the sharding / gather logic under gloo); the default is the model's LoopEngine.
@@ -145,19 +149,22 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
                 auxs.append(au)
                 local_off[u] = off
                 off += mu.size(0)
-                g = torch.Generator(device='cpu').manual_seed(int(seeds[u]))
-                noise[u] = draw_noise(mode, int(plan.folds[u]), plan.T, model.n_classes, model.rnn_dims, model.aux_dims,
-                                      'cpu', 'cpu', generator=g)
+                if noise_source == 'cpu':
+                    g = torch.Generator(device='cpu').manual_seed(int(seeds[u]))
+                    noise[u] = draw_noise(mode, int(plan.folds[u]), plan.T, model.n_classes, model.rnn_dims, model.aux_dims,
+                                          'cpu', 'cpu', generator=g)
             mels_up, aux = torch.cat(ups).contiguous(), torch.cat(auxs).contiguous()
             # this block's segment table, rebased onto the conditioning of the utterances it touches
             rebase = np.array([local_off[int(u)] - int(plan.offsets[int(u)]) for u in plan.seg_utt[lo:hi]], dtype=np.int64)
             seg_pos = (plan.seg_pos[lo:hi].astype(np.int64) + rebase).astype(np.int32)
             seg_lim = (plan.seg_lim[lo:hi].astype(np.int64) + rebase).astype(np.int32)
-            nz = pack_noise(mode, plan, noise, lo, hi).to(device)
+            if noise_source == 'cpu':
+                nz = pack_noise(mode, plan, noise, lo, hi).to(device)
+            else:
+                nz = draw_noise(mode, hi - lo, plan.T, model.n_classes, model.rnn_dims, model.aux_dims, device, 'device')
             if loop_fn is None:
                 eng = model._loop_engine()
-                res = eng.run_segments(mels_up, aux, seg_pos, seg_lim, plan.T, nz, hop, algo=model.loop_algo)
-                model.last_loop_ms, model.last_loop_kernel = eng.last_loop_ms(), eng.last_loop_kernel()
+                res = eng.run_segments(mels_up, aux, seg_pos, seg_lim, plan.T, nz, hop, algo=model.loop_algo, check=check)
             else:
                 res = loop_fn(mels_up, aux, seg_pos, seg_lim, plan.T, nz, hop)
             out_local[:hi - lo] = res
@@ -175,6 +182,9 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
         return segs, plan
     outs = []
     for u, n in enumerate(frames):
+        if finish == 'own' and not (lo <= plan.first[u] < hi):
+            outs.append(None)
+            continue
         y = segs[plan.first[u]:plan.first[u] + plan.folds[u]].copy()
         if mu_law:
             y = _fold.decode_mu_law(y, model.n_classes, False)
