@@ -42,7 +42,7 @@ def cpu_baseline(sd, mode, frames, target, overlap, budget_s):
     mel = random_mel(1234, frames)
     mels, aux, wave_len = O.conditioning(sd, mel, True, target, overlap)
     B, T, _ = mels.shape
-    noise = O.draw_noise(77, mode, B, min(T, 4000))
+    noise = O.draw_noise(77, mode, B, T)
     # pick the OpenMP width that is fastest on this host (the layer-by-layer barriers make very wide teams slower)
     ncpu = os.cpu_count() or 1
     best = None
@@ -76,7 +76,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--utterances', type=int, default=8, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=641, help='mel frames per utterance')
-    ap.add_argument('--algo', default='auto', choices=['auto', 'cluster', 'persist', 'stream'])
+    ap.add_argument('--algo', default='auto', choices=['auto', 'pipe', 'cluster', 'persist', 'stream'])
     ap.add_argument('--parity-noise', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -155,9 +155,9 @@ def main():
         # algorithmic bytes per batch step = W + n*836; one launch = T batch steps
         bytes_per_launch = (W + n_local * 836) * T
         achieved = bytes_per_launch / (kms * 1e-3) / 1e9
-        flops_per_launch = 2.0 * (W / 4.0) * n_local * T     # 2 flops per weight per segment-step
+        flops_per_launch = 2.0 * 3825152 * n_local * T if mode == 'MOL' else 2.0 * 4071936 * n_local * T
         tf = flops_per_launch / (kms * 1e-3) / 1e12
-        u_per_wg, ncl = eng.last_loop_split()
+        u_per_wg, ncl, depth = eng.last_loop_split()
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
         if os.path.exists(tpath):
@@ -174,22 +174,30 @@ def main():
                                    f'overlap={overlap}) on a batch of {args.utterances} random {args.frames}-frame mels per GPU '
                                    f'-> {n_local} folded segments x T={T} steps in one launch per GPU, '
                                    f'{wave_total // world} output samples per GPU per step',
-                       'kernel': eng.last_loop_kernel(), 'units_per_workgroup': u_per_wg, 'clusters': ncl,
+                       'kernel': eng.last_loop_kernel(), 'units_per_workgroup': u_per_wg, 'clusters': ncl, 'groups_in_flight_per_cluster': depth,
                        'segment_steps_per_s': round(plan.n_segments * T * args.steps / dt, 1),
                        'noise': 'host MT19937 stream (parity mode)' if args.parity_noise else 'device Philox (as the reference on a GPU)',
                        'parallelism': f'{world} x (1 process per GPU, contiguous block of the segment table, RCCL all-gather of audio)'},
-            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
-                         'kernel': eng.last_loop_kernel(), 'kernel_ms': round(kms, 3),
-                         'algorithmic_bytes_per_launch': bytes_per_launch,
-                         'note': 'weight-streaming-equivalent bandwidth, SURVEY.md 8(d): (W + n*836 B) per batch step x T steps '
-                                 '/ kernel time (HIP events on the launch stream); the weights are on-chip resident, so this '
-                                 'is a latency figure of merit, not HBM traffic (DESIGN.md)'},
-            'roofline_mfma': {'bound': 'mfma', 'achieved': round(tf, 3), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
-                              'frac': round(tf / MFMA_F32_PEAK_TF, 5),
-                              'note': 'useful f32 FLOPs of the loop (2 x 3.83 M weights per segment-step) / kernel time vs the '
-                                      'dense f32 MFMA peak'},
         }
+        # Which roofline bounds the loop: arithmetic intensity = 2n FLOP per 4 weight bytes = n/2 FLOP/B for n
+        # segments per weight pass; the f32 ridge of gfx950 is 157.3 TF / 6.3 TB/s = 25 FLOP/B, i.e. weight-bandwidth-bound
+        # below ~50 resident segments and f32-MFMA-bound above.  The other figure is reported beside it.
+        hbm = {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+               'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'kernel': eng.last_loop_kernel(),
+               'kernel_ms': round(kms, 3), 'algorithmic_bytes_per_launch': bytes_per_launch,
+               'note': 'weight-streaming-equivalent bandwidth, SURVEY.md 8(d): (W + n*836 B) per batch step x T steps / kernel '
+                       'time (HIP events on the launch stream); the weights are on-chip resident, so this is a per-step latency '
+                       'figure of merit, not HBM traffic (DESIGN.md)'}
+        mfma = {'bound': 'mfma', 'achieved': round(tf, 3), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
+                'frac': round(tf / MFMA_F32_PEAK_TF, 5), 'traffic': traffic, 'kernel': eng.last_loop_kernel(),
+                'kernel_ms': round(kms, 3), 'algorithmic_flops_per_launch': flops_per_launch,
+                'note': 'useful f32 FLOPs of the loop (2 x 3,825,152 weights per segment-step x n x T) / kernel time (HIP events '
+                        'on the launch stream) vs the dense f32 MFMA peak; n >= 50 resident segments puts the loop right of the '
+                        'f32 ridge (SURVEY.md 8d)'}
+        if n_local >= 50:
+            res['roofline'], res['roofline_hbm_equivalent'] = mfma, hbm
+        else:
+            res['roofline'], res['roofline_mfma'] = hbm, mfma
         if not args.no_cpu_baseline and world == 1:
             try:
                 res['cpu_baseline'] = cpu_baseline(sd, mode, args.frames, target, overlap, args.cpu_seconds)

@@ -42,11 +42,13 @@ enum { WRNN_MODE_RAW = 0, WRNN_MODE_MOL = 1 };  /* reference: WaveRNN(mode='RAW'
 
 /* Loop kernel selection. */
 enum {
-    WRNN_ALGO_AUTO = 0,     /* clustered persistent kernel when the device admits it, else stream */
+    WRNN_ALGO_AUTO = 0,     /* pipelined / clustered persistent kernel when the device admits it, else stream */
     WRNN_ALGO_STREAM = 1,   /* one workgroup per folded segment, weights streamed from L2/MALL each step */
     WRNN_ALGO_PERSIST = 2,  /* chip-wide persistent kernel: one cooperative launch per group of <= 16 segments */
-    WRNN_ALGO_CLUSTER = 3   /* clustered persistent kernel: 1, 2 or 4 independent CU clusters, each with a full
+    WRNN_ALGO_CLUSTER = 3,  /* clustered persistent kernel: 1, 2 or 4 independent CU clusters, each with a full
                                on-chip copy of the weights, all groups of <= 16 segments in ONE launch */
+    WRNN_ALGO_PIPE = 4      /* pipelined clustered kernel (MOL): 4 clusters x up to 3 groups in flight per cluster,
+                               interleaved stage by stage so the inter-CU exchange latency hides behind MFMA work */
 };
 
 /*
@@ -152,10 +154,11 @@ int wrnn_status(void *workspace, void *stream);
  * synchronises).  <0 if unavailable. */
 float wrnn_last_loop_ms(const wrnn_pack *p);
 /* name of the loop kernel the last wrnn_generate launched
- * ("wrnn_cluster_kernel" / "wrnn_persist_kernel" / "wrnn_stream_kernel") */
+ * ("wrnn_pipe_kernel" / "wrnn_cluster_kernel" / "wrnn_persist_kernel" / "wrnn_stream_kernel") */
 const char *wrnn_last_loop_kernel(const wrnn_pack *p);
-/* how that kernel split the chip: hidden units per workgroup and number of independent clusters (0,0 = stream) */
-int wrnn_last_loop_split(const wrnn_pack *p, int *units_per_wg, int *clusters);
+/* how that kernel split the chip: hidden units per workgroup, number of independent clusters and groups of segments in
+ * flight per cluster (0,0,0 = stream) */
+int wrnn_last_loop_split(const wrnn_pack *p, int *units_per_wg, int *clusters, int *groups_in_flight);
 
 /* Self tests of the device primitives (MFMA fragment layout, inter-workgroup granule all-gather).
  * Synchronous.  WRNN_OK or an error with a message. */

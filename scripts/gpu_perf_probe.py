@@ -16,8 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--T', type=int, default=1500)
 ap.add_argument('--mode', default='MOL')
 ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'probe.json'))
-ap.add_argument('--B', default='12,16,32,48,64,96,128,192,256')
-ap.add_argument('--variants', default='persist,u2,u4,u8,u8nl16')
+ap.add_argument('--B', default='12,64,120,128,180,192,256,360')
+ap.add_argument('--variants', default='u4,u8,p1,p2,p3,p3nl16')
 args = ap.parse_args()
 
 dev = torch.device('cuda', 0)
@@ -27,7 +27,9 @@ eng = LoopEngine(sd, mode, device=dev)
 rs = np.random.RandomState(3)
 VARS = {'persist': ('persist', {}), 'u2': ('cluster', {'WRNN_CLUSTER_U': '2'}), 'u4': ('cluster', {'WRNN_CLUSTER_U': '4'}),
         'u8': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '8'}),
-        'u8nl16': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '16'}), 'auto': ('auto', {})}
+        'u8nl16': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '16'}), 'auto': ('auto', {}),
+        'p1': ('pipe', {'WRNN_PIPE_G': '1'}), 'p2': ('pipe', {'WRNN_PIPE_G': '2'}), 'p3': ('pipe', {'WRNN_PIPE_G': '3'}),
+        'p3nl16': ('pipe', {'WRNN_PIPE_G': '3', 'WRNN_PIPE_NL': '16'}), 'p2nl16': ('pipe', {'WRNN_PIPE_G': '2', 'WRNN_PIPE_NL': '16'})}
 rows = []
 for B in [int(x) for x in args.B.split(',')]:
     stride = 64
@@ -42,11 +44,11 @@ for B in [int(x) for x in args.B.split(',')]:
     ref = None
     for v in args.variants.split(','):
         algo, env = VARS[v]
-        if mode == 'RAW' and v.startswith('u8'):
+        if mode == 'RAW' and (v.startswith('u8') or v.startswith('p')) and v != 'persist':
             continue
         if v == 'persist' and B > 64:
             continue
-        for k in ('WRNN_CLUSTER_U', 'WRNN_CLUSTER_NL'):
+        for k in ('WRNN_CLUSTER_U', 'WRNN_CLUSTER_NL', 'WRNN_PIPE_G', 'WRNN_PIPE_NL'):
             os.environ.pop(k, None)
         os.environ.update(env)
         try:
@@ -57,13 +59,12 @@ for B in [int(x) for x in args.B.split(',')]:
             if ref is None:
                 ref = o
             err = float(np.abs(o - ref).max())
-            groups = (B + 15) // 16
-            u, ncl = eng.last_loop_split()
-            rounds = 1 if algo == 'persist' and False else max(1, -(-groups // max(ncl, 1)))
-            if algo == 'persist':
-                rounds = groups
-            row = dict(variant=v, B=B, T=T, ms=round(ms, 3), us_per_group_step=round(ms * 1e3 / (T * rounds), 3),
-                       seg_steps_per_s=round(B * T / (ms * 1e-3)), split=[u, ncl], max_dev_vs_first=err)
+            u, ncl, gdepth = eng.last_loop_split()
+            rows_g = 15 if gdepth >= 3 else 16
+            groups = -(-B // rows_g)
+            rounds = groups if algo == 'persist' else max(1, -(-groups // max(ncl * max(gdepth, 1), 1)))
+            row = dict(variant=v, B=B, T=T, ms=round(ms, 3), us_per_round_step=round(ms * 1e3 / (T * rounds), 3),
+                       seg_steps_per_s=round(B * T / (ms * 1e-3)), split=[u, ncl, gdepth], max_dev_vs_first=err)
         except Exception as e:
             row = dict(variant=v, B=B, error=str(e)[:200])
         rows.append(row)

@@ -51,13 +51,23 @@ VARIANTS = {
     'cluster-u4': ('cluster', {'WRNN_CLUSTER_U': '4'}),
     'cluster-u8': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '8'}),
     'cluster-u8-nl16': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '16'}),
+    'pipe-g1': ('pipe', {'WRNN_PIPE_G': '1'}),
+    'pipe-g2': ('pipe', {'WRNN_PIPE_G': '2'}),
+    'pipe-g3': ('pipe', {'WRNN_PIPE_G': '3'}),
+    'pipe-g3-nl16': ('pipe', {'WRNN_PIPE_G': '3', 'WRNN_PIPE_NL': '16'}),
 }
-KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'persist': 'wrnn_persist_kernel', 'cluster': 'wrnn_cluster_kernel'}
+KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'persist': 'wrnn_persist_kernel', 'cluster': 'wrnn_cluster_kernel',
+               'pipe': 'wrnn_pipe_kernel'}
+ENV_KEYS = ('WRNN_CLUSTER_U', 'WRNN_CLUSTER_NL', 'WRNN_PIPE_G', 'WRNN_PIPE_NL')
+
+
+def _mol_only(variant):
+    return variant.startswith('cluster-u8') or variant.startswith('pipe')
 
 
 def _select(monkeypatch, variant):
     algo, env = VARIANTS[variant]
-    for k in ('WRNN_CLUSTER_U', 'WRNN_CLUSTER_NL'):
+    for k in ENV_KEYS:
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -82,8 +92,8 @@ def test_loop_matches_reference_golden(gpu, name, variant, monkeypatch):
     from oracle import c_oracle as C
     from wavernn_amd.engine import LoopEngine
     cfg, g = load_case(name)
-    if cfg['mode'] == 'RAW' and variant.startswith('cluster-u8'):
-        pytest.skip('the U = 8 split exists for MOL only')
+    if cfg['mode'] == 'RAW' and _mol_only(variant):
+        pytest.skip('the U = 8 split / the pipelined kernel exist for MOL only')
     algo = _select(monkeypatch, variant)
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     eng = LoopEngine(sd, cfg['mode'], device=gpu)
@@ -92,6 +102,8 @@ def test_loop_matches_reference_golden(gpu, name, variant, monkeypatch):
     assert eng.last_loop_kernel() == KERNEL_NAME[algo]
     if algo == 'cluster':
         assert eng.last_loop_split()[0] == int(VARIANTS[variant][1]['WRNN_CLUSTER_U'])
+    if algo == 'pipe':
+        assert eng.last_loop_split()[2] == int(VARIANTS[variant][1]['WRNN_PIPE_G'])
     mels_f, aux_f, _ = __import__('oracle.wavernn_oracle', fromlist=['x']).conditioning(sd, mel, cfg['batched'], cfg['target'], cfg['overlap'])
     ref = C.loop(sd, cfg['mode'], mels_f, aux_f, noise)
     if cfg['mode'] == 'RAW':
@@ -103,7 +115,7 @@ def test_loop_matches_reference_golden(gpu, name, variant, monkeypatch):
         assert np.abs(out - ref).max() <= MOL_TOL
 
 
-@pytest.mark.parametrize('variant', ['stream', 'persist', 'cluster-u4', 'cluster-u8'])
+@pytest.mark.parametrize('variant', ['stream', 'persist', 'cluster-u4', 'cluster-u8', 'pipe-g2'])
 @pytest.mark.parametrize('name', ['raw_batched_60f', 'mol_batched_100f'])
 def test_teacher_forced_logits(gpu, name, variant, monkeypatch):
     """Feed the reference's samples back (teacher forcing) and compare every step's fc3 logits with the C
@@ -111,8 +123,8 @@ def test_teacher_forced_logits(gpu, name, variant, monkeypatch):
     from oracle import c_oracle as C, wavernn_oracle as O
     from wavernn_amd.engine import LoopEngine
     cfg, g = load_case(name)
-    if cfg['mode'] == 'RAW' and variant.startswith('cluster-u8'):
-        pytest.skip('the U = 8 split exists for MOL only')
+    if cfg['mode'] == 'RAW' and _mol_only(variant):
+        pytest.skip('the U = 8 split / the pipelined kernel exist for MOL only')
     algo = _select(monkeypatch, variant)
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     mels_f, aux_f, _ = O.conditioning(sd, mel, cfg['batched'], cfg['target'], cfg['overlap'])
@@ -153,7 +165,8 @@ def test_generate_end_to_end(gpu, name, tmp_path):
     assert np.array_equal(torch.empty(4).uniform_(0, 1).numpy(), st.uniform_(4, 0, 1))
 
 
-@pytest.mark.parametrize('variant', ['cluster-u2', 'cluster-u4', 'cluster-u8', 'cluster-u8-nl16', 'persist'])
+@pytest.mark.parametrize('variant', ['cluster-u2', 'cluster-u4', 'cluster-u8', 'cluster-u8-nl16', 'persist', 'pipe-g1', 'pipe-g2',
+                                     'pipe-g3', 'pipe-g3-nl16'])
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_many_segments_all_clusters(gpu, mode, variant, monkeypatch):
     """46 folded segments (the last one zero-padded): 4 groups on the 4-cluster split, 4 groups = two per cluster on the
@@ -161,8 +174,8 @@ def test_many_segments_all_clusters(gpu, mode, variant, monkeypatch):
     C oracle.  RAW bit-exact, MoL <= MOL_TOL."""
     from oracle import c_oracle as C, wavernn_oracle as O
     from wavernn_amd.engine import LoopEngine
-    if mode == 'RAW' and variant.startswith('cluster-u8'):
-        pytest.skip('the U = 8 split exists for MOL only')
+    if mode == 'RAW' and _mol_only(variant):
+        pytest.skip('the U = 8 split / the pipelined kernel exist for MOL only')
     cfg = dict(mode=mode, wseed=31, mseed=131, frames=100, batched=True, target=550, overlap=55, seed=91)
     algo = _select(monkeypatch, variant)
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
@@ -179,7 +192,27 @@ def test_many_segments_all_clusters(gpu, mode, variant, monkeypatch):
         assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
 
 
-@pytest.mark.parametrize('variant', ['stream', 'cluster-u4', 'cluster-u8'])
+@pytest.mark.parametrize('variant', ['cluster-u8', 'pipe-g1', 'pipe-g2', 'pipe-g3'])
+def test_more_segments_than_slots(gpu, variant, monkeypatch):
+    """114 segments x 264 steps (MoL): more 16-segment groups than the 4 clusters hold at once, so the single-depth
+    kernels run two rounds back to back inside one launch (tags keep counting) and the deeper pipelines fill every
+    slot -- against the C oracle."""
+    from oracle import c_oracle as C, wavernn_oracle as O
+    from wavernn_amd.engine import LoopEngine
+    cfg = dict(mode='MOL', wseed=32, mseed=132, frames=100, batched=True, target=220, overlap=22, seed=92)
+    algo = _select(monkeypatch, variant)
+    sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
+    assert (B, T) == (114, 264)
+    mels_f, aux_f, _ = O.conditioning(sd, mel, True, cfg['target'], cfg['overlap'])
+    ref = C.loop(sd, 'MOL', mels_f, aux_f, noise)
+    eng = LoopEngine(sd, 'MOL', device=gpu)
+    out = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
+                  torch.from_numpy(flat).to(gpu), 275, algo=algo).cpu().numpy()
+    assert eng.last_loop_kernel() == KERNEL_NAME[algo]
+    assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
+
+
+@pytest.mark.parametrize('variant', ['stream', 'cluster-u4', 'cluster-u8', 'pipe-g2', 'pipe-g3'])
 def test_segment_table_several_utterances(gpu, variant, monkeypatch):
     """`run_segments`: three utterances of different length, conditioning concatenated, ONE launch -- every utterance's
     segments must equal that utterance generated alone (C oracle on its own folded conditioning)."""
@@ -232,9 +265,9 @@ def test_full_size_properties(gpu, mode):
     else:
         noise = torch.empty(T, B, 512).exponential_(1, generator=g).to(gpu)
     eng = LoopEngine(sd, mode, device=gpu)
-    a = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='cluster').cpu().numpy()
+    a = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='auto').cpu().numpy()
     ms, split = eng.last_loop_ms(), eng.last_loop_split()
-    b = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='cluster').cpu().numpy()
+    b = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='auto').cpu().numpy()
     s = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='stream').cpu().numpy()
     print(f'{mode} cluster loop (split {split}) {ms:.1f} ms for {B}x{T} segment-steps; stream {eng.last_loop_ms():.1f} ms')
     assert np.array_equal(a, b), 'persistent kernel is not deterministic'

@@ -13,8 +13,8 @@ SO_PATH = os.path.join(CSRC, 'libwavernn_amd.so')
 
 WRNN_OK = 0
 MODE_RAW, MODE_MOL = 0, 1
-ALGO_AUTO, ALGO_STREAM, ALGO_PERSIST, ALGO_CLUSTER = 0, 1, 2, 3
-ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'persist': ALGO_PERSIST, 'cluster': ALGO_CLUSTER}
+ALGO_AUTO, ALGO_STREAM, ALGO_PERSIST, ALGO_CLUSTER, ALGO_PIPE = 0, 1, 2, 3, 4
+ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'persist': ALGO_PERSIST, 'cluster': ALGO_CLUSTER, 'pipe': ALGO_PIPE}
 
 #: every symbol include/wavernn_amd.h declares
 EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_create', 'wrnn_pack_destroy',
@@ -88,7 +88,8 @@ def lib():
                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                          ctypes.POINTER(Debug), ctypes.c_void_p]
-    L.wrnn_last_loop_split.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    L.wrnn_last_loop_split.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                       ctypes.POINTER(ctypes.c_int)]
     L.wrnn_status.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.wrnn_last_loop_ms.argtypes = [ctypes.c_void_p]
     L.wrnn_last_loop_ms.restype = ctypes.c_float

@@ -17,6 +17,9 @@ hipError_t launch_stream(const LoopArgs &args, int mode, hipStream_t stream);
 hipError_t launch_persist(const LoopArgs &args, int U, int mode, hipStream_t stream);
 hipError_t launch_cluster(const LoopArgs &args, int U, int ncl, int mode, int nl, hipStream_t stream);
 int cluster_count(int U, int n_cus);
+hipError_t launch_pipe(const LoopArgs &args, int G, int ncl, int nl, hipStream_t stream);
+int pipe_rows(int G);
+int pipe_clusters(int n_cus);
 size_t persist_lds_bytes();
 int selftest_mfma(char *msg, size_t n);
 int selftest_allgather(int n_cus, char *msg, size_t n, float *us_per_round);
@@ -54,7 +57,7 @@ struct wrnn_pack {
     hipEvent_t ev0, ev1;
     bool timed;
     const char *last_kernel;
-    int last_U, last_ncl;
+    int last_U, last_ncl, last_G;
 };
 
 extern "C" const char *wrnn_last_error(void) { return g_err; }
@@ -159,7 +162,7 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     hipEventCreate(&p->ev1);
     p->timed = false;
     p->last_kernel = "";
-    p->last_U = 0; p->last_ncl = 0;
+    p->last_U = 0; p->last_ncl = 0; p->last_G = 0;
     *out = p;
     return WRNN_OK;
 }
@@ -179,7 +182,7 @@ namespace {
 struct WsLayout {
     size_t status, gran, segs, c2f, c3f, c4f, cI, total;
 };
-constexpr size_t GRAN_BYTES = (size_t)MAXCL * NGRAN * SEG * H * sizeof(u64);
+constexpr size_t GRAN_BYTES = (size_t)GRAN_WORDS * sizeof(u64);
 size_t al(size_t x) { return (x + 255) / 256 * 256; }
 WsLayout ws_layout(int B, int T, int n_frames)
 {
@@ -284,9 +287,46 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
     // cluster: clustered persistent kernel (all groups in one launch); persist: the chip-wide kernel, one launch
     // per 16-segment group; stream: one workgroup per segment.  auto = cluster where the device admits it.
     const bool shape_ok = (p->mode == WRNN_MODE_MOL) || (p->C == H);
-    enum { K_STREAM, K_PERSIST, K_CLUSTER } kind = K_STREAM;
-    int U = 0, ncl = 0;
-    if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_CLUSTER) {
+    enum { K_STREAM, K_PERSIST, K_CLUSTER, K_PIPE } kind = K_STREAM;
+    int U = 0, ncl = 0, G = 0;
+    if ((algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_PIPE) && p->mode == WRNN_MODE_MOL) {
+        // pipelined kernel: pays once a cluster has more than one group to run (B > 16 segments per cluster)
+        const int pcl = pipe_clusters(p->n_cus);
+        const char *envg = getenv("WRNN_PIPE_G");
+        int g = envg ? atoi(envg) : 0;
+        if (pcl >= 1 && (algo == WRNN_ALGO_PIPE || B > SEG * pcl)) {
+            if (g < 1 || g > MAXG) {
+                // depth that minimises rounds x (relative step time of that depth); deeper pipelines hide more of
+                // the exchange latency but lengthen the step (measured: profiles/)
+                static const double rel_step[MAXG + 1] = {0.0, 1.0, 1.05, 1.2};
+                double best = 1e30;
+                for (int c = 1; c <= MAXG; ++c) {
+                    const int rows_c = pipe_rows(c);
+                    const int rounds_c = ((B + rows_c - 1) / rows_c + pcl * c - 1) / (pcl * c);
+                    const double cost = rounds_c * rel_step[c];
+                    if (cost < best - 1e-9) { best = cost; g = c; }
+                }
+            }
+            const int rows = pipe_rows(g);
+            const int groups = (B + rows - 1) / rows;
+            const int rounds = (groups + pcl * g - 1) / (pcl * g);
+            const long ng = (long)rounds * pcl * g;
+            if ((double)rounds * T < 4.0e9) {
+                kind = K_PIPE; G = g; ncl = pcl; U = 8;
+                a.NG = ng < B ? (int)ng : B;
+            }
+        }
+        if (kind != K_PIPE && algo == WRNN_ALGO_PIPE) {
+            set_err("pipelined kernel needs >= 64 CUs and MOL mode; device has %d CUs", p->n_cus);
+            return WRNN_ERR_RESIDENCY;
+        }
+    } else if (algo == WRNN_ALGO_PIPE) {
+        set_err("the pipelined kernel exists for MOL only");
+        return WRNN_ERR_ARG;
+    }
+    if (kind == K_PIPE) {
+        // chosen above
+    } else if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_CLUSTER) {
         if (shape_ok && (double)a.NG * T < 4.0e9) {
             const char *envu = getenv("WRNN_CLUSTER_U");
             const int want = envu ? atoi(envu) : 0;
@@ -322,12 +362,23 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
             return WRNN_ERR_RESIDENCY;
         }
         kind = K_PERSIST;
-    } else if (algo != WRNN_ALGO_STREAM) { set_err("unknown algo %d", algo); return WRNN_ERR_ARG; }
+    } else if (algo != WRNN_ALGO_STREAM && algo != WRNN_ALGO_PIPE) { set_err("unknown algo %d", algo); return WRNN_ERR_ARG; }
 
     HIPCHK(hipEventRecord(p->ev0, stream));
-    if (kind == K_CLUSTER) {
+    if (kind == K_PIPE) {
+        p->last_kernel = "wrnn_pipe_kernel";
+        p->last_U = U; p->last_ncl = ncl; p->last_G = G;
+        HIPCHK(hipMemsetAsync(ws + l.gran, 0, GRAN_BYTES, stream));
+        const char *envn = getenv("WRNN_PIPE_NL");
+        hipError_t e = launch_pipe(a, G, ncl, envn ? atoi(envn) : 8, stream);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_err("pipelined cooperative launch failed: %s", hipGetErrorString(e));
+            return e == hipErrorCooperativeLaunchTooLarge ? WRNN_ERR_RESIDENCY : WRNN_ERR_HIP;
+        }
+    } else if (kind == K_CLUSTER) {
         p->last_kernel = "wrnn_cluster_kernel";
-        p->last_U = U; p->last_ncl = ncl;
+        p->last_U = U; p->last_ncl = ncl; p->last_G = 1;
         HIPCHK(hipMemsetAsync(ws + l.gran, 0, GRAN_BYTES, stream));
         const char *envn = getenv("WRNN_CLUSTER_NL");
         hipError_t e = launch_cluster(a, U, ncl, p->mode, envn ? atoi(envn) : 0, stream);
@@ -343,7 +394,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
         }
     } else if (kind == K_PERSIST) {
         p->last_kernel = "wrnn_persist_kernel";
-        p->last_U = U; p->last_ncl = 1;
+        p->last_U = U; p->last_ncl = 1; p->last_G = 1;
         for (int b0 = 0; b0 < B; b0 += SEG) {
             a.b0 = b0;
             a.nb = (B - b0 < SEG) ? (B - b0) : SEG;
@@ -358,7 +409,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
     }
     if (kind == K_STREAM) {
         p->last_kernel = "wrnn_stream_kernel";
-        p->last_U = 0; p->last_ncl = 0;
+        p->last_U = 0; p->last_ncl = 0; p->last_G = 0;
         a.b0 = 0;
         a.nb = B;
         HIPCHK(launch_stream(a, p->mode, stream));
@@ -404,11 +455,12 @@ extern "C" float wrnn_last_loop_ms(const wrnn_pack *p)
 
 extern "C" const char *wrnn_last_loop_kernel(const wrnn_pack *p) { return p ? p->last_kernel : ""; }
 
-extern "C" int wrnn_last_loop_split(const wrnn_pack *p, int *units_per_wg, int *clusters)
+extern "C" int wrnn_last_loop_split(const wrnn_pack *p, int *units_per_wg, int *clusters, int *groups_in_flight)
 {
     if (!p) { set_err("NULL pack"); return WRNN_ERR_ARG; }
     if (units_per_wg) *units_per_wg = p->last_U;
     if (clusters) *clusters = p->last_ncl;
+    if (groups_in_flight) *groups_in_flight = p->last_G;
     return WRNN_OK;
 }
 

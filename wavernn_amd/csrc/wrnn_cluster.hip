@@ -26,11 +26,9 @@
 //     the argmax / softmax reductions.
 //   * conditioning products that do not depend on the recurrence were hoisted (wrnn_cond.hip); GRU
 //     hidden-to-hidden products (W_hh.h) depend only on the previous step and run while granules are in flight.
-#include "wrnn_device.h"
+#include "wrnn_tiles.h"
 
 namespace wrnn {
-
-constexpr int LDC = 520;            // LDS row stride (floats) of activation / fc3 tiles in this kernel
 
 template <int U>
 struct ClusterCfg {
@@ -62,119 +60,6 @@ struct ClusterCfg {
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
     static_assert(OFF_HS % 4 == 0 && OFF_W3 % 4 == 0 && OFF_PART % 4 == 0 && OFF_WI0 % 2 == 0, "alignment");
 };
-
-// A operand from LDS (fc3): lane reads W[fi][kbase + 16r + 4(l>>4) .. +3] exactly like the activation operand
-__device__ __forceinline__ f32x4 mfma_tile_lds(const float *w_lane, const float *act_lane)
-{
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < AF / 4; r += 2) {
-        const float4 a0 = *reinterpret_cast<const float4 *>(w_lane + 16 * r);
-        const float4 a1 = *reinterpret_cast<const float4 *>(w_lane + 16 * (r + 1));
-        const float4 b0 = *reinterpret_cast<const float4 *>(act_lane + 16 * r);
-        const float4 b1 = *reinterpret_cast<const float4 *>(act_lane + 16 * (r + 1));
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
-    }
-    return acc0 + acc1;
-}
-
-// partial tile of wave w, slot s -> part[(w*NSLOT + s)*256 + i*16 + j]
-template <int NSLOT>
-__device__ __forceinline__ void put_partial(float *part, int w, int s, int lane, f32x4 acc)
-{
-    float *p = part + (w * NSLOT + s) * 256 + ((lane >> 4) * 4) * 16 + (lane & 15);
-    p[0] = acc[0]; p[16] = acc[1]; p[32] = acc[2]; p[48] = acc[3];
-}
-
-// fragment row ri (0 .. 16*RT-1) of slot block `base` (0 critical / RT off-path), segment j: sum over the 4 waves
-template <int NSLOT>
-__device__ __forceinline__ float get_partial(const float *part, int base, int ri, int j)
-{
-    const int o = (base + (ri >> 4)) * 256 + (ri & 15) * 16 + j;
-    float s = part[o];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) s += part[w * NSLOT * 256 + o];
-    return s;
-}
-
-// Sweep one layer of this cluster's granules (byte offset `soff` into the buffer resource) until every tag
-// matches; thread (r = tid>>4, c = tid&15) owns row r (segment), column pairs own_col(i, c).  Writes the values
-// to dst[r][..] and, if ADD, adds them onto acc[r][..] (the residual adds of fatchord_version.py:212,216).
-// NL = loads in flight per thread: 16 = the whole row slice at once (64 registers); 8 = two dependent half
-// sweeps per pass (32 registers; used where the register file is full of weights, U = 8).
-template <bool ADD, int NL>
-__device__ __forceinline__ bool sweep_layer(__amdgpu_buffer_rsrc_t rs, int soff, unsigned tag, int nb, int tid,
-                                            float *dst, float *acc, unsigned *status)
-{
-    const int r = tid >> 4, c = tid & 15;
-    if (r >= nb) return true;
-    const int voff = r * (H * 8) + c * 16;
-    unsigned spins = 0;
-    if (NL == 16) {
-        u32x4 x[16];
-        for (;;) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * 256, soff, 16 /* sc1 */);
-            bool ok = true;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) ok &= (x[i].y == tag) & (x[i].w == tag);
-            if (ok) break;
-            ++spins;
-            if ((spins & 255u) == 0u) {
-                if (spins > SPIN_LIMIT || ld_agent32(status) != 0u) return false;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float2 v = make_float2(__uint_as_float(x[i].x), __uint_as_float(x[i].z));
-            *reinterpret_cast<float2 *>(dst + r * LDC + own_col(i, c)) = v;
-            if (ADD) {
-                float2 s = *reinterpret_cast<float2 *>(acc + r * LDC + own_col(i, c));
-                s.x += v.x; s.y += v.y;
-                *reinterpret_cast<float2 *>(acc + r * LDC + own_col(i, c)) = s;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            u32x4 x[8];
-            for (;;) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (8 * half + i) * 256, soff, 16 /* sc1 */);
-                bool ok = true;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ok &= (x[i].y == tag) & (x[i].w == tag);
-                if (ok) break;
-                ++spins;
-                if ((spins & 255u) == 0u) {
-                    if (spins > SPIN_LIMIT || ld_agent32(status) != 0u) return false;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int col = own_col(8 * half + i, c);
-                const float2 v = make_float2(__uint_as_float(x[i].x), __uint_as_float(x[i].z));
-                *reinterpret_cast<float2 *>(dst + r * LDC + col) = v;
-                if (ADD) {
-                    float2 s = *reinterpret_cast<float2 *>(acc + r * LDC + col);
-                    s.x += v.x; s.y += v.y;
-                    *reinterpret_cast<float2 *>(acc + r * LDC + col) = s;
-                }
-            }
-        }
-    }
-    return true;
-}
 
 // U: hidden units per workgroup (2, 4 or 8).  MODE: 0 RAW (C == 512), 1 MOL (C == 30).  NL: sweep loads in flight.
 template <int U, int MODE, int NL>

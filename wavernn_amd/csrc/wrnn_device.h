@@ -18,7 +18,9 @@ constexpr int KCOND = MEL + AUX;   // conditioning inputs of the I layer (112)
 constexpr int SEG = 16;       // segments per persistent launch group (= MFMA N)
 constexpr int LDA = 516;      // padded row stride (floats) of the LDS activation tiles
 constexpr int NGRAN = 5;      // granule buffers: h1, h2, y1, y2, (RAW) logits
-constexpr int MAXCL = 4;      // cluster kernel: at most 4 independent clusters per chip
+constexpr int MAXCL = 4;      // cluster kernels: at most 4 independent clusters per chip
+constexpr int MAXG = 3;       // pipelined kernel: at most 3 groups in flight per cluster
+constexpr int GRAN_WORDS = MAXCL * MAXG * NGRAN * SEG * H;   // u64 granules in the workspace
 constexpr int STATUS_WORDS = 16;
 
 // Everything the loop kernels read.  All pointers are device pointers.
@@ -43,7 +45,7 @@ struct LoopArgs {
     const float *force_x;               // optional [Btot][T]
     float *out;                         // [Btot][T]
     float *dbg_logits;                  // optional [T][Btot][C]
-    u64 *gran;                          // [MAXCL][NGRAN][SEG][H] {tag,value} granules (persistent / cluster kernels)
+    u64 *gran;                          // [GRAN_WORDS] {tag,value} granules: cluster kernel [cl][layer][SEG][H], pipe kernel [cl][slot][layer][SEG][H]
     unsigned *status;                   // [STATUS_WORDS]: 0 abort flag, 1 code, 2 wg, 3 step, 4 detail
     // segment table: segment b, step t reads conditioning position p = seg_pos[b] + t; p >= seg_lim[b] is the
     // fold's zero padding (fatchord_version.py:326-330).  One utterance: seg_pos[b] = b*(target+overlap),

@@ -1,0 +1,435 @@
+// wrnn_pipe.hip -- the PIPELINED clustered persistent WaveRNN loop kernel (MOL) for MI355X (gfx950 / CDNA4).
+//
+// Same arithmetic, weight split and exchange protocol as wrnn_cluster.hip at U = 8 (4 clusters of 64 workgroups,
+// each cluster holds one fp32 copy of the loop weights in registers; reference models/fatchord_version.py:201-241),
+// but every cluster advances G INDEPENDENT groups of segments at once and interleaves them stage by stage:
+//
+//      for t:  S1(g0) S1(g1) S1(g2)  S2(g0) S2(g1) S2(g2)  S3(g0) ...  S6(g2)
+//
+// A stage of one group ends with publishing that group's granules; by the time the workgroup comes back to the
+// same group (G-1 other units later) its all-gather has landed, so the ~3-4 us exchange latency that bounds the
+// single-group kernels is hidden behind MFMA work on the other groups.
+//
+// What had to move to make G groups fit one CU:
+//   * LDS holds one activation tile per group (x = xi, then xi+h1, xi+h1+h2, y1, y2) plus ONE transient tile for
+//     the freshly gathered h (used at once for the residual add and the W_hh.h product of the NEXT step, then free
+//     for the next group).  G = 3 groups of <= 15 segments + the transient tile = 125 KB.
+//   * the 30-row MOL fc3 no longer fits LDS (62 KB replicated): it is DISTRIBUTED -- workgroup r < 30 of the cluster
+//     computes logit row r for all segments of the group (512-long VALU dot products over the gathered y2) and the
+//     30 logits per segment make a 5th, tiny all-gather (240 B per segment).  Sampling stays replicated.
+//   * cI(t+1) is fetched at the start of the sampling stage of each group (no per-group prefetch registers).
+// Register file: 10 weight tiles x 32 = 320 registers per lane, as in the U = 8 cluster kernel.
+#include "wrnn_tiles.h"
+
+namespace wrnn {
+
+constexpr int PU = 8;                 // hidden units per workgroup
+constexpr int PNWGC = H / PU;         // workgroups per cluster (64)
+constexpr int PGR = 3 * PU;           // GRU gate rows per workgroup (24)
+constexpr int PRT = 2;                // 16-row MFMA tiles per GRU matrix
+constexpr int PNSLOT = 4;             // partial-tile slots per wave: 0,1 critical; 2,3 hidden-to-hidden
+constexpr int PGHI = (PGR * SEG + NT - 1) / NT;
+
+template <int G>
+struct PipeCfg {
+    static constexpr int R = (G >= 3) ? 15 : 16;                     // segment rows per group tile
+    static constexpr int TILE = R * LDC;
+    static constexpr int GRP = 2 * PGR * SEG + 2 * PU * SEG + SEG;     // per-group small state: GH1 GH2 HOWN1 HOWN2 XS
+    static constexpr int OFF_HS = 0;                                   // [R][LDC] transient gathered h
+    static constexpr int OFF_ACT = OFF_HS + TILE;                      // [G][R][LDC]
+    static constexpr int OFF_PART = OFF_ACT + G * TILE;                // [NW][PNSLOT][16][16]
+    static constexpr int OFF_GRP = OFF_PART + NW * PNSLOT * 256;       // [G][GRP]
+    static constexpr int OFF_LOG = OFF_GRP + G * GRP;                  // [SEG][32] logits of the group being sampled
+    static constexpr int OFF_WI0 = OFF_LOG + SEG * 32;                 // [H]  I.weight[:,0]
+    static constexpr int OFF_W3R = OFF_WI0 + H;                        // [H]  fc3 row owned by this workgroup (wg < 30)
+    static constexpr int OFF_SCR = OFF_W3R + H;                        // [16 k-chunks][SEG] fc3 partial dot products
+    static constexpr int OFF_BI1 = OFF_SCR + 16 * SEG;                 // [PGR] b_ih1, then b_hh1, b_hh2 of the owned rows
+    static constexpr int OFF_BH1 = OFF_BI1 + PGR;
+    static constexpr int OFF_BH2 = OFF_BH1 + PGR;
+    static constexpr int OFF_GEO = OFF_BH2 + PGR;                      // [2*MAXG] ints: b0, nb of every slot
+    static constexpr int LDS_FLOATS = ((OFF_GEO + 2 * MAXG + 3) / 4) * 4;
+    static_assert(G >= 1 && G <= MAXG, "G in 1..MAXG");
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+    static_assert(TILE % 4 == 0 && OFF_PART % 4 == 0 && OFF_GRP % 4 == 0 && OFF_WI0 % 4 == 0, "alignment");
+};
+
+// G: groups in flight per cluster.  NL: sweep loads in flight per thread (16 or 8).
+template <int G, int NL>
+__global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
+{
+    using K = PipeCfg<G>;
+    constexpr int R = K::R;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *HS = smem + K::OFF_HS, *PART = smem + K::OFF_PART, *LOG = smem + K::OFF_LOG, *WI0 = smem + K::OFF_WI0;
+    float *W3R = smem + K::OFF_W3R, *SCR = smem + K::OFF_SCR;
+    float *BI1 = smem + K::OFF_BI1, *BH1 = smem + K::OFF_BH1, *BH2 = smem + K::OFF_BH2;
+    int *GEO = reinterpret_cast<int *>(smem + K::OFF_GEO);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // cluster / workgroup-in-cluster: whole XCDs per cluster (block b runs on XCD b % 8; speed only)
+    int cl, wg;
+    const int ncl = gridDim.x / PNWGC;
+    {
+        const int b = blockIdx.x, nblk = gridDim.x;
+        if (nblk % 8 == 0 && ncl >= 1 && 8 % ncl == 0) {
+            const int xpc = 8 / ncl, per_xcd = nblk / 8;
+            const int xcd = b % 8;
+            cl = xcd / xpc;
+            wg = (xcd % xpc) * per_xcd + b / 8;
+        } else {
+            cl = b / PNWGC;
+            wg = b % PNWGC;
+        }
+    }
+    const int fi = lane & 15, kq = lane >> 4;
+    const int kbase_lane = KCH * w + 4 * kq;
+    const int Btot = a.Btot, T = a.T, C = a.C, NG = a.NG;
+    const int er = tid >> 4, ec = tid & 15;             // elementwise / sweep role: row er, column pairs own_col(i, ec)
+    const int pu = tid >> 4, pj = tid & 15;             // pointwise role: (owned unit pu, segment pj) for tid < 16*PU
+    const bool pw_thread = tid < 16 * PU;
+    const int prow = PU * wg + (pu % PU);
+    const bool fc3_wg = wg < 30;                        // this workgroup owns logit row `wg`
+
+    // ---- one-time: weight slice -> register-resident MFMA A fragments (row ri = gate*PU + u, tile ri/16) ------
+    float A_ih1[PRT][AF], A_hh1[PRT][AF], A_ih2[PRT][AF], A_hh2[PRT][AF], A_fc1[AF], A_fc2[AF];
+#pragma unroll
+    for (int rt = 0; rt < PRT; ++rt) {
+        const int ri = 16 * rt + fi;
+        const bool vg = ri < PGR;
+        const int grow = (ri / PU) * H + PU * wg + (ri % PU);
+        load_afrag(A_ih1[rt], a.w_ih1, H, grow, vg, kbase_lane);
+        load_afrag(A_hh1[rt], a.w_hh1, H, grow, vg, kbase_lane);
+        load_afrag(A_ih2[rt], a.w_ih2, H + AUX, grow, vg, kbase_lane);
+        load_afrag(A_hh2[rt], a.w_hh2, H, grow, vg, kbase_lane);
+    }
+    {
+        const bool vf = fi < PU;
+        const int frow = PU * wg + fi;
+        load_afrag(A_fc1, a.fc1_w, H + AUX, frow, vf, kbase_lane);
+        load_afrag(A_fc2, a.fc2_w, H + AUX, frow, vf, kbase_lane);
+    }
+    for (int q = tid; q < K::LDS_FLOATS; q += NT) smem[q] = 0.f;       // no NaN bit patterns in never-written rows
+    __syncthreads();
+    WI0[2 * tid] = a.I_w0[2 * tid];
+    WI0[2 * tid + 1] = a.I_w0[2 * tid + 1];
+    if (fc3_wg) { W3R[2 * tid] = a.fc3_w[(size_t)wg * H + 2 * tid]; W3R[2 * tid + 1] = a.fc3_w[(size_t)wg * H + 2 * tid + 1]; }
+    const float b3 = fc3_wg ? a.fc3_b[wg] : 0.f;
+    if (tid < PGR) {
+        const int grow = (tid / PU) * H + PU * wg + (tid % PU);
+        BI1[tid] = a.b_ih1[grow];
+        BH1[tid] = a.b_hh1[grow];
+        BH2[tid] = a.b_hh2[grow];
+    }
+
+    const __amdgpu_buffer_rsrc_t grs = make_rsrc(a.gran, GRAN_WORDS * 8);
+    constexpr int LAYER_BYTES = SEG * H * 8;
+    constexpr int SLOT_BYTES = NGRAN * LAYER_BYTES;
+    const int soff_cl = cl * MAXG * SLOT_BYTES;
+
+    unsigned tagbase = 0u;
+    for (int round = 0;; ++round, tagbase += (unsigned)T) {
+        const int gfirst = cl + ncl * (round * G);
+        if (gfirst >= NG) break;
+        int nact = 0;                                                    // active slots of this round (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            if (gfirst + ncl * i < NG) nact = i + 1;
+        __syncthreads();                                                 // previous round's LDS reads are done
+        if (tid < G) {
+            const int g = gfirst + ncl * tid;
+            int b0 = 0, nb = 0;
+            if (g < NG) {
+                b0 = (int)(((long)g * Btot) / NG);
+                nb = (int)(((long)(g + 1) * Btot) / NG) - b0;
+            }
+            GEO[2 * tid] = b0;
+            GEO[2 * tid + 1] = nb;
+        }
+        // ---- state init (fatchord_version.py:194-196: h1 = h2 = 0, x = 0): gh = W_hh . 0 + b_hh = b_hh ----
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < nact; ++i) {
+            float *GP = smem + K::OFF_GRP + i * K::GRP;
+            float *ACT = smem + K::OFF_ACT + i * K::TILE;
+            const int b0 = GEO[2 * i], nb = GEO[2 * i + 1];
+            for (int q = tid; q < PGR * SEG; q += NT) { GP[q] = BH1[q >> 4]; GP[PGR * SEG + q] = BH2[q >> 4]; }
+            if (tid < 2 * PU * SEG) GP[2 * PGR * SEG + tid] = 0.f;                  // HOWN1 + HOWN2
+            if (tid < SEG) GP[2 * PGR * SEG + 2 * PU * SEG + tid] = 0.f;             // XS
+            if (er < R) {                                                            // xi(0) = cI(0)  (x_{-1} = 0)
+                const int erc = er < nb ? er : nb - 1;
+                const float *crow = a.cI + ((size_t)0 * Btot + b0 + erc) * H + 2 * ec;
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    *reinterpret_cast<float2 *>(ACT + er * LDC + own_col(c, ec)) = *reinterpret_cast<const float2 *>(crow + 32 * c);
+            }
+        }
+        __syncthreads();
+
+        for (int t = 0; t < T; ++t) {
+            const unsigned tag = tagbase + (unsigned)t + 1u;
+
+            // =========================== S1: GRU1 (fatchord_version.py:210) ===========================
+#pragma unroll 1
+            for (int i = 0; i < nact; ++i) {
+                const int nb = GEO[2 * i + 1], b0 = GEO[2 * i];
+                float *GP = smem + K::OFF_GRP + i * K::GRP;
+                float *ACT = smem + K::OFF_ACT + i * K::TILE;
+                float *GH1 = GP, *HOWN1 = GP + 2 * PGR * SEG;
+                u64 *G1 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 0 * SEG * H;
+                __syncthreads();                                         // PART free; ACT written by S6 visible
+#pragma unroll
+                for (int rt = 0; rt < PRT; ++rt)
+                    put_partial<PNSLOT>(PART, w, rt, lane, mfma_tile(A_ih1[rt], ACT + fi * LDC + kbase_lane));
+                __syncthreads();
+                if (pw_thread && pj < nb) {
+                    const float gir = get_partial<PNSLOT>(PART, 0, 0 * PU + pu, pj) + BI1[0 * PU + pu];
+                    const float giz = get_partial<PNSLOT>(PART, 0, 1 * PU + pu, pj) + BI1[1 * PU + pu];
+                    const float gin = get_partial<PNSLOT>(PART, 0, 2 * PU + pu, pj) + BI1[2 * PU + pu];
+                    const float hn = gru_update(gir, giz, gin, GH1[(0 * PU + pu) * SEG + pj], GH1[(1 * PU + pu) * SEG + pj],
+                                                GH1[(2 * PU + pu) * SEG + pj], HOWN1[pu * SEG + pj]);
+                    HOWN1[pu * SEG + pj] = hn;
+                    publish(G1, tag, pj, prow, hn);
+                }
+            }
+
+            // =========================== S2: GRU2 (:212-214) ==========================================
+#pragma unroll 1
+            for (int i = 0; i < nact; ++i) {
+                const int nb = GEO[2 * i + 1], b0 = GEO[2 * i];
+                float *GP = smem + K::OFF_GRP + i * K::GRP;
+                float *ACT = smem + K::OFF_ACT + i * K::TILE;
+                float *GH1 = GP, *GH2 = GP + PGR * SEG, *HOWN2 = GP + 2 * PGR * SEG + PU * SEG;
+                u64 *G2 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 1 * SEG * H;
+                float c2r = 0, c2z = 0, c2n = 0;
+                const bool is_pw = pw_thread && pj < nb;
+                if (is_pw) {
+                    const int f = cond_frame(a.seg_pos, a.seg_lim, b0 + pj, t, a.hop, a.NF);
+                    c2r = a.c2f[(size_t)f * 3 * H + prow];
+                    c2z = a.c2f[(size_t)f * 3 * H + H + prow];
+                    c2n = a.c2f[(size_t)f * 3 * H + 2 * H + prow];
+                }
+                // h1(t) -> HS ; ACT = xi + h1 (:212)
+                bool ok = sweep_layer<true, NL>(grs, soff_cl + i * SLOT_BYTES + 0 * LAYER_BYTES, tag, nb, tid, HS, ACT, a.status);
+                if (!ok) report_failure(a.status, 0x300u | 1u, blockIdx.x, t, tid);
+                if (__syncthreads_or(!ok)) return;
+#pragma unroll
+                for (int rt = 0; rt < PRT; ++rt)
+                    put_partial<PNSLOT>(PART, w, rt, lane, mfma_tile(A_ih2[rt], ACT + fi * LDC + kbase_lane));
+#pragma unroll
+                for (int rt = 0; rt < PRT; ++rt)                        // gh1(t+1) = W_hh1 . h1(t)
+                    put_partial<PNSLOT>(PART, w, PRT + rt, lane, mfma_tile(A_hh1[rt], HS + fi * LDC + kbase_lane));
+                __syncthreads();
+                if (is_pw) {
+                    const float gir = get_partial<PNSLOT>(PART, 0, 0 * PU + pu, pj) + c2r;
+                    const float giz = get_partial<PNSLOT>(PART, 0, 1 * PU + pu, pj) + c2z;
+                    const float gin = get_partial<PNSLOT>(PART, 0, 2 * PU + pu, pj) + c2n;
+                    const float hn = gru_update(gir, giz, gin, GH2[(0 * PU + pu) * SEG + pj], GH2[(1 * PU + pu) * SEG + pj],
+                                                GH2[(2 * PU + pu) * SEG + pj], HOWN2[pu * SEG + pj]);
+                    HOWN2[pu * SEG + pj] = hn;
+                    publish(G2, tag, pj, prow, hn);
+                }
+#pragma unroll
+                for (int q0 = 0; q0 < PGHI; ++q0) {
+                    const int q = tid + NT * q0;
+                    if (q < PGR * SEG) GH1[q] = get_partial<PNSLOT>(PART, PRT, q >> 4, q & 15) + BH1[q >> 4];
+                }
+            }
+
+            // =========================== S3: fc1 + relu (:216-218) ====================================
+#pragma unroll 1
+            for (int i = 0; i < nact; ++i) {
+                const int nb = GEO[2 * i + 1], b0 = GEO[2 * i];
+                float *GP = smem + K::OFF_GRP + i * K::GRP;
+                float *ACT = smem + K::OFF_ACT + i * K::TILE;
+                float *GH2 = GP + PGR * SEG;
+                u64 *G3 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 2 * SEG * H;
+                float c3v = 0;
+                const bool is_pw = pw_thread && pj < nb;
+                if (is_pw) {
+                    const int f = cond_frame(a.seg_pos, a.seg_lim, b0 + pj, t, a.hop, a.NF);
+                    c3v = a.c3f[(size_t)f * H + prow];
+                }
+                // h2(t) -> HS ; ACT = x1 + h2 (:216)
+                bool ok = sweep_layer<true, NL>(grs, soff_cl + i * SLOT_BYTES + 1 * LAYER_BYTES, tag, nb, tid, HS, ACT, a.status);
+                if (!ok) report_failure(a.status, 0x300u | 2u, blockIdx.x, t, tid);
+                if (__syncthreads_or(!ok)) return;
+                put_partial<PNSLOT>(PART, w, 0, lane, mfma_tile(A_fc1, ACT + fi * LDC + kbase_lane));
+#pragma unroll
+                for (int rt = 0; rt < PRT; ++rt)                        // gh2(t+1) = W_hh2 . h2(t)
+                    put_partial<PNSLOT>(PART, w, PRT + rt, lane, mfma_tile(A_hh2[rt], HS + fi * LDC + kbase_lane));
+                __syncthreads();
+                if (is_pw) publish(G3, tag, pj, prow, fmaxf(get_partial<PNSLOT>(PART, 0, pu, pj) + c3v, 0.f));
+#pragma unroll
+                for (int q0 = 0; q0 < PGHI; ++q0) {
+                    const int q = tid + NT * q0;
+                    if (q < PGR * SEG) GH2[q] = get_partial<PNSLOT>(PART, PRT, q >> 4, q & 15) + BH2[q >> 4];
+                }
+            }
+
+            // =========================== S4: fc2 + relu (:220-221) ====================================
+#pragma unroll 1
+            for (int i = 0; i < nact; ++i) {
+                const int nb = GEO[2 * i + 1], b0 = GEO[2 * i];
+                float *ACT = smem + K::OFF_ACT + i * K::TILE;
+                u64 *G4 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 3 * SEG * H;
+                float c4v = 0;
+                const bool is_pw = pw_thread && pj < nb;
+                if (is_pw) {
+                    const int f = cond_frame(a.seg_pos, a.seg_lim, b0 + pj, t, a.hop, a.NF);
+                    c4v = a.c4f[(size_t)f * H + prow];
+                }
+                bool ok = sweep_layer<false, NL>(grs, soff_cl + i * SLOT_BYTES + 2 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y1
+                if (!ok) report_failure(a.status, 0x300u | 3u, blockIdx.x, t, tid);
+                if (__syncthreads_or(!ok)) return;
+                put_partial<PNSLOT>(PART, w, 0, lane, mfma_tile(A_fc2, ACT + fi * LDC + kbase_lane));
+                __syncthreads();
+                if (is_pw) publish(G4, tag, pj, prow, fmaxf(get_partial<PNSLOT>(PART, 0, pu, pj) + c4v, 0.f));
+            }
+
+            // =========================== S5: fc3, one logit row per workgroup (:223) ==================
+            if (fc3_wg) {                                               // workgroup-uniform
+#pragma unroll 1
+                for (int i = 0; i < nact; ++i) {
+                    const int nb = GEO[2 * i + 1];
+                    float *ACT = smem + K::OFF_ACT + i * K::TILE;
+                    u64 *G5 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 4 * SEG * H;
+                    bool ok = sweep_layer<false, NL>(grs, soff_cl + i * SLOT_BYTES + 3 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y2
+                    if (!ok) report_failure(a.status, 0x300u | 4u, blockIdx.x, t, tid);
+                    if (__syncthreads_or(!ok)) return;
+                    {   // thread (segment pj, k-chunk pu): 32 terms of logit[wg][pj]
+                        const float *xr = ACT + (pj < R ? pj : R - 1) * LDC + 32 * pu;
+                        const float *wr = W3R + 32 * pu;
+                        float s = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 32; k += 4) {
+                            const float4 x4 = *reinterpret_cast<const float4 *>(xr + k);
+                            const float4 w4 = *reinterpret_cast<const float4 *>(wr + k);
+                            s = fmaf(w4.x, x4.x, s); s = fmaf(w4.y, x4.y, s); s = fmaf(w4.z, x4.z, s); s = fmaf(w4.w, x4.w, s);
+                        }
+                        SCR[pu * SEG + pj] = s;
+                    }
+                    __syncthreads();
+                    if (tid < nb) {
+                        float s = SCR[tid];
+#pragma unroll
+                        for (int kc = 1; kc < 16; ++kc) s += SCR[kc * SEG + tid];
+                        publish(G5, tag, tid, wg, s + b3);
+                    }
+                }
+            }
+
+            // =========================== S6: sampling (utils/distribution.py:102-121) + xi(t+1) ========
+#pragma unroll 1
+            for (int i = 0; i < nact; ++i) {
+                float *GP = smem + K::OFF_GRP + i * K::GRP;
+                float *ACT = smem + K::OFF_ACT + i * K::TILE;
+                float *XS = GP + 2 * PGR * SEG + 2 * PU * SEG;
+                const int nb = GEO[2 * i + 1], b0 = GEO[2 * i];
+                // cI of the next step (row er, owned columns) and this step's sampling noise
+                float2 cn[16];
+                if (er < R) {
+                    const int tn = (t + 1 < T) ? t + 1 : t;
+                    const int erc = er < nb ? er : nb - 1;
+                    const float *crow = a.cI + ((size_t)tn * Btot + b0 + erc) * H + 2 * ec;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) cn[c] = *reinterpret_cast<const float2 *>(crow + 32 * c);
+                }
+                float nz0 = 0.5f, nz1 = 0.5f;                           // u1 (mixture pj of segment pu), u2 (pj == 0)
+                if (pu < nb) {
+                    const float *nrow = a.noise + (size_t)t * 11 * Btot;
+                    if (pj < 10) nz0 = nrow[(b0 + pu) * 10 + pj];
+                    if (pj == 0) nz1 = nrow[10 * Btot + b0 + pu];
+                }
+                // gather the 30 logits of every segment: thread (segment er, c = ec < 15) reads logits 2c, 2c+1
+                {
+                    bool ok = true;
+                    if (er < nb && ec < 15) {
+                        const int voff = er * (H * 8) + ec * 16;
+                        const int soff = soff_cl + i * SLOT_BYTES + 4 * LAYER_BYTES;
+                        unsigned spins = 0;
+                        u32x4 x;
+                        for (;;) {
+                            x = __builtin_amdgcn_raw_buffer_load_b128(grs, voff, soff, 16 /* sc1 */);
+                            if (x.y == tag && x.w == tag) break;
+                            ++spins;
+                            if ((spins & 255u) == 0u) {
+                                if (spins > SPIN_LIMIT || ld_agent32(a.status) != 0u) { ok = false; break; }
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        const float l0 = __uint_as_float(x.x), l1 = __uint_as_float(x.z);
+                        LOG[er * 32 + 2 * ec] = l0;
+                        LOG[er * 32 + 2 * ec + 1] = l1;
+                        if (a.dbg_logits && wg == 0 && ok) {
+                            a.dbg_logits[((size_t)t * Btot + b0 + er) * C + 2 * ec] = l0;
+                            a.dbg_logits[((size_t)t * Btot + b0 + er) * C + 2 * ec + 1] = l1;
+                        }
+                    }
+                    if (!ok) report_failure(a.status, 0x300u | 5u, blockIdx.x, t, tid);
+                    if (__syncthreads_or(!ok)) return;
+                }
+                {   // 16-lane group = one segment (pu), lane pj = mixture
+                    float best = (pj < 10) ? mol_gumbel(LOG[pu * 32 + pj], nz0) : -INFINITY;
+                    int bidx = pj;
+#pragma unroll
+                    for (int m = 8; m >= 1; m >>= 1) {
+                        const float ob = __shfl_xor(best, m, 16);
+                        const int oi = __shfl_xor(bidx, m, 16);
+                        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+                    }
+                    if (pj == 0 && pu < nb) {
+                        float x = mol_sample(LOG[pu * 32 + 10 + bidx], LOG[pu * 32 + 20 + bidx], nz1);
+                        if (wg == 0) a.out[(size_t)(b0 + pu) * T + t] = x;
+                        if (a.force_x) x = a.force_x[(size_t)(b0 + pu) * T + t];
+                        XS[pu] = x;
+                    }
+                }
+                __syncthreads();
+                if (er < R) {                                           // xi(t+1) = W_I[:,0] * x_t + cI(t+1)  (:208-209)
+                    const float xs = XS[er];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const float2 wv = *reinterpret_cast<const float2 *>(WI0 + own_col(c, ec));
+                        *reinterpret_cast<float2 *>(ACT + er * LDC + own_col(c, ec)) = make_float2(fmaf(wv.x, xs, cn[c].x), fmaf(wv.y, xs, cn[c].y));
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int G, int NL>
+static hipError_t launch_pipe_t(const LoopArgs &args, int ncl, hipStream_t stream)
+{
+    using K = PipeCfg<G>;
+    const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void *)wrnn_pipe_kernel<G, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    LoopArgs a = args;
+    void *params[] = {(void *)&a};
+    return hipLaunchCooperativeKernel((const void *)wrnn_pipe_kernel<G, NL>, dim3(ncl * PNWGC), dim3(NT), params, (unsigned)lds, stream);
+}
+
+// segment rows per group of the G-deep pipeline (15 at G = 3: three tiles + the transient tile must fit 160 KiB)
+int pipe_rows(int G) { return G >= 3 ? 15 : 16; }
+
+// clusters of 64 workgroups on an n_cus-CU device
+int pipe_clusters(int n_cus)
+{
+    int ncl = n_cus / PNWGC;
+    if (ncl > MAXCL) ncl = MAXCL;
+    while (ncl > 1 && (8 % ncl) != 0) --ncl;
+    return ncl;
+}
+
+hipError_t launch_pipe(const LoopArgs &args, int G, int ncl, int nl, hipStream_t stream)
+{
+    if (ncl < 1) return hipErrorInvalidValue;
+    if (nl != 16) nl = 8;
+    if (G == 1) return nl == 16 ? launch_pipe_t<1, 16>(args, ncl, stream) : launch_pipe_t<1, 8>(args, ncl, stream);
+    if (G == 2) return nl == 16 ? launch_pipe_t<2, 16>(args, ncl, stream) : launch_pipe_t<2, 8>(args, ncl, stream);
+    if (G == 3) return nl == 16 ? launch_pipe_t<3, 16>(args, ncl, stream) : launch_pipe_t<3, 8>(args, ncl, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace wrnn

@@ -121,10 +121,12 @@ class LoopEngine:
         return (out, logits) if want_logits else out
 
     def last_loop_split(self):
-        """(hidden units per workgroup, independent clusters) of the last loop kernel; (0, 0) for the stream kernel."""
-        u, c = ctypes.c_int(0), ctypes.c_int(0)
-        _lib.check(self.lib.wrnn_last_loop_split(self._pack, ctypes.byref(u), ctypes.byref(c)), 'wrnn_last_loop_split')
-        return u.value, c.value
+        """(hidden units per workgroup, independent clusters, groups in flight per cluster) of the last loop kernel;
+        (0, 0, 0) for the stream kernel."""
+        u, c, g = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self.lib.wrnn_last_loop_split(self._pack, ctypes.byref(u), ctypes.byref(c), ctypes.byref(g)),
+                   'wrnn_last_loop_split')
+        return u.value, c.value, g.value
 
     def last_loop_ms(self):
         return float(self.lib.wrnn_last_loop_ms(self._pack))
