@@ -174,6 +174,7 @@ def main():
                                    f'overlap={overlap}) on a batch of {args.utterances} random {args.frames}-frame mels per GPU '
                                    f'-> {n_local} folded segments x T={T} steps in one launch per GPU, '
                                    f'{wave_total // world} output samples per GPU per step',
+                       'segments_per_gpu': n_local, 'steps_per_segment': T,
                        'kernel': eng.last_loop_kernel(), 'units_per_workgroup': u_per_wg, 'clusters': ncl, 'groups_in_flight_per_cluster': depth,
                        'segment_steps_per_s': round(plan.n_segments * T * args.steps / dt, 1),
                        'noise': 'host MT19937 stream (parity mode)' if args.parity_noise else 'device Philox (as the reference on a GPU)',

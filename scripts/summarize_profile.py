@@ -51,11 +51,26 @@ with open(os.path.join(dst, f'{tag}_pmc.csv'), 'w', newline='') as f:
 lines = [f'# rocprofv3 summary `{tag}`', '', 'Source: `scripts/gpu_profile.sh` on one MI355X (separate `--pmc` passes); '
          'raw CSVs condensed by `scripts/summarize_profile.py`.', '']
 bench = os.path.join(src, f'bench_{tag}.log')
+bj = None
 if os.path.exists(bench):
     for ln in open(bench):
         if ln.startswith('{'):
-            b = json.loads(ln)
-            lines += ['## bench line', '', '```json', json.dumps(b, indent=1), '```', '']
+            bj = json.loads(ln)
+            lines += ['## bench line', '', '```json', json.dumps(bj, indent=1), '```', '']
+# fabric-side traffic of the loop kernel per launch -> profiles/traffic_latest.json (read back by bench.py's roofline.traffic)
+if bj is not None:
+    kname = bj['config'].get('kernel', '')
+    for k, cs in pmc.items():
+        if kname and kname in k and 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs and 'segments_per_gpu' in bj['config']:
+            # FETCH_SIZE / WRITE_SIZE are in KB; the granule polls are 16-B sc1 loads (not the calibrated 2x-under-counted
+            # wide streaming pattern), so the raw counters are reported uncorrected
+            tr = dict(tag=tag, kernel=kname, kernel_instance=k, segments=bj['config']['segments_per_gpu'],
+                      T=bj['config']['steps_per_segment'],
+                      bytes_per_launch=int((cs['FETCH_SIZE'][0] + cs['WRITE_SIZE'][0]) * 1024),
+                      fetch_bytes=int(cs['FETCH_SIZE'][0] * 1024), write_bytes=int(cs['WRITE_SIZE'][0] * 1024),
+                      note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per dispatch; fabric-side '
+                           '(L2 <-> Infinity Fabric) bytes = inter-CU granule exchange + conditioning; uncorrected')
+            json.dump(tr, open(os.path.join(dst, 'traffic_latest.json'), 'w'), indent=1)
 for k, cs in pmc.items():
     g = lambda c: cs.get(c, (None,))[0]
     lines += [f'## {k}', '', f'launch geometry / registers: {meta[k]}', '']
