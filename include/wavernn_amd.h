@@ -160,6 +160,11 @@ const char *wrnn_last_loop_kernel(const wrnn_pack *p);
  * flight per cluster (0,0,0 = stream) */
 int wrnn_last_loop_split(const wrnn_pack *p, int *units_per_wg, int *clusters, int *groups_in_flight);
 
+/* Profiling builds (environment WRNN_PROF=1 at wrnn_generate time, pipelined kernel): copies the per-workgroup phase
+ * clocks [256 workgroups][16 phases] (shader cycles summed over the launch; phases listed in wrnn_pipe.hip) to `out`.
+ * Synchronises `stream`.  Returns the number of words copied or a negative error. */
+int wrnn_profile_read(void *workspace, unsigned long long *out, int max_words, void *stream);
+
 /* Self tests of the device primitives (MFMA fragment layout, inter-workgroup granule all-gather).
  * Synchronous.  WRNN_OK or an error with a message. */
 int wrnn_selftest(int device, int which);

@@ -20,7 +20,7 @@ ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'persist': ALGO_PERSIST, 'clu
 EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_create', 'wrnn_pack_destroy',
            'wrnn_pack_weight_bytes', 'wrnn_workspace_bytes', 'wrnn_workspace_bytes_segments', 'wrnn_generate',
            'wrnn_generate_segments', 'wrnn_status', 'wrnn_last_loop_ms', 'wrnn_last_loop_kernel',
-           'wrnn_last_loop_split', 'wrnn_selftest', 'wrnn_selftest_metric']
+           'wrnn_last_loop_split', 'wrnn_profile_read', 'wrnn_selftest', 'wrnn_selftest_metric']
 
 
 class Weights(ctypes.Structure):
@@ -90,6 +90,7 @@ def lib():
                                          ctypes.POINTER(Debug), ctypes.c_void_p]
     L.wrnn_last_loop_split.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                        ctypes.POINTER(ctypes.c_int)]
+    L.wrnn_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.wrnn_status.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.wrnn_last_loop_ms.argtypes = [ctypes.c_void_p]
     L.wrnn_last_loop_ms.restype = ctypes.c_float

@@ -180,7 +180,7 @@ extern "C" size_t wrnn_pack_weight_bytes(const wrnn_pack *p) { return p ? p->wei
 
 namespace {
 struct WsLayout {
-    size_t status, gran, segs, c2f, c3f, c4f, cI, total;
+    size_t status, prof, gran, segs, c2f, c3f, c4f, cI, total;
 };
 constexpr size_t GRAN_BYTES = (size_t)GRAN_WORDS * sizeof(u64);
 size_t al(size_t x) { return (x + 255) / 256 * 256; }
@@ -189,6 +189,7 @@ WsLayout ws_layout(int B, int T, int n_frames)
     WsLayout l;
     size_t o = 0;
     l.status = o; o = al(o + STATUS_WORDS * sizeof(unsigned));
+    l.prof = o;   o = al(o + (size_t)MAXWG * NPROF * sizeof(u64));     // fixed offset: wrnn_profile_read finds it
     l.gran = o;   o = al(o + GRAN_BYTES);
     l.segs = o;   o = al(o + (size_t)2 * B * sizeof(int));
     l.c2f = o;    o = al(o + (size_t)(n_frames + 1) * 3 * H * sizeof(float));
@@ -279,6 +280,11 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
     a.cI = c.cI; a.c2f = c.c2f; a.c3f = c.c3f; a.c4f = c.c4f;
     a.noise = noise; a.force_x = dbg ? dbg->force_x : nullptr; a.out = out; a.dbg_logits = dbg ? dbg->logits : nullptr;
     a.gran = (u64 *)(ws + l.gran); a.status = (unsigned *)(ws + l.status);
+    a.prof = nullptr;
+    if (getenv("WRNN_PROF") && atoi(getenv("WRNN_PROF")) != 0) {
+        a.prof = (u64 *)(ws + l.prof);
+        HIPCHK(hipMemsetAsync(ws + l.prof, 0, (size_t)MAXWG * NPROF * sizeof(u64), stream));
+    }
     a.seg_pos = d_pos; a.seg_lim = d_lim;
     a.Btot = B; a.T = T; a.hop = hop; a.NF = n_frames; a.C = p->C;
     a.NG = (B + SEG - 1) / SEG;
@@ -442,6 +448,17 @@ extern "C" int wrnn_status(void *workspace, void *stream)
         return WRNN_ERR_KERNEL;
     }
     return WRNN_OK;
+}
+
+extern "C" int wrnn_profile_read(void *workspace, unsigned long long *out, int max_words, void *stream)
+{
+    if (!workspace || !out || max_words < 1) { set_err("bad argument"); return WRNN_ERR_ARG; }
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    size_t n = (size_t)MAXWG * NPROF;
+    if ((size_t)max_words < n) n = (size_t)max_words;
+    const size_t off = (STATUS_WORDS * sizeof(unsigned) + 255) / 256 * 256;
+    HIPCHK(hipMemcpy(out, (char *)workspace + off, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return (int)n;
 }
 
 extern "C" float wrnn_last_loop_ms(const wrnn_pack *p)

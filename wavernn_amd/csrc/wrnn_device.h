@@ -22,6 +22,8 @@ constexpr int MAXCL = 4;      // cluster kernels: at most 4 independent clusters
 constexpr int MAXG = 3;       // pipelined kernel: at most 3 groups in flight per cluster
 constexpr int GRAN_WORDS = MAXCL * MAXG * NGRAN * SEG * H;   // u64 granules in the workspace
 constexpr int STATUS_WORDS = 16;
+constexpr int NPROF = 16;     // phase counters per workgroup (wrnn_pipe.hip PROF builds)
+constexpr int MAXWG = 256;    // workgroups of a persistent launch
 
 // Everything the loop kernels read.  All pointers are device pointers.
 struct LoopArgs {
@@ -47,6 +49,7 @@ struct LoopArgs {
     float *dbg_logits;                  // optional [T][Btot][C]
     u64 *gran;                          // [GRAN_WORDS] {tag,value} granules: cluster kernel [cl][layer][SEG][H], pipe kernel [cl][slot][layer][SEG][H]
     unsigned *status;                   // [STATUS_WORDS]: 0 abort flag, 1 code, 2 wg, 3 step, 4 detail
+    u64 *prof;                          // optional [workgroups][NPROF] shader-clock totals per phase (profiling builds)
     // segment table: segment b, step t reads conditioning position p = seg_pos[b] + t; p >= seg_lim[b] is the
     // fold's zero padding (fatchord_version.py:326-330).  One utterance: seg_pos[b] = b*(target+overlap),
     // seg_lim[b] = L.  Several utterances: positions in the concatenated conditioning (each utterance starts

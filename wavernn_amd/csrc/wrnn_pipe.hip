@@ -47,14 +47,25 @@ struct PipeCfg {
     static constexpr int OFF_BH1 = OFF_BI1 + PGR;
     static constexpr int OFF_BH2 = OFF_BH1 + PGR;
     static constexpr int OFF_GEO = OFF_BH2 + PGR;                      // [2*MAXG] ints: b0, nb of every slot
-    static constexpr int LDS_FLOATS = ((OFF_GEO + 2 * MAXG + 3) / 4) * 4;
+    static constexpr int OFF_PROF = ((OFF_GEO + 2 * MAXG + 3) / 4) * 4;   // [NPROF] u64 phase clocks (PROF builds)
+    static constexpr int LDS_FLOATS = OFF_PROF + 2 * NPROF;
     static_assert(G >= 1 && G <= MAXG, "G in 1..MAXG");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
     static_assert(TILE % 4 == 0 && OFF_PART % 4 == 0 && OFF_GRP % 4 == 0 && OFF_WI0 % 4 == 0, "alignment");
 };
 
-// G: groups in flight per cluster.  NL: sweep loads in flight per thread (16 or 8).
-template <int G, int NL>
+// Phase clock (PROF builds only): thread 0 adds the shader cycles since the previous mark to phase k.
+#define PH(k)                                                                  \
+    do {                                                                       \
+        if (PROF && tid == 0) {                                                \
+            const u64 now_ = __builtin_amdgcn_s_memtime();                     \
+            PROFL[k] += now_ - plast;                                          \
+            plast = now_;                                                      \
+        }                                                                      \
+    } while (0)
+
+// G: groups in flight per cluster.  NL: sweep loads in flight per thread (16 or 8).  PROF: per-phase clocks.
+template <int G, int NL, bool PROF>
 __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
 {
     using K = PipeCfg<G>;
@@ -64,6 +75,8 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
     float *W3R = smem + K::OFF_W3R, *SCR = smem + K::OFF_SCR;
     float *BI1 = smem + K::OFF_BI1, *BH1 = smem + K::OFF_BH1, *BH2 = smem + K::OFF_BH2;
     int *GEO = reinterpret_cast<int *>(smem + K::OFF_GEO);
+    u64 *PROFL = reinterpret_cast<u64 *>(smem + K::OFF_PROF);
+    u64 plast = 0;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // cluster / workgroup-in-cluster: whole XCDs per cluster (block b runs on XCD b % 8; speed only)
@@ -126,6 +139,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
     constexpr int SLOT_BYTES = NGRAN * LAYER_BYTES;
     const int soff_cl = cl * MAXG * SLOT_BYTES;
 
+    if (PROF) plast = __builtin_amdgcn_s_memtime();
     unsigned tagbase = 0u;
     for (int round = 0;; ++round, tagbase += (unsigned)T) {
         const int gfirst = cl + ncl * (round * G);
@@ -177,10 +191,13 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                 float *GH1 = GP, *HOWN1 = GP + 2 * PGR * SEG;
                 u64 *G1 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 0 * SEG * H;
                 __syncthreads();                                         // PART free; ACT written by S6 visible
+                PH(0);
 #pragma unroll
                 for (int rt = 0; rt < PRT; ++rt)
                     put_partial<PNSLOT>(PART, w, rt, lane, mfma_tile(A_ih1[rt], ACT + fi * LDC + kbase_lane));
+                PH(1);
                 __syncthreads();
+                PH(2);
                 if (pw_thread && pj < nb) {
                     const float gir = get_partial<PNSLOT>(PART, 0, 0 * PU + pu, pj) + BI1[0 * PU + pu];
                     const float giz = get_partial<PNSLOT>(PART, 0, 1 * PU + pu, pj) + BI1[1 * PU + pu];
@@ -190,6 +207,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                     HOWN1[pu * SEG + pj] = hn;
                     publish(G1, tag, pj, prow, hn);
                 }
+                PH(3);
             }
 
             // =========================== S2: GRU2 (:212-214) ==========================================
@@ -209,16 +227,21 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                     c2n = a.c2f[(size_t)f * 3 * H + 2 * H + prow];
                 }
                 // h1(t) -> HS ; ACT = xi + h1 (:212)
+                PH(8);
                 bool ok = sweep_layer<true, NL>(grs, soff_cl + i * SLOT_BYTES + 0 * LAYER_BYTES, tag, nb, tid, HS, ACT, a.status);
                 if (!ok) report_failure(a.status, 0x300u | 1u, blockIdx.x, t, tid);
+                PH(4);
                 if (__syncthreads_or(!ok)) return;
+                PH(5);
 #pragma unroll
                 for (int rt = 0; rt < PRT; ++rt)
                     put_partial<PNSLOT>(PART, w, rt, lane, mfma_tile(A_ih2[rt], ACT + fi * LDC + kbase_lane));
 #pragma unroll
                 for (int rt = 0; rt < PRT; ++rt)                        // gh1(t+1) = W_hh1 . h1(t)
                     put_partial<PNSLOT>(PART, w, PRT + rt, lane, mfma_tile(A_hh1[rt], HS + fi * LDC + kbase_lane));
+                PH(6);
                 __syncthreads();
+                PH(7);
                 if (is_pw) {
                     const float gir = get_partial<PNSLOT>(PART, 0, 0 * PU + pu, pj) + c2r;
                     const float giz = get_partial<PNSLOT>(PART, 0, 1 * PU + pu, pj) + c2z;
@@ -233,6 +256,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                     const int q = tid + NT * q0;
                     if (q < PGR * SEG) GH1[q] = get_partial<PNSLOT>(PART, PRT, q >> 4, q & 15) + BH1[q >> 4];
                 }
+                PH(8);
             }
 
             // =========================== S3: fc1 + relu (:216-218) ====================================
@@ -250,20 +274,26 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                     c3v = a.c3f[(size_t)f * H + prow];
                 }
                 // h2(t) -> HS ; ACT = x1 + h2 (:216)
+                PH(8);
                 bool ok = sweep_layer<true, NL>(grs, soff_cl + i * SLOT_BYTES + 1 * LAYER_BYTES, tag, nb, tid, HS, ACT, a.status);
                 if (!ok) report_failure(a.status, 0x300u | 2u, blockIdx.x, t, tid);
+                PH(4);
                 if (__syncthreads_or(!ok)) return;
+                PH(5);
                 put_partial<PNSLOT>(PART, w, 0, lane, mfma_tile(A_fc1, ACT + fi * LDC + kbase_lane));
 #pragma unroll
                 for (int rt = 0; rt < PRT; ++rt)                        // gh2(t+1) = W_hh2 . h2(t)
                     put_partial<PNSLOT>(PART, w, PRT + rt, lane, mfma_tile(A_hh2[rt], HS + fi * LDC + kbase_lane));
+                PH(6);
                 __syncthreads();
+                PH(7);
                 if (is_pw) publish(G3, tag, pj, prow, fmaxf(get_partial<PNSLOT>(PART, 0, pu, pj) + c3v, 0.f));
 #pragma unroll
                 for (int q0 = 0; q0 < PGHI; ++q0) {
                     const int q = tid + NT * q0;
                     if (q < PGR * SEG) GH2[q] = get_partial<PNSLOT>(PART, PRT, q >> 4, q & 15) + BH2[q >> 4];
                 }
+                PH(8);
             }
 
             // =========================== S4: fc2 + relu (:220-221) ====================================
@@ -278,12 +308,18 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                     const int f = cond_frame(a.seg_pos, a.seg_lim, b0 + pj, t, a.hop, a.NF);
                     c4v = a.c4f[(size_t)f * H + prow];
                 }
+                PH(8);
                 bool ok = sweep_layer<false, NL>(grs, soff_cl + i * SLOT_BYTES + 2 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y1
                 if (!ok) report_failure(a.status, 0x300u | 3u, blockIdx.x, t, tid);
+                PH(4);
                 if (__syncthreads_or(!ok)) return;
+                PH(5);
                 put_partial<PNSLOT>(PART, w, 0, lane, mfma_tile(A_fc2, ACT + fi * LDC + kbase_lane));
+                PH(6);
                 __syncthreads();
+                PH(7);
                 if (is_pw) publish(G4, tag, pj, prow, fmaxf(get_partial<PNSLOT>(PART, 0, pu, pj) + c4v, 0.f));
+                PH(8);
             }
 
             // =========================== S5: fc3, one logit row per workgroup (:223) ==================
@@ -295,7 +331,9 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                     u64 *G5 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 4 * SEG * H;
                     bool ok = sweep_layer<false, NL>(grs, soff_cl + i * SLOT_BYTES + 3 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y2
                     if (!ok) report_failure(a.status, 0x300u | 4u, blockIdx.x, t, tid);
+                    PH(4);
                     if (__syncthreads_or(!ok)) return;
+                    PH(5);
                     {   // thread (segment pj, k-chunk pu): 32 terms of logit[wg][pj]
                         const float *xr = ACT + (pj < R ? pj : R - 1) * LDC + 32 * pu;
                         const float *wr = W3R + 32 * pu;
@@ -315,6 +353,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                         for (int kc = 1; kc < 16; ++kc) s += SCR[kc * SEG + tid];
                         publish(G5, tag, tid, wg, s + b3);
                     }
+                    PH(9);
                 }
             }
 
@@ -340,6 +379,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                     if (pj < 10) nz0 = nrow[(b0 + pu) * 10 + pj];
                     if (pj == 0) nz1 = nrow[10 * Btot + b0 + pu];
                 }
+                PH(10);
                 // gather the 30 logits of every segment: thread (segment er, c = ec < 15) reads logits 2c, 2c+1
                 {
                     bool ok = true;
@@ -366,7 +406,9 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                         }
                     }
                     if (!ok) report_failure(a.status, 0x300u | 5u, blockIdx.x, t, tid);
+                    PH(11);
                     if (__syncthreads_or(!ok)) return;
+                    PH(12);
                 }
                 {   // 16-lane group = one segment (pu), lane pj = mixture
                     float best = (pj < 10) ? mol_gumbel(LOG[pu * 32 + pj], nz0) : -INFINITY;
@@ -384,7 +426,9 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                         XS[pu] = x;
                     }
                 }
+                PH(13);
                 __syncthreads();
+                PH(14);
                 if (er < R) {                                           // xi(t+1) = W_I[:,0] * x_t + cI(t+1)  (:208-209)
                     const float xs = XS[er];
 #pragma unroll
@@ -393,21 +437,26 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                         *reinterpret_cast<float2 *>(ACT + er * LDC + own_col(c, ec)) = make_float2(fmaf(wv.x, xs, cn[c].x), fmaf(wv.y, xs, cn[c].y));
                     }
                 }
+                PH(15);
             }
         }
     }
+    if (PROF && tid == 0 && a.prof && blockIdx.x < MAXWG) {
+#pragma unroll
+        for (int k = 0; k < NPROF; ++k) a.prof[(size_t)blockIdx.x * NPROF + k] = PROFL[k];
+    }
 }
 
-template <int G, int NL>
+template <int G, int NL, bool PROF>
 static hipError_t launch_pipe_t(const LoopArgs &args, int ncl, hipStream_t stream)
 {
     using K = PipeCfg<G>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
-    hipError_t e = hipFuncSetAttribute((const void *)wrnn_pipe_kernel<G, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)wrnn_pipe_kernel<G, NL, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     LoopArgs a = args;
     void *params[] = {(void *)&a};
-    return hipLaunchCooperativeKernel((const void *)wrnn_pipe_kernel<G, NL>, dim3(ncl * PNWGC), dim3(NT), params, (unsigned)lds, stream);
+    return hipLaunchCooperativeKernel((const void *)wrnn_pipe_kernel<G, NL, PROF>, dim3(ncl * PNWGC), dim3(NT), params, (unsigned)lds, stream);
 }
 
 // segment rows per group of the G-deep pipeline (15 at G = 3: three tiles + the transient tile must fit 160 KiB)
@@ -422,14 +471,23 @@ int pipe_clusters(int n_cus)
     return ncl;
 }
 
+// args.prof != nullptr selects the phase-clock build (NL = 8 only)
 hipError_t launch_pipe(const LoopArgs &args, int G, int ncl, int nl, hipStream_t stream)
 {
     if (ncl < 1) return hipErrorInvalidValue;
     if (nl != 16) nl = 8;
-    if (G == 1) return nl == 16 ? launch_pipe_t<1, 16>(args, ncl, stream) : launch_pipe_t<1, 8>(args, ncl, stream);
-    if (G == 2) return nl == 16 ? launch_pipe_t<2, 16>(args, ncl, stream) : launch_pipe_t<2, 8>(args, ncl, stream);
-    if (G == 3) return nl == 16 ? launch_pipe_t<3, 16>(args, ncl, stream) : launch_pipe_t<3, 8>(args, ncl, stream);
+    if (args.prof) {
+        if (G == 1) return launch_pipe_t<1, 8, true>(args, ncl, stream);
+        if (G == 2) return launch_pipe_t<2, 8, true>(args, ncl, stream);
+        if (G == 3) return launch_pipe_t<3, 8, true>(args, ncl, stream);
+        return hipErrorInvalidValue;
+    }
+    if (G == 1) return nl == 16 ? launch_pipe_t<1, 16, false>(args, ncl, stream) : launch_pipe_t<1, 8, false>(args, ncl, stream);
+    if (G == 2) return nl == 16 ? launch_pipe_t<2, 16, false>(args, ncl, stream) : launch_pipe_t<2, 8, false>(args, ncl, stream);
+    if (G == 3) return nl == 16 ? launch_pipe_t<3, 16, false>(args, ncl, stream) : launch_pipe_t<3, 8, false>(args, ncl, stream);
     return hipErrorInvalidValue;
 }
+
+#undef PH
 
 }  // namespace wrnn

@@ -128,6 +128,16 @@ class LoopEngine:
                    'wrnn_last_loop_split')
         return u.value, c.value, g.value
 
+    def read_profile(self):
+        """Phase clocks of the last launch made with WRNN_PROF=1 (pipelined kernel): uint64 array [256 workgroups, 16 phases]
+        of shader cycles (see wrnn_pipe.hip).  Synchronises."""
+        out = np.zeros((256, 16), dtype=np.uint64)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        n = self.lib.wrnn_profile_read(self._ws.data_ptr(), out.ctypes.data, out.size, stream)
+        if n < 0:
+            _lib.check(n, 'wrnn_profile_read')
+        return out
+
     def last_loop_ms(self):
         return float(self.lib.wrnn_last_loop_ms(self._pack))
 
