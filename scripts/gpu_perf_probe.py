@@ -17,7 +17,7 @@ ap.add_argument('--T', type=int, default=1500)
 ap.add_argument('--mode', default='MOL')
 ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'probe.json'))
 ap.add_argument('--B', default='12,64,120,128,180,192,256,360')
-ap.add_argument('--variants', default='u4,u8,p1,p2,p3,p3nl16')
+ap.add_argument('--variants', default='u8,p2,p3,auto')
 args = ap.parse_args()
 
 dev = torch.device('cuda', 0)
@@ -29,7 +29,7 @@ VARS = {'persist': ('persist', {}), 'u2': ('cluster', {'WRNN_CLUSTER_U': '2'}), 
         'u8': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '8'}),
         'u8nl16': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '16'}), 'auto': ('auto', {}),
         'p1': ('pipe', {'WRNN_PIPE_G': '1'}), 'p2': ('pipe', {'WRNN_PIPE_G': '2'}), 'p3': ('pipe', {'WRNN_PIPE_G': '3'}),
-        'p3nl16': ('pipe', {'WRNN_PIPE_G': '3', 'WRNN_PIPE_NL': '16'}), 'p2nl16': ('pipe', {'WRNN_PIPE_G': '2', 'WRNN_PIPE_NL': '16'})}
+        'p3nl8': ('pipe', {'WRNN_PIPE_G': '3', 'WRNN_PIPE_NL': '8'}), 'p2nl8': ('pipe', {'WRNN_PIPE_G': '2', 'WRNN_PIPE_NL': '8'})}
 rows = []
 for B in [int(x) for x in args.B.split(',')]:
     stride = 64

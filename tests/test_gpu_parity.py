@@ -54,7 +54,7 @@ VARIANTS = {
     'pipe-g1': ('pipe', {'WRNN_PIPE_G': '1'}),
     'pipe-g2': ('pipe', {'WRNN_PIPE_G': '2'}),
     'pipe-g3': ('pipe', {'WRNN_PIPE_G': '3'}),
-    'pipe-g3-nl16': ('pipe', {'WRNN_PIPE_G': '3', 'WRNN_PIPE_NL': '16'}),
+    'pipe-g3-nl8': ('pipe', {'WRNN_PIPE_G': '3', 'WRNN_PIPE_NL': '8'}),
 }
 KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'persist': 'wrnn_persist_kernel', 'cluster': 'wrnn_cluster_kernel',
                'pipe': 'wrnn_pipe_kernel'}
@@ -166,7 +166,7 @@ def test_generate_end_to_end(gpu, name, tmp_path):
 
 
 @pytest.mark.parametrize('variant', ['cluster-u2', 'cluster-u4', 'cluster-u8', 'cluster-u8-nl16', 'persist', 'pipe-g1', 'pipe-g2',
-                                     'pipe-g3', 'pipe-g3-nl16'])
+                                     'pipe-g3', 'pipe-g3-nl8'])
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_many_segments_all_clusters(gpu, mode, variant, monkeypatch):
     """46 folded segments (the last one zero-padded): 4 groups on the 4-cluster split, 4 groups = two per cluster on the

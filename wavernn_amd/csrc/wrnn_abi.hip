@@ -296,30 +296,33 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
     enum { K_STREAM, K_PERSIST, K_CLUSTER, K_PIPE } kind = K_STREAM;
     int U = 0, ncl = 0, G = 0;
     if ((algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_PIPE) && p->mode == WRNN_MODE_MOL) {
-        // pipelined kernel: pays once a cluster has more than one group to run (B > 16 segments per cluster)
+        // Pipelined kernel: G groups in flight per cluster.  Measured step times on MI355X (profiles/r01g_*): single-depth
+        // cluster kernel 25 us per round-step, G = 2 33.7 us, G = 3 (15-row groups) 49.2 us.  One launch costs
+        // rounds x step: pick the cheapest depth; auto falls back to the cluster kernel when depth 1 wins.
         const int pcl = pipe_clusters(p->n_cus);
         const char *envg = getenv("WRNN_PIPE_G");
         int g = envg ? atoi(envg) : 0;
-        if (pcl >= 1 && (algo == WRNN_ALGO_PIPE || B > SEG * pcl)) {
+        if (pcl >= 1) {
+            static const double step_us[MAXG + 1] = {0.0, 25.0, 33.7, 49.2};
             if (g < 1 || g > MAXG) {
-                // depth that minimises rounds x (relative step time of that depth); deeper pipelines hide more of
-                // the exchange latency but lengthen the step (measured: profiles/)
-                static const double rel_step[MAXG + 1] = {0.0, 1.0, 1.05, 1.2};
                 double best = 1e30;
                 for (int c = 1; c <= MAXG; ++c) {
                     const int rows_c = pipe_rows(c);
                     const int rounds_c = ((B + rows_c - 1) / rows_c + pcl * c - 1) / (pcl * c);
-                    const double cost = rounds_c * rel_step[c];
+                    const double cost = rounds_c * step_us[c];
                     if (cost < best - 1e-9) { best = cost; g = c; }
                 }
+                if (g == 1 && algo == WRNN_ALGO_AUTO) g = 0;             // the cluster kernel is the better depth-1 kernel
             }
-            const int rows = pipe_rows(g);
-            const int groups = (B + rows - 1) / rows;
-            const int rounds = (groups + pcl * g - 1) / (pcl * g);
-            const long ng = (long)rounds * pcl * g;
-            if ((double)rounds * T < 4.0e9) {
-                kind = K_PIPE; G = g; ncl = pcl; U = 8;
-                a.NG = ng < B ? (int)ng : B;
+            if (g >= 1) {
+                const int rows = pipe_rows(g);
+                const int groups = (B + rows - 1) / rows;
+                const int rounds = (groups + pcl * g - 1) / (pcl * g);
+                const long ng = (long)rounds * pcl * g;
+                if ((double)rounds * T < 4.0e9) {
+                    kind = K_PIPE; G = g; ncl = pcl; U = 8;
+                    a.NG = ng < B ? (int)ng : B;
+                }
             }
         }
         if (kind != K_PIPE && algo == WRNN_ALGO_PIPE) {
@@ -376,7 +379,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
         p->last_U = U; p->last_ncl = ncl; p->last_G = G;
         HIPCHK(hipMemsetAsync(ws + l.gran, 0, GRAN_BYTES, stream));
         const char *envn = getenv("WRNN_PIPE_NL");
-        hipError_t e = launch_pipe(a, G, ncl, envn ? atoi(envn) : 8, stream);
+        hipError_t e = launch_pipe(a, G, ncl, envn ? atoi(envn) : 16, stream);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             set_err("pipelined cooperative launch failed: %s", hipGetErrorString(e));

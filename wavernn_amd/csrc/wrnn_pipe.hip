@@ -34,7 +34,7 @@ template <int G>
 struct PipeCfg {
     static constexpr int R = (G >= 3) ? 15 : 16;                     // segment rows per group tile
     static constexpr int TILE = R * LDC;
-    static constexpr int GRP = 2 * PGR * SEG + 2 * PU * SEG + SEG;     // per-group small state: GH1 GH2 HOWN1 HOWN2 XS
+    static constexpr int GRP = 2 * PGR * SEG + 2 * PU * SEG + 3 * SEG; // per-group small state: GH1 GH2 HOWN1 HOWN2 XS POS LIM
     static constexpr int OFF_HS = 0;                                   // [R][LDC] transient gathered h
     static constexpr int OFF_ACT = OFF_HS + TILE;                      // [G][R][LDC]
     static constexpr int OFF_PART = OFF_ACT + G * TILE;                // [NW][PNSLOT][16][16]
@@ -64,6 +64,23 @@ struct PipeCfg {
         }                                                                      \
     } while (0)
 
+// NL = 8 selects the streaming sweep, NL = 16 the whole-row sweep
+template <bool ADD, int NL>
+__device__ __forceinline__ bool pipe_sweep(__amdgpu_buffer_rsrc_t rs, int soff, unsigned tag, int nb, int tid, float *dst,
+                                           float *acc, unsigned *status)
+{
+    if (NL == 8) return sweep_stream<ADD>(rs, soff, tag, nb, tid, dst, acc, status);
+    return sweep_layer<ADD, 16>(rs, soff, tag, nb, tid, dst, acc, status);
+}
+
+// conditioning frame of segment j of a group at step t, from the group's LDS copy of the segment table
+__device__ __forceinline__ int group_frame(const float *GP, int j, int t, int hop, int NF)
+{
+    const int *SP = reinterpret_cast<const int *>(GP + 2 * PGR * SEG + 2 * PU * SEG + SEG);
+    const int p = SP[j] + t;
+    return (p < SP[SEG + j]) ? (p / hop) : NF;
+}
+
 // G: groups in flight per cluster.  NL: sweep loads in flight per thread (16 or 8).  PROF: per-phase clocks.
 template <int G, int NL, bool PROF>
 __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
@@ -77,6 +94,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
     int *GEO = reinterpret_cast<int *>(smem + K::OFF_GEO);
     u64 *PROFL = reinterpret_cast<u64 *>(smem + K::OFF_PROF);
     u64 plast = 0;
+    float touch = 0.f;                                  // in-flight L2 touch of a future cI block (S6)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // cluster / workgroup-in-cluster: whole XCDs per cluster (block b runs on XCD b % 8; speed only)
@@ -168,13 +186,24 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
             const int b0 = GEO[2 * i], nb = GEO[2 * i + 1];
             for (int q = tid; q < PGR * SEG; q += NT) { GP[q] = BH1[q >> 4]; GP[PGR * SEG + q] = BH2[q >> 4]; }
             if (tid < 2 * PU * SEG) GP[2 * PGR * SEG + tid] = 0.f;                  // HOWN1 + HOWN2
-            if (tid < SEG) GP[2 * PGR * SEG + 2 * PU * SEG + tid] = 0.f;             // XS
+            if (tid < SEG) {
+                GP[2 * PGR * SEG + 2 * PU * SEG + tid] = 0.f;                        // XS
+                int *SP = reinterpret_cast<int *>(GP + 2 * PGR * SEG + 2 * PU * SEG + SEG);
+                const int sc = b0 + (tid < nb ? tid : nb - 1);                       // segment table of the group -> LDS
+                SP[tid] = a.seg_pos[sc];
+                SP[SEG + tid] = a.seg_lim[sc];
+            }
             if (er < R) {                                                            // xi(0) = cI(0)  (x_{-1} = 0)
                 const int erc = er < nb ? er : nb - 1;
                 const float *crow = a.cI + ((size_t)0 * Btot + b0 + erc) * H + 2 * ec;
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
                     *reinterpret_cast<float2 *>(ACT + er * LDC + own_col(c, ec)) = *reinterpret_cast<const float2 *>(crow + 32 * c);
+            }
+            {   // warm L2 with the conditioning block of step 1
+                asm volatile("" ::"v"(touch));
+                const int line = (tid < 16 * nb) ? tid : 0;
+                touch = a.cI[((size_t)(T > 1 ? 1 : 0) * Btot + b0) * H + 32 * line];
             }
         }
         __syncthreads();
@@ -192,9 +221,12 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                 u64 *G1 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 0 * SEG * H;
                 __syncthreads();                                         // PART free; ACT written by S6 visible
                 PH(0);
-#pragma unroll
-                for (int rt = 0; rt < PRT; ++rt)
-                    put_partial<PNSLOT>(PART, w, rt, lane, mfma_tile(A_ih1[rt], ACT + fi * LDC + kbase_lane));
+                {
+                    f32x4 o0, o1;
+                    mfma_tile2(A_ih1[0], A_ih1[1], ACT + fi * LDC + kbase_lane, o0, o1);
+                    put_partial<PNSLOT>(PART, w, 0, lane, o0);
+                    put_partial<PNSLOT>(PART, w, 1, lane, o1);
+                }
                 PH(1);
                 __syncthreads();
                 PH(2);
@@ -218,27 +250,28 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                 float *ACT = smem + K::OFF_ACT + i * K::TILE;
                 float *GH1 = GP, *GH2 = GP + PGR * SEG, *HOWN2 = GP + 2 * PGR * SEG + PU * SEG;
                 u64 *G2 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 1 * SEG * H;
-                float c2r = 0, c2z = 0, c2n = 0;
                 const bool is_pw = pw_thread && pj < nb;
-                if (is_pw) {
-                    const int f = cond_frame(a.seg_pos, a.seg_lim, b0 + pj, t, a.hop, a.NF);
-                    c2r = a.c2f[(size_t)f * 3 * H + prow];
-                    c2z = a.c2f[(size_t)f * 3 * H + H + prow];
-                    c2n = a.c2f[(size_t)f * 3 * H + 2 * H + prow];
-                }
+                // unconditional (clamped) loads: a load inside a divergent branch is waited for at the branch end
+                const int f2 = group_frame(GP, pj, t, a.hop, a.NF);
+                const float c2r = a.c2f[(size_t)f2 * 3 * H + prow];
+                const float c2z = a.c2f[(size_t)f2 * 3 * H + H + prow];
+                const float c2n = a.c2f[(size_t)f2 * 3 * H + 2 * H + prow];
                 // h1(t) -> HS ; ACT = xi + h1 (:212)
                 PH(8);
-                bool ok = sweep_layer<true, NL>(grs, soff_cl + i * SLOT_BYTES + 0 * LAYER_BYTES, tag, nb, tid, HS, ACT, a.status);
+                bool ok = pipe_sweep<true, NL>(grs, soff_cl + i * SLOT_BYTES + 0 * LAYER_BYTES, tag, nb, tid, HS, ACT, a.status);
                 if (!ok) report_failure(a.status, 0x300u | 1u, blockIdx.x, t, tid);
                 PH(4);
                 if (__syncthreads_or(!ok)) return;
                 PH(5);
-#pragma unroll
-                for (int rt = 0; rt < PRT; ++rt)
-                    put_partial<PNSLOT>(PART, w, rt, lane, mfma_tile(A_ih2[rt], ACT + fi * LDC + kbase_lane));
-#pragma unroll
-                for (int rt = 0; rt < PRT; ++rt)                        // gh1(t+1) = W_hh1 . h1(t)
-                    put_partial<PNSLOT>(PART, w, PRT + rt, lane, mfma_tile(A_hh1[rt], HS + fi * LDC + kbase_lane));
+                {
+                    f32x4 o0, o1;
+                    mfma_tile2(A_ih2[0], A_ih2[1], ACT + fi * LDC + kbase_lane, o0, o1);
+                    put_partial<PNSLOT>(PART, w, 0, lane, o0);
+                    put_partial<PNSLOT>(PART, w, 1, lane, o1);
+                    mfma_tile2(A_hh1[0], A_hh1[1], HS + fi * LDC + kbase_lane, o0, o1);   // gh1(t+1) = W_hh1 . h1(t)
+                    put_partial<PNSLOT>(PART, w, PRT + 0, lane, o0);
+                    put_partial<PNSLOT>(PART, w, PRT + 1, lane, o1);
+                }
                 PH(6);
                 __syncthreads();
                 PH(7);
@@ -267,23 +300,22 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                 float *ACT = smem + K::OFF_ACT + i * K::TILE;
                 float *GH2 = GP + PGR * SEG;
                 u64 *G3 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 2 * SEG * H;
-                float c3v = 0;
                 const bool is_pw = pw_thread && pj < nb;
-                if (is_pw) {
-                    const int f = cond_frame(a.seg_pos, a.seg_lim, b0 + pj, t, a.hop, a.NF);
-                    c3v = a.c3f[(size_t)f * H + prow];
-                }
+                const float c3v = a.c3f[(size_t)group_frame(GP, pj, t, a.hop, a.NF) * H + prow];
                 // h2(t) -> HS ; ACT = x1 + h2 (:216)
                 PH(8);
-                bool ok = sweep_layer<true, NL>(grs, soff_cl + i * SLOT_BYTES + 1 * LAYER_BYTES, tag, nb, tid, HS, ACT, a.status);
+                bool ok = pipe_sweep<true, NL>(grs, soff_cl + i * SLOT_BYTES + 1 * LAYER_BYTES, tag, nb, tid, HS, ACT, a.status);
                 if (!ok) report_failure(a.status, 0x300u | 2u, blockIdx.x, t, tid);
                 PH(4);
                 if (__syncthreads_or(!ok)) return;
                 PH(5);
                 put_partial<PNSLOT>(PART, w, 0, lane, mfma_tile(A_fc1, ACT + fi * LDC + kbase_lane));
-#pragma unroll
-                for (int rt = 0; rt < PRT; ++rt)                        // gh2(t+1) = W_hh2 . h2(t)
-                    put_partial<PNSLOT>(PART, w, PRT + rt, lane, mfma_tile(A_hh2[rt], HS + fi * LDC + kbase_lane));
+                {
+                    f32x4 o0, o1;
+                    mfma_tile2(A_hh2[0], A_hh2[1], HS + fi * LDC + kbase_lane, o0, o1);   // gh2(t+1) = W_hh2 . h2(t)
+                    put_partial<PNSLOT>(PART, w, PRT + 0, lane, o0);
+                    put_partial<PNSLOT>(PART, w, PRT + 1, lane, o1);
+                }
                 PH(6);
                 __syncthreads();
                 PH(7);
@@ -299,17 +331,14 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
             // =========================== S4: fc2 + relu (:220-221) ====================================
 #pragma unroll 1
             for (int i = 0; i < nact; ++i) {
-                const int nb = GEO[2 * i + 1], b0 = GEO[2 * i];
+                const int nb = GEO[2 * i + 1];
+                float *GP = smem + K::OFF_GRP + i * K::GRP;
                 float *ACT = smem + K::OFF_ACT + i * K::TILE;
                 u64 *G4 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 3 * SEG * H;
-                float c4v = 0;
                 const bool is_pw = pw_thread && pj < nb;
-                if (is_pw) {
-                    const int f = cond_frame(a.seg_pos, a.seg_lim, b0 + pj, t, a.hop, a.NF);
-                    c4v = a.c4f[(size_t)f * H + prow];
-                }
+                const float c4v = a.c4f[(size_t)group_frame(GP, pj, t, a.hop, a.NF) * H + prow];
                 PH(8);
-                bool ok = sweep_layer<false, NL>(grs, soff_cl + i * SLOT_BYTES + 2 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y1
+                bool ok = pipe_sweep<false, NL>(grs, soff_cl + i * SLOT_BYTES + 2 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y1
                 if (!ok) report_failure(a.status, 0x300u | 3u, blockIdx.x, t, tid);
                 PH(4);
                 if (__syncthreads_or(!ok)) return;
@@ -329,7 +358,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                     const int nb = GEO[2 * i + 1];
                     float *ACT = smem + K::OFF_ACT + i * K::TILE;
                     u64 *G5 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 4 * SEG * H;
-                    bool ok = sweep_layer<false, NL>(grs, soff_cl + i * SLOT_BYTES + 3 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y2
+                    bool ok = pipe_sweep<false, NL>(grs, soff_cl + i * SLOT_BYTES + 3 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y2
                     if (!ok) report_failure(a.status, 0x300u | 4u, blockIdx.x, t, tid);
                     PH(4);
                     if (__syncthreads_or(!ok)) return;
@@ -364,21 +393,11 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                 float *ACT = smem + K::OFF_ACT + i * K::TILE;
                 float *XS = GP + 2 * PGR * SEG + 2 * PU * SEG;
                 const int nb = GEO[2 * i + 1], b0 = GEO[2 * i];
-                // cI of the next step (row er, owned columns) and this step's sampling noise
-                float2 cn[16];
-                if (er < R) {
-                    const int tn = (t + 1 < T) ? t + 1 : t;
-                    const int erc = er < nb ? er : nb - 1;
-                    const float *crow = a.cI + ((size_t)tn * Btot + b0 + erc) * H + 2 * ec;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) cn[c] = *reinterpret_cast<const float2 *>(crow + 32 * c);
-                }
-                float nz0 = 0.5f, nz1 = 0.5f;                           // u1 (mixture pj of segment pu), u2 (pj == 0)
-                if (pu < nb) {
-                    const float *nrow = a.noise + (size_t)t * 11 * Btot;
-                    if (pj < 10) nz0 = nrow[(b0 + pu) * 10 + pj];
-                    if (pj == 0) nz1 = nrow[10 * Btot + b0 + pu];
-                }
+                // this step's sampling noise: clamped, unconditional loads (rows >= nb are never sampled)
+                const float *nrow = a.noise + (size_t)t * 11 * Btot;
+                const int puc = pu < nb ? pu : nb - 1;
+                const float nz0 = nrow[(b0 + puc) * 10 + (pj < 10 ? pj : 9)];
+                const float nz1 = nrow[10 * Btot + b0 + puc];
                 PH(10);
                 // gather the 30 logits of every segment: thread (segment er, c = ec < 15) reads logits 2c, 2c+1
                 {
@@ -409,6 +428,23 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                     PH(11);
                     if (__syncthreads_or(!ok)) return;
                     PH(12);
+                }
+                // cI of the next step (row er, owned columns).  Issued AFTER the last poll of this group's step: vector
+                // loads return in order, so an earlier issue would put the (cold) conditioning rows in front of every
+                // poll.  The rows are L2-warm: the block was touched one step ago (below); the sampling math hides the rest.
+                float2 cn[16];
+                {
+                    const int tn = (t + 1 < T) ? t + 1 : t;
+                    const int erc = er < nb ? er : nb - 1;
+                    const float *crow = a.cI + ((size_t)tn * Btot + b0 + erc) * H + 2 * ec;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) cn[c] = *reinterpret_cast<const float2 *>(crow + 32 * c);
+                    // touch the block of step t+2 (nb rows x 2 KB = one 128-B line per thread) so it is in this XCD's L2
+                    // by the time it is needed; the previous touch is retired first (issued one unit ago)
+                    asm volatile("" ::"v"(touch));
+                    const int tt = (t + 2 < T) ? t + 2 : T - 1;
+                    const int line = (tid < 16 * nb) ? tid : 0;
+                    touch = a.cI[((size_t)tt * Btot + b0) * H + 32 * line];
                 }
                 {   // 16-lane group = one segment (pu), lane pj = mixture
                     float best = (pj < 10) ? mol_gumbel(LOG[pu * 32 + pj], nz0) : -INFINITY;
@@ -441,6 +477,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
             }
         }
     }
+    asm volatile("" ::"v"(touch));
     if (PROF && tid == 0 && a.prof && blockIdx.x < MAXWG) {
 #pragma unroll
         for (int k = 0; k < NPROF; ++k) a.prof[(size_t)blockIdx.x * NPROF + k] = PROFL[k];

@@ -120,4 +120,84 @@ __device__ __forceinline__ bool sweep_layer(__amdgpu_buffer_rsrc_t rs, int soff,
     return true;
 }
 
+
+// Two row tiles that share the activation operand (the two 16-row tiles of one GRU matrix): B fragments are read
+// from LDS once, four independent accumulator chains keep the matrix pipe busy.  Per tile the accumulation order is
+// exactly mfma_tile's (even r -> chain 0, odd r -> chain 1, then chain 0 + chain 1), so results are bit-identical.
+__device__ __forceinline__ void mfma_tile2(const float (&a0)[AF], const float (&a1)[AF], const float *act_lane,
+                                           f32x4 &o0, f32x4 &o1)
+{
+    f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = {0.f, 0.f, 0.f, 0.f}, c10 = {0.f, 0.f, 0.f, 0.f}, c11 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < AF / 4; r += 2) {
+        const float4 b0 = *reinterpret_cast<const float4 *>(act_lane + 16 * r);
+        const float4 b1 = *reinterpret_cast<const float4 *>(act_lane + 16 * (r + 1));
+        c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + 0], b0.x, c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + 0], b0.x, c10, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + 4], b1.x, c01, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + 4], b1.x, c11, 0, 0, 0);
+        c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + 1], b0.y, c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + 1], b0.y, c10, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + 5], b1.y, c01, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + 5], b1.y, c11, 0, 0, 0);
+        c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + 2], b0.z, c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + 2], b0.z, c10, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + 6], b1.z, c01, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + 6], b1.z, c11, 0, 0, 0);
+        c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + 3], b0.w, c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + 3], b0.w, c10, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + 7], b1.w, c01, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + 7], b1.w, c11, 0, 0, 0);
+    }
+    o0 = c00 + c01;
+    o1 = c10 + c11;
+}
+
+// Streaming sweep: like sweep_layer<ADD, 8> but ONE pass keeps 8 loads in flight continuously -- slot i is consumed
+// (tag check + LDS write) and immediately reloaded with piece i+8 -- instead of two dependent half sweeps.  Values are
+// written to dst unconditionally and the pass repeats until every tag matched; the residual add runs afterwards from
+// dst (the thread re-reads its own LDS writes, in order).
+template <bool ADD>
+__device__ __forceinline__ bool sweep_stream(__amdgpu_buffer_rsrc_t rs, int soff, unsigned tag, int nb, int tid,
+                                             float *dst, float *acc, unsigned *status)
+{
+    const int r = tid >> 4, c = tid & 15;
+    if (r >= nb) return true;
+    const int voff = r * (H * 8) + c * 16;
+    unsigned spins = 0;
+    for (;;) {
+        u32x4 x[8];
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * 256, soff, 16 /* sc1 */);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ok &= (x[i].y == tag) & (x[i].w == tag);
+            *reinterpret_cast<float2 *>(dst + r * LDC + own_col(i, c)) = make_float2(__uint_as_float(x[i].x), __uint_as_float(x[i].z));
+            x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (8 + i) * 256, soff, 16 /* sc1 */);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ok &= (x[i].y == tag) & (x[i].w == tag);
+            *reinterpret_cast<float2 *>(dst + r * LDC + own_col(8 + i, c)) = make_float2(__uint_as_float(x[i].x), __uint_as_float(x[i].z));
+        }
+        if (ok) break;
+        ++spins;
+        if ((spins & 255u) == 0u) {
+            if (spins > SPIN_LIMIT || ld_agent32(status) != 0u) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (ADD) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float2 v = *reinterpret_cast<const float2 *>(dst + r * LDC + own_col(i, c));
+            float2 s = *reinterpret_cast<float2 *>(acc + r * LDC + own_col(i, c));
+            s.x += v.x; s.y += v.y;
+            *reinterpret_cast<float2 *>(acc + r * LDC + own_col(i, c)) = s;
+        }
+    }
+    return true;
+}
+
 }  // namespace wrnn
