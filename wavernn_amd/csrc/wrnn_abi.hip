@@ -13,6 +13,7 @@
 
 namespace wrnn {
 hipError_t launch_cond(const CondArgs &a, int n_cus, hipStream_t stream);
+hipError_t launch_noise_mol(const float *in, float *out, long n, int B, int n_cus, hipStream_t stream);
 hipError_t launch_stream(const LoopArgs &args, int mode, hipStream_t stream);
 hipError_t launch_persist(const LoopArgs &args, int U, int mode, hipStream_t stream);
 hipError_t launch_cluster(const LoopArgs &args, int U, int ncl, int mode, int nl, hipStream_t stream);
@@ -180,11 +181,11 @@ extern "C" size_t wrnn_pack_weight_bytes(const wrnn_pack *p) { return p ? p->wei
 
 namespace {
 struct WsLayout {
-    size_t status, prof, gran, segs, c2f, c3f, c4f, cI, total;
+    size_t status, prof, gran, segs, c2f, c3f, c4f, cI, npre, total;
 };
 constexpr size_t GRAN_BYTES = (size_t)GRAN_WORDS * sizeof(u64);
 size_t al(size_t x) { return (x + 255) / 256 * 256; }
-WsLayout ws_layout(int B, int T, int n_frames)
+WsLayout ws_layout(int B, int T, int n_frames, bool mol = true)
 {
     WsLayout l;
     size_t o = 0;
@@ -196,6 +197,7 @@ WsLayout ws_layout(int B, int T, int n_frames)
     l.c3f = o;    o = al(o + (size_t)(n_frames + 1) * H * sizeof(float));
     l.c4f = o;    o = al(o + (size_t)(n_frames + 1) * H * sizeof(float));
     l.cI = o;     o = al(o + (size_t)T * B * H * sizeof(float));
+    l.npre = o;   if (mol) o = al(o + (size_t)T * 11 * B * sizeof(float));   // derived MOL noise (pipelined kernel)
     l.total = o;
     return l;
 }
@@ -373,6 +375,10 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
         kind = K_PERSIST;
     } else if (algo != WRNN_ALGO_STREAM && algo != WRNN_ALGO_PIPE) { set_err("unknown algo %d", algo); return WRNN_ERR_ARG; }
 
+    if (kind == K_PIPE) {
+        HIPCHK(launch_noise_mol(noise, (float *)(ws + l.npre), (long)T * 11 * B, B, p->n_cus, stream));
+        a.noise_pre = (const float *)(ws + l.npre);
+    }
     HIPCHK(hipEventRecord(p->ev0, stream));
     if (kind == K_PIPE) {
         p->last_kernel = "wrnn_pipe_kernel";

@@ -80,6 +80,28 @@ __global__ __launch_bounds__(H) void wrnn_cond_frame_kernel(const CondArgs a)
     a.c4f[(size_t)f * H + r] = y4 + a.fc2_b[r];
 }
 
+// MOL sampling noise -> the two derived variates the sampler needs (utils/distribution.py:106-108,118-121), once per
+// launch instead of once per workgroup and step: mixture columns u -> log(-log u) (Gumbel), logistic column
+// u -> log u - log(1-u).  Same device math functions and operation order as the in-loop form (mol_gumbel / mol_sample).
+__global__ __launch_bounds__(256) void wrnn_noise_mol_kernel(const float *__restrict__ in, float *__restrict__ out, long n, int B)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float u = in[i];
+        const int col = (int)(i % (11L * B));
+        out[i] = (col < 10 * B) ? logf(-logf(u)) : (logf(u) - logf(1.0f - u));
+    }
+}
+
+hipError_t launch_noise_mol(const float *in, float *out, long n, int B, int n_cus, hipStream_t stream)
+{
+    long blocks = (n + 255) / 256;
+    if (blocks > (long)n_cus * 8) blocks = (long)n_cus * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wrnn_noise_mol_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, n, B);
+    return hipGetLastError();
+}
+
 hipError_t launch_cond(const CondArgs &a, int n_cus, hipStream_t stream)
 {
     hipLaunchKernelGGL(wrnn_cond_frame_kernel, dim3(a.NF + 1), dim3(H), 0, stream, a);

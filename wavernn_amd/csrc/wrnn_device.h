@@ -44,6 +44,7 @@ struct LoopArgs {
     const float *cI;                    // [T][Btot][H]   b_I + W_I[:,1:] . [m_t, a1_t]
     const float *c2f, *c3f, *c4f;       // [NF+1][3H], [NF+1][H], [NF+1][H]  per-frame aux projections + bias
     const float *noise;                 // MOL [T][11*Btot]; RAW [T][Btot][C]
+    const float *noise_pre;             // MOL, pipelined kernel: [T][11*Btot] derived variates (wrnn_noise_mol_kernel)
     const float *force_x;               // optional [Btot][T]
     float *out;                         // [Btot][T]
     float *dbg_logits;                  // optional [T][Btot][C]
@@ -90,6 +91,17 @@ __device__ __forceinline__ float gru_update(float gi_r, float gi_z, float gi_n, 
 
 // utils/distribution.py:106-108  logit_probs - log(-log(u))
 __device__ __forceinline__ float mol_gumbel(float lp, float u) { return lp - logf(-logf(u)); }
+
+// the same two steps on pre-transformed noise (wrnn_noise_mol_kernel): g = log(-log u), l = log u - log(1-u)
+__device__ __forceinline__ float mol_gumbel_pre(float lp, float g) { return lp - g; }
+__device__ __forceinline__ float mol_sample_pre(float mean, float ls, float l)
+{
+    const float lsmin = -32.23619130191664f;
+    ls = fmaxf(ls, lsmin);
+    float x = mean + expf(ls) * l;
+    x = fmaxf(x, -1.0f);
+    return fminf(x, 1.0f);
+}
 
 // utils/distribution.py:113-121  x = clamp(mean + exp(max(ls, ln 1e-14)) * (log u - log(1-u)), -1, 1)
 __device__ __forceinline__ float mol_sample(float mean, float ls, float u)

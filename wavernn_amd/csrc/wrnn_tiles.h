@@ -127,11 +127,15 @@ __device__ __forceinline__ bool sweep_layer(__amdgpu_buffer_rsrc_t rs, int soff,
 __device__ __forceinline__ void mfma_tile2(const float (&a0)[AF], const float (&a1)[AF], const float *act_lane,
                                            f32x4 &o0, f32x4 &o1)
 {
+    // all 8 B fragments up front (32 registers, free during the MFMA phase): 64 MFMAs then issue back to back
+    float4 b[AF / 4];
+#pragma unroll
+    for (int r = 0; r < AF / 4; ++r) b[r] = *reinterpret_cast<const float4 *>(act_lane + 16 * r);
+    __builtin_amdgcn_sched_barrier(0);      // keep the 8 ds_read_b128 ahead of the MFMA stream (hipcc sinks them otherwise)
     f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = {0.f, 0.f, 0.f, 0.f}, c10 = {0.f, 0.f, 0.f, 0.f}, c11 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < AF / 4; r += 2) {
-        const float4 b0 = *reinterpret_cast<const float4 *>(act_lane + 16 * r);
-        const float4 b1 = *reinterpret_cast<const float4 *>(act_lane + 16 * (r + 1));
+        const float4 b0 = b[r], b1 = b[r + 1];
         c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + 0], b0.x, c00, 0, 0, 0);
         c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + 0], b0.x, c10, 0, 0, 0);
         c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + 4], b1.x, c01, 0, 0, 0);
@@ -151,6 +155,29 @@ __device__ __forceinline__ void mfma_tile2(const float (&a0)[AF], const float (&
     }
     o0 = c00 + c01;
     o1 = c10 + c11;
+}
+
+// mfma_tile with the 8 B fragments loaded up front (same accumulation order, bit-identical result)
+__device__ __forceinline__ f32x4 mfma_tile_pre(const float (&a)[AF], const float *act_lane)
+{
+    float4 b[AF / 4];
+#pragma unroll
+    for (int r = 0; r < AF / 4; ++r) b[r] = *reinterpret_cast<const float4 *>(act_lane + 16 * r);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < AF / 4; r += 2) {
+        const float4 b0 = b[r], b1 = b[r + 1];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 0], b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 4], b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 1], b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 5], b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 2], b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 6], b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 3], b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 7], b1.w, acc1, 0, 0, 0);
+    }
+    return acc0 + acc1;
 }
 
 // Streaming sweep: like sweep_layer<ADD, 8> but ONE pass keeps 8 loads in flight continuously -- slot i is consumed
