@@ -73,17 +73,6 @@ __device__ __forceinline__ bool pipe_sweep(__amdgpu_buffer_rsrc_t rs, int soff, 
     return sweep_layer<ADD, 16>(rs, soff, tag, nb, tid, dst, acc, status);
 }
 
-// Warm this XCD's L2 with the granule rows the NEXT unit will sweep: a remote sc1 store invalidates the L2 copy, so the
-// first sc1 read of a row set pays a fabric round trip (~1 us).  Issued right after the current unit's sweep (the loads
-// fly during its MFMA / pointwise work) and retired before the next sweep; thread (r, c) touches lines 2c, 2c+1 of row r.
-__device__ __forceinline__ void touch_rows(__amdgpu_buffer_rsrc_t rs, int soff, int nb, int tid, unsigned &t0, unsigned &t1)
-{
-    const int r = tid >> 4, c = tid & 15;
-    const int voff = (r < nb ? r : 0) * (H * 8) + c * 256;
-    t0 = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 16 /* sc1 */);
-    t1 = __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 128, soff, 16 /* sc1 */);
-}
-
 // conditioning frame of segment j of a group at step t, from the group's LDS copy of the segment table
 __device__ __forceinline__ int group_frame(const float *GP, int j, int t, int hop, int NF)
 {
@@ -106,7 +95,6 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
     u64 *PROFL = reinterpret_cast<u64 *>(smem + K::OFF_PROF);
     u64 plast = 0;
     float touch = 0.f;                                  // in-flight L2 touch of a future cI block (S6)
-    unsigned tg0 = 0u, tg1 = 0u;                        // in-flight L2 touches of the next unit's granule rows
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // cluster / workgroup-in-cluster: whole XCDs per cluster (block b runs on XCD b % 8; speed only)
@@ -232,10 +220,6 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                 float *GH1 = GP, *HOWN1 = GP + 2 * PGR * SEG;
                 u64 *G1 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 0 * SEG * H;
                 __syncthreads();                                         // PART free; ACT written by S6 visible
-                if (G > 1 && i + 1 == nact && t > 0) {                   // next sweep: S2 of slot 0 (published one S1 pass ago)
-                    asm volatile("" ::"v"(tg0), "v"(tg1));
-                    touch_rows(grs, soff_cl + 0 * SLOT_BYTES + 0 * LAYER_BYTES, GEO[1], tid, tg0, tg1);
-                }
                 PH(0);
                 {
                     f32x4 o0, o1;
@@ -274,15 +258,10 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                 const float c2n = a.c2f[(size_t)f2 * 3 * H + 2 * H + prow];
                 // h1(t) -> HS ; ACT = xi + h1 (:212)
                 PH(8);
-                if (G > 1) asm volatile("" ::"v"(tg0), "v"(tg1));       // retire the touches issued one unit ago
                 bool ok = pipe_sweep<true, NL>(grs, soff_cl + i * SLOT_BYTES + 0 * LAYER_BYTES, tag, nb, tid, HS, ACT, a.status);
                 if (!ok) report_failure(a.status, 0x300u | 1u, blockIdx.x, t, tid);
                 PH(4);
                 if (__syncthreads_or(!ok)) return;
-                if (G > 1) {                                             // next sweep: S2 of the next slot, else S3 of slot 0
-                    const int j = (i + 1 < nact) ? i + 1 : 0;
-                    touch_rows(grs, soff_cl + j * SLOT_BYTES + ((i + 1 < nact) ? 0 : 1) * LAYER_BYTES, GEO[2 * j + 1], tid, tg0, tg1);
-                }
                 PH(5);
                 {
                     f32x4 o0, o1;
@@ -325,15 +304,10 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                 const float c3v = a.c3f[(size_t)group_frame(GP, pj, t, a.hop, a.NF) * H + prow];
                 // h2(t) -> HS ; ACT = x1 + h2 (:216)
                 PH(8);
-                if (G > 1) asm volatile("" ::"v"(tg0), "v"(tg1));
                 bool ok = pipe_sweep<true, NL>(grs, soff_cl + i * SLOT_BYTES + 1 * LAYER_BYTES, tag, nb, tid, HS, ACT, a.status);
                 if (!ok) report_failure(a.status, 0x300u | 2u, blockIdx.x, t, tid);
                 PH(4);
                 if (__syncthreads_or(!ok)) return;
-                if (G > 1) {                                             // next sweep: S3 of the next slot, else S4 of slot 0
-                    const int j = (i + 1 < nact) ? i + 1 : 0;
-                    touch_rows(grs, soff_cl + j * SLOT_BYTES + ((i + 1 < nact) ? 1 : 2) * LAYER_BYTES, GEO[2 * j + 1], tid, tg0, tg1);
-                }
                 PH(5);
                 put_partial<PNSLOT>(PART, w, 0, lane, mfma_tile_pre(A_fc1, ACT + fi * LDC + kbase_lane));
                 {
@@ -364,15 +338,10 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                 const bool is_pw = pw_thread && pj < nb;
                 const float c4v = a.c4f[(size_t)group_frame(GP, pj, t, a.hop, a.NF) * H + prow];
                 PH(8);
-                if (G > 1) asm volatile("" ::"v"(tg0), "v"(tg1));
                 bool ok = pipe_sweep<false, NL>(grs, soff_cl + i * SLOT_BYTES + 2 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y1
                 if (!ok) report_failure(a.status, 0x300u | 3u, blockIdx.x, t, tid);
                 PH(4);
                 if (__syncthreads_or(!ok)) return;
-                if (G > 1 && (i + 1 < nact || fc3_wg)) {                 // next sweep: S4 of the next slot, else S5 of slot 0
-                    const int j = (i + 1 < nact) ? i + 1 : 0;
-                    touch_rows(grs, soff_cl + j * SLOT_BYTES + ((i + 1 < nact) ? 2 : 3) * LAYER_BYTES, GEO[2 * j + 1], tid, tg0, tg1);
-                }
                 PH(5);
                 put_partial<PNSLOT>(PART, w, 0, lane, mfma_tile_pre(A_fc2, ACT + fi * LDC + kbase_lane));
                 PH(6);
@@ -389,13 +358,10 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                     const int nb = GEO[2 * i + 1];
                     float *ACT = smem + K::OFF_ACT + i * K::TILE;
                     u64 *G5 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 4 * SEG * H;
-                    if (G > 1) asm volatile("" ::"v"(tg0), "v"(tg1));
-                    bool ok = pipe_sweep<false, NL>(grs, soff_cl + i * SLOT_BYTES + 3 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y2
+                        bool ok = pipe_sweep<false, NL>(grs, soff_cl + i * SLOT_BYTES + 3 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y2
                     if (!ok) report_failure(a.status, 0x300u | 4u, blockIdx.x, t, tid);
                     PH(4);
                     if (__syncthreads_or(!ok)) return;
-                    if (G > 1 && i + 1 < nact)                           // next sweep: S5 of the next slot
-                        touch_rows(grs, soff_cl + (i + 1) * SLOT_BYTES + 3 * LAYER_BYTES, GEO[2 * (i + 1) + 1], tid, tg0, tg1);
                     PH(5);
                     {   // thread (segment pj, k-chunk pu): 32 terms of logit[wg][pj]
                         const float *xr = ACT + (pj < R ? pj : R - 1) * LDC + 32 * pu;
@@ -511,7 +477,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
             }
         }
     }
-    asm volatile("" ::"v"(touch), "v"(tg0), "v"(tg1));
+    asm volatile("" ::"v"(touch));
     if (PROF && tid == 0 && a.prof && blockIdx.x < MAXWG) {
 #pragma unroll
         for (int k = 0; k < NPROF; ++k) a.prof[(size_t)blockIdx.x * NPROF + k] = PROFL[k];
