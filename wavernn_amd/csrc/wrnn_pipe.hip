@@ -28,7 +28,7 @@ constexpr int PNWGC = H / PU;         // workgroups per cluster (64)
 constexpr int PGR = 3 * PU;           // GRU gate rows per workgroup (24)
 constexpr int PRT = 2;                // 16-row MFMA tiles per GRU matrix
 constexpr int PNSLOT = 4;             // partial-tile slots per wave: 0,1 critical; 2,3 hidden-to-hidden
-constexpr int PGHI = (PGR * SEG + NT - 1) / NT;
+static_assert((PGR * SEG) % (NT / 2) == 0, "gh reduce split over waves 2,3");
 
 template <int G>
 struct PipeCfg {
@@ -284,10 +284,12 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                     HOWN2[pu * SEG + pj] = hn;
                     publish(G2, tag, pj, prow, hn);
                 }
+                if (tid >= NT / 2) {                                     // waves 2,3 (idle during the pointwise math of waves 0,1)
 #pragma unroll
-                for (int q0 = 0; q0 < PGHI; ++q0) {
-                    const int q = tid + NT * q0;
-                    if (q < PGR * SEG) GH1[q] = get_partial<PNSLOT>(PART, PRT, q >> 4, q & 15) + BH1[q >> 4];
+                    for (int q0 = 0; q0 < (PGR * SEG) / (NT / 2); ++q0) {
+                        const int q = (tid - NT / 2) + (NT / 2) * q0;
+                        GH1[q] = get_partial<PNSLOT>(PART, PRT, q >> 4, q & 15) + BH1[q >> 4];
+                    }
                 }
                 PH(8);
             }
@@ -320,10 +322,12 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                 __syncthreads();
                 PH(7);
                 if (is_pw) publish(G3, tag, pj, prow, fmaxf(get_partial<PNSLOT>(PART, 0, pu, pj) + c3v, 0.f));
+                if (tid >= NT / 2) {                                     // waves 2,3 (idle during the pointwise math of waves 0,1)
 #pragma unroll
-                for (int q0 = 0; q0 < PGHI; ++q0) {
-                    const int q = tid + NT * q0;
-                    if (q < PGR * SEG) GH2[q] = get_partial<PNSLOT>(PART, PRT, q >> 4, q & 15) + BH2[q >> 4];
+                    for (int q0 = 0; q0 < (PGR * SEG) / (NT / 2); ++q0) {
+                        const int q = (tid - NT / 2) + (NT / 2) * q0;
+                        GH2[q] = get_partial<PNSLOT>(PART, PRT, q >> 4, q & 15) + BH2[q >> 4];
+                    }
                 }
                 PH(8);
             }
