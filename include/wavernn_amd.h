@@ -160,6 +160,39 @@ const char *wrnn_last_loop_kernel(const wrnn_pack *p);
  * flight per cluster (0,0,0 = stream) */
 int wrnn_last_loop_split(const wrnn_pack *p, int *units_per_wg, int *clusters, int *groups_in_flight);
 
+/*
+ * Pre-loop stage: `UpsampleNetwork.forward` (fatchord_version.py:82-89) = MelResNet (:31-48) + ResBlocks (:13-28) on
+ * f32 MFMA, and the Stretch2d / box-filter up-sampling of the mel (:51-61, :73-80, :86-88).  Host pointers, float32,
+ * row-major, in the reference's state-dict order (keys in comments, C = compute_dims, R = res_out_dims).
+ */
+typedef struct wrnn_pre_weights {
+    int32_t feat_dims;            /* 80 */
+    int32_t compute_dims;         /* C: 128 in this build */
+    int32_t res_out_dims;         /* R: 128 in this build */
+    int32_t res_blocks;           /* number of ResBlocks */
+    int32_t pad;                  /* 2 */
+    int32_t upsample_factors[3];  /* (5, 5, 11) */
+    const float *conv_in_w;       /* upsample.resnet.conv_in.weight (C, feat, 2*pad+1) */
+    const float *bn_in;           /* upsample.resnet.batch_norm.{weight,bias,running_mean,running_var}: [4][C] */
+    const float *res_w;           /* upsample.resnet.layers.{i}.{conv1,conv2}.weight: [res_blocks][2][C][C] */
+    const float *res_bn;          /* upsample.resnet.layers.{i}.batch_norm{1,2}.{weight,bias,running_mean,running_var}: [res_blocks][2][4][C] */
+    const float *conv_out_w;      /* upsample.resnet.conv_out.weight (R, C) */
+    const float *conv_out_b;      /* upsample.resnet.conv_out.bias (R) */
+    const float *up_w;            /* upsample.up_layers.{1,3,5}.weight, concatenated: (2*s0+1) + (2*s1+1) + (2*s2+1) taps */
+} wrnn_pre_weights;
+typedef struct wrnn_pre wrnn_pre;
+
+int wrnn_pre_create(const wrnn_pre_weights *w, int device, wrnn_pre **out);
+void wrnn_pre_destroy(wrnn_pre *p);
+int wrnn_pre_hop(const wrnn_pre *p);                                   /* product of the upsample factors */
+size_t wrnn_pre_workspace_bytes(const wrnn_pre *p, int32_t n_frames);
+/* mel: device [feat][n_frames] (the (1, feat, N) tensor generate() receives, fatchord_version.py:169,183);
+ * mels_up: device [n_frames*hop][feat]; aux: device [n_frames][R] (per FRAME: the x hop Stretch2d repeat of :83-85 is
+ * left to the loop).  Several utterances: call once per utterance with offset output pointers.  Asynchronous on `stream`. */
+int wrnn_pre_upsample(const wrnn_pre *p, const float *mel, int32_t n_frames, float *mels_up, float *aux,
+                      void *workspace, size_t workspace_bytes, void *stream);
+const char *wrnn_pre_last_error(void);
+
 /* Profiling builds (environment WRNN_PROF=1 at wrnn_generate time, pipelined kernel): copies the per-workgroup phase
  * clocks [256 workgroups][16 phases] (shader cycles summed over the launch; phases listed in wrnn_pipe.hip) to `out`.
  * Synchronises `stream`.  Returns the number of words copied or a negative error. */

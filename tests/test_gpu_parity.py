@@ -137,9 +137,44 @@ def test_teacher_forced_logits(gpu, name, variant, monkeypatch):
     assert err <= 1e-4, err
 
 
+@pytest.mark.parametrize('frames', [21, 16, 53, 100, 481])
+def test_pre_loop_kernels_match_oracle(gpu, frames):
+    """`wrnn_pre_upsample` (MFMA MelResNet + box-filter up-sampling) vs the oracle's numpy UpsampleNetwork (itself pinned
+    to the reference in test_oracle_golden.py).  float32 with a different summation order: mel 5e-6, aux 5e-5 abs."""
+    from oracle import wavernn_oracle as O
+    from wavernn_amd.pre import PreEngine
+    from wavernn_amd.synthetic import random_state_dict, random_mel
+    sd = random_state_dict(61, mode='MOL')
+    mel = random_mel(700 + frames, frames)
+    m = O.pad_tensor(mel.T[None], 2, 'both')[0].T
+    ref_mels, ref_aux = O.upsample_network(sd, m)
+    eng = PreEngine(sd, device=gpu)
+    assert eng.hop == 275
+    mels_up, aux = eng.upsample(torch.from_numpy(mel).to(gpu))
+    torch.cuda.synchronize()
+    assert mels_up.shape == (frames * 275, 80) and aux.shape == (frames, 128)
+    np.testing.assert_allclose(mels_up.cpu().numpy(), ref_mels, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(aux.cpu().numpy(), ref_aux[::275], rtol=0, atol=5e-5)
+
+
 @pytest.mark.parametrize('name', CASES)
-def test_generate_end_to_end(gpu, name, tmp_path):
-    """`WaveRNN.generate()` drop-in (PyTorch-ROCm upsample + HIP loop + host unfold) vs the reference's returned
+def test_pre_loop_kernels_match_reference_golden(gpu, name):
+    """... and against the conditioning the reference itself produced (strided samples kept in the golden fixtures)."""
+    from wavernn_amd.pre import PreEngine
+    from wavernn_amd.synthetic import random_state_dict, random_mel
+    cfg, g = load_case(name)
+    sd = random_state_dict(cfg['wseed'], mode=cfg['mode'])
+    mel = random_mel(cfg['mseed'], cfg['frames'])
+    mels_up, aux = PreEngine(sd, device=gpu).upsample(torch.from_numpy(mel).to(gpu))
+    np.testing.assert_allclose(mels_up.cpu().numpy()[::97], g['mels_up_strided'], rtol=0, atol=5e-6)
+    rows = (np.arange(g['aux_up_strided'].shape[0]) * 97) // 275
+    np.testing.assert_allclose(aux.cpu().numpy()[rows], g['aux_up_strided'], rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize('pre', ['native', 'torch'])
+@pytest.mark.parametrize('name', CASES)
+def test_generate_end_to_end(gpu, name, pre, tmp_path):
+    """`WaveRNN.generate()` drop-in (HIP or PyTorch-ROCm upsample + HIP loop + host unfold) vs the reference's returned
     float64 waveform under the same `torch.manual_seed`."""
     from wavernn_amd.model import WaveRNN
     from wavernn_amd.synthetic import random_state_dict, random_mel, SHIPPED
@@ -148,6 +183,7 @@ def test_generate_end_to_end(gpu, name, tmp_path):
     sd = random_state_dict(cfg['wseed'], mode=cfg['mode'])
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
     model = model.to(gpu)
+    model.pre_algo = pre
     mel = random_mel(cfg['mseed'], cfg['frames'])
     torch.manual_seed(cfg['seed'])
     wav = tmp_path / 'o.wav'

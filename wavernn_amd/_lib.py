@@ -20,13 +20,20 @@ ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'persist': ALGO_PERSIST, 'clu
 EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_create', 'wrnn_pack_destroy',
            'wrnn_pack_weight_bytes', 'wrnn_workspace_bytes', 'wrnn_workspace_bytes_segments', 'wrnn_generate',
            'wrnn_generate_segments', 'wrnn_status', 'wrnn_last_loop_ms', 'wrnn_last_loop_kernel',
-           'wrnn_last_loop_split', 'wrnn_profile_read', 'wrnn_selftest', 'wrnn_selftest_metric']
+           'wrnn_last_loop_split', 'wrnn_profile_read', 'wrnn_selftest', 'wrnn_selftest_metric', 'wrnn_pre_create',
+           'wrnn_pre_destroy', 'wrnn_pre_hop', 'wrnn_pre_workspace_bytes', 'wrnn_pre_upsample', 'wrnn_pre_last_error']
 
 
 class Weights(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('rnn_dims', 'fc_dims', 'feat_dims', 'aux_dims', 'n_classes', 'mode')] + \
                [(n, ctypes.c_void_p) for n in ('I_w', 'I_b', 'w_ih1', 'w_hh1', 'b_ih1', 'b_hh1', 'w_ih2', 'w_hh2',
                                                'b_ih2', 'b_hh2', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'fc3_w', 'fc3_b')]
+
+
+class PreWeights(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('feat_dims', 'compute_dims', 'res_out_dims', 'res_blocks', 'pad')] + \
+               [('upsample_factors', ctypes.c_int32 * 3)] + \
+               [(n, ctypes.c_void_p) for n in ('conv_in_w', 'bn_in', 'res_w', 'res_bn', 'conv_out_w', 'conv_out_b', 'up_w')]
 
 
 class Geometry(ctypes.Structure):
@@ -90,6 +97,15 @@ def lib():
                                          ctypes.POINTER(Debug), ctypes.c_void_p]
     L.wrnn_last_loop_split.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                        ctypes.POINTER(ctypes.c_int)]
+    L.wrnn_pre_create.argtypes = [ctypes.POINTER(PreWeights), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.wrnn_pre_destroy.argtypes = [ctypes.c_void_p]
+    L.wrnn_pre_destroy.restype = None
+    L.wrnn_pre_hop.argtypes = [ctypes.c_void_p]
+    L.wrnn_pre_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    L.wrnn_pre_workspace_bytes.restype = ctypes.c_size_t
+    L.wrnn_pre_upsample.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.wrnn_pre_last_error.restype = ctypes.c_char_p
     L.wrnn_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.wrnn_status.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.wrnn_last_loop_ms.argtypes = [ctypes.c_void_p]

@@ -126,10 +126,15 @@ class WaveRNN(nn.Module):
         #: 'cpu' = consume torch's global CPU generator exactly like the reference's CPU run (parity);
         #: 'device' = device Philox generator (what the reference does when it runs on a GPU)
         self.noise_source = 'cpu'
-        #: 'auto' | 'persist' | 'stream'
+        #: 'auto' | 'pipe' | 'cluster' | 'persist' | 'stream'
         self.loop_algo = 'auto'
+        #: 'native' = the HIP pre-loop kernels (MFMA MelResNet + box-filter up-sampling, wrnn_pre_*);
+        #: 'torch' = the nn.Modules below through PyTorch-ROCm (MIOpen)
+        self.pre_algo = 'native'
         self._engine = None
         self._engine_key = None
+        self._pre = None
+        self._pre_key = None
         self.last_loop_ms = None
         self.last_loop_kernel = None
 
@@ -165,12 +170,24 @@ class WaveRNN(nn.Module):
             self._engine_key = key
         return self._engine
 
+    def _pre_engine(self):
+        from .pre import PreEngine
+        sd = {k: v for k, v in self.state_dict().items() if k.startswith('upsample.')}
+        key = tuple((k, v.data_ptr(), v._version, str(v.device)) for k, v in sorted(sd.items()))
+        if self._pre is None or key != self._pre_key:
+            self._pre = PreEngine(sd, device=next(self.parameters()).device)
+            self._pre_key = key
+        return self._pre
+
     def conditioning(self, mels):
         """Pre-loop stage (reference :183-186) without the Stretch2d repeat of aux and without the fold:
         returns mels_up (L, feat), aux frames (N, res_out), wave_len."""
         device = next(self.parameters()).device
         mels = torch.as_tensor(mels, device=device)
         wave_len = (mels.size(-1) - 1) * self.hop_length
+        if self.pre_algo == 'native' and device.type == 'cuda':
+            mels_up, aux = self._pre_engine().upsample(mels.float())
+            return mels_up, aux, wave_len
         m = _fold.pad_tensor(mels.transpose(1, 2), pad=self.pad, side='both').transpose(1, 2)
         mels_up = self.upsample.upsample_mel(m)[0].contiguous()
         aux = self.upsample.aux_frames(m)[0].transpose(0, 1).contiguous()
