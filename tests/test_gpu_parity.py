@@ -282,6 +282,80 @@ def test_segment_table_several_utterances(gpu, variant, monkeypatch):
         assert np.abs(got - ref).max() <= MOL_TOL, (u, np.abs(got - ref).max())
 
 
+@pytest.mark.parametrize('mode,variant', [('MOL', 'auto'), ('RAW', 'auto'), ('MOL', 'pipe-g2')])
+def test_block_sparse_gru_weights(gpu, mode, variant, monkeypatch):
+    """BASELINE config 5: the GRU matrices block-pruned to 95 % zeros (16x1 blocks, per gate) run through the dense HIP
+    kernels as masked weights and must equal the oracle on the same pruned weights."""
+    from oracle import c_oracle as C, wavernn_oracle as O
+    from wavernn_amd.engine import LoopEngine
+    from wavernn_amd.prune import block_prune_state_dict
+    from wavernn_amd.synthetic import random_state_dict
+    if variant == 'auto':
+        for k in ENV_KEYS:
+            monkeypatch.delenv(k, raising=False)
+        algo = 'auto'
+    else:
+        algo = _select(monkeypatch, variant)
+    cfg = dict(mode=mode, wseed=33, mseed=133, frames=100, batched=True, target=550, overlap=55, seed=93)
+    sd0, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
+    sd, density = block_prune_state_dict(sd0, 0.95, (16, 1))
+    assert all(0.049 < d < 0.0512 for d in density.values()), density
+    m = O.pad_tensor(mel.T[None], 2, 'both')[0].T
+    mels_up, aux_up = O.upsample_network(sd, m)                       # upsample weights are not pruned
+    mels_f, aux_f, _ = O.conditioning(sd, mel, True, cfg['target'], cfg['overlap'])
+    ref = C.loop(sd, mode, mels_f, aux_f, noise)
+    eng = LoopEngine(sd, mode, device=gpu)
+    out = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(np.ascontiguousarray(aux_up[::275])).to(gpu), B, T, stride,
+                  torch.from_numpy(flat).to(gpu), 275, algo=algo).cpu().numpy()
+    if mode == 'RAW':
+        bad = np.argwhere(out != ref)
+        assert bad.size == 0, f'first divergence at (b,t)={bad[0]}'
+    else:
+        assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
+
+
+def test_config1_raw_unbatched_one_second(gpu, tmp_path):
+    """BASELINE config 1 geometry: 9-bit mu-law WaveRNN, unbatched generate on 1 s of random mel (81 frames -> 22,275
+    steps, one segment) -- `generate()` end to end against the oracle's end-to-end restatement, bit-exact."""
+    from oracle import wavernn_oracle as O
+    from wavernn_amd.model import WaveRNN
+    from wavernn_amd.synthetic import random_state_dict, random_mel, SHIPPED
+    sd = random_state_dict(0, mode='RAW')
+    mel = random_mel(1234, 81)
+    ref = O.generate(sd, 'RAW', mel, False, 11000, 550, True, 77)
+    model = WaveRNN(**SHIPPED, mode='RAW')
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(gpu)
+    torch.manual_seed(77)
+    out = model.generate(torch.tensor(mel).unsqueeze(0), tmp_path / 'c1.wav', False, 11000, 550, True)
+    assert out.shape == ref.shape == (22000,)
+    assert np.array_equal(out, ref), f'{np.count_nonzero(out != ref)} of {out.size} samples differ'
+    print(f'config 1 on the GPU: loop {model.last_loop_kernel} {model.last_loop_ms:.1f} ms for 22275 steps')
+
+
+@pytest.mark.parametrize('mode', ['MOL', 'RAW'])
+def test_generate_corpus_equals_per_utterance_generate(gpu, mode, tmp_path):
+    """`generate_corpus` (one launch for several utterances, single process) == one `generate()` call per utterance with
+    `torch.manual_seed(seed_u)` before each -- the reference's usage (gen_wavernn.py:26-35)."""
+    from wavernn_amd.batch import generate_corpus
+    from wavernn_amd.model import WaveRNN
+    from wavernn_amd.synthetic import random_state_dict, random_mel, SHIPPED
+    sd = random_state_dict(52, mode=mode)
+    model = WaveRNN(**SHIPPED, mode=mode)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(gpu)
+    frames, seeds = [23, 40, 31, 26, 55], [910, 911, 912, 913, 914]
+    mels = [torch.from_numpy(random_mel(610 + u, n)).unsqueeze(0) for u, n in enumerate(frames)]
+    outs = generate_corpus(model, mels, 550, 55, True, seeds)
+    for u, mel in enumerate(mels):
+        torch.manual_seed(seeds[u])
+        one = model.generate(mel, tmp_path / f'u{u}.wav', True, 550, 55, True)
+        if mode == 'RAW':
+            assert np.array_equal(outs[u], one), (u, np.abs(outs[u] - one).max())
+        else:
+            assert np.abs(outs[u] - one).max() <= MOL_TOL
+
+
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_full_size_properties(gpu, mode):
     """BASELINE config 2 geometry (B=12, T=12100): cluster and stream kernels agree, runs are deterministic,

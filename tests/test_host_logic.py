@@ -132,3 +132,28 @@ def test_private_generator_equals_global_stream(mode):
     if mode == 'MOL':
         ref = np.concatenate([ref[0].reshape(T, B * 10), ref[1].reshape(T, B)], axis=1)
     assert np.array_equal(a.numpy().reshape(ref.shape), ref)
+
+
+def test_block_prune_mask():
+    """Config 5 recipe: per gate, the 95 % lowest-magnitude 16x1 blocks are zeroed; survivors keep their values."""
+    from wavernn_amd.prune import block_mask, block_prune_state_dict
+    from wavernn_amd.synthetic import random_state_dict
+    sd = random_state_dict(3, mode='MOL')
+    out, density = block_prune_state_dict(sd, 0.95, (16, 1))
+    for k in ('rnn1.weight_ih_l0', 'rnn1.weight_hh_l0', 'rnn2.weight_ih_l0', 'rnn2.weight_hh_l0'):
+        W, P = sd[k], out[k]
+        assert P.shape == W.shape and abs(density[k] - 0.05) < 1.2e-3
+        nz = P != 0
+        assert np.array_equal(P[nz], W[nz])
+        for g in range(3):                                   # every gate is pruned on its own
+            blk = nz[g * 512:(g + 1) * 512].reshape(32, 16, -1)
+            assert np.all(blk.all(axis=1) | ~blk.any(axis=1))          # blocks are all-or-nothing
+            assert abs(blk.any(axis=1).mean() - 0.05) < 2e-3
+    assert np.array_equal(out['fc1.weight'], sd['fc1.weight'])
+    # the notebook's element-wise rule is the 1x1 special case
+    W = sd['rnn1.weight_hh_l0']
+    M = block_mask(W, 0.9, (1, 1))
+    for g in range(3):
+        a = np.abs(W[g * 512:(g + 1) * 512])
+        thr = np.sort(a.reshape(-1))[int(a.size * 0.9)]
+        assert np.array_equal(M[g * 512:(g + 1) * 512], (a >= thr).astype(np.float32))

@@ -119,7 +119,8 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
     const int pu = tid >> 4, pj = tid & 15;             // pointwise role: (owned unit pu, segment pj) for tid < 16*PU
     const bool pw_thread = tid < 16 * PU;
     const int prow = PU * wg + (pu % PU);
-    const bool fc3_wg = wg < 30;                        // this workgroup owns logit row `wg`
+    const bool fc3_wg = wg < 60;                        // this workgroup owns one K-half of logit row wg % 30
+    const int f3row = wg % 30, f3half = (wg / 30) & 1;
 
     // ---- one-time: weight slice -> register-resident MFMA A fragments (row ri = gate*PU + u, tile ri/16) ------
     float A_ih1[PRT][AF], A_hh1[PRT][AF], A_ih2[PRT][AF], A_hh2[PRT][AF], A_fc1[AF], A_fc2[AF];
@@ -143,8 +144,8 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
     __syncthreads();
     WI0[2 * tid] = a.I_w0[2 * tid];
     WI0[2 * tid + 1] = a.I_w0[2 * tid + 1];
-    if (fc3_wg) { W3R[2 * tid] = a.fc3_w[(size_t)wg * H + 2 * tid]; W3R[2 * tid + 1] = a.fc3_w[(size_t)wg * H + 2 * tid + 1]; }
-    const float b3 = fc3_wg ? a.fc3_b[wg] : 0.f;
+    if (fc3_wg) { W3R[2 * tid] = a.fc3_w[(size_t)f3row * H + 2 * tid]; W3R[2 * tid + 1] = a.fc3_w[(size_t)f3row * H + 2 * tid + 1]; }
+    const float b3 = (fc3_wg && f3half == 0) ? a.fc3_b[f3row] : 0.f;       // the bias rides on the k < 256 partial
     if (tid < PGR) {
         const int grow = (tid / PU) * H + PU * wg + (tid % PU);
         BI1[tid] = a.b_ih1[grow];
@@ -355,24 +356,25 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                 PH(8);
             }
 
-            // =========================== S5: fc3, one logit row per workgroup (:223) ==================
+            // =========================== S5: fc3 (:223): workgroup wg < 60 = K-half wg/30 of logit row wg%30 ==========
             if (fc3_wg) {                                               // workgroup-uniform
 #pragma unroll 1
                 for (int i = 0; i < nact; ++i) {
                     const int nb = GEO[2 * i + 1];
                     float *ACT = smem + K::OFF_ACT + i * K::TILE;
                     u64 *G5 = a.gran + (size_t)(cl * MAXG + i) * NGRAN * SEG * H + 4 * SEG * H;
-                        bool ok = pipe_sweep<false, NL>(grs, soff_cl + i * SLOT_BYTES + 3 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y2
+                    bool ok = sweep_half(grs, soff_cl + i * SLOT_BYTES + 3 * LAYER_BYTES, tag, nb, tid, ACT, f3half, a.status);   // ACT <- half of y2
                     if (!ok) report_failure(a.status, 0x300u | 4u, blockIdx.x, t, tid);
                     PH(4);
                     if (__syncthreads_or(!ok)) return;
                     PH(5);
-                    {   // thread (segment pj, k-chunk pu): 32 terms of logit[wg][pj]
-                        const float *xr = ACT + (pj < R ? pj : R - 1) * LDC + 32 * pu;
-                        const float *wr = W3R + 32 * pu;
+                    {   // thread (segment pj, k-chunk pu): 16 terms of this half of logit[f3row][pj]
+                        const int k0 = 256 * f3half + 16 * pu;
+                        const float *xr = ACT + (pj < R ? pj : R - 1) * LDC + k0;
+                        const float *wr = W3R + k0;
                         float s = 0.f;
 #pragma unroll
-                        for (int k = 0; k < 32; k += 4) {
+                        for (int k = 0; k < 16; k += 4) {
                             const float4 x4 = *reinterpret_cast<const float4 *>(xr + k);
                             const float4 w4 = *reinterpret_cast<const float4 *>(wr + k);
                             s = fmaf(w4.x, x4.x, s); s = fmaf(w4.y, x4.y, s); s = fmaf(w4.z, x4.z, s); s = fmaf(w4.w, x4.w, s);
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                         float s = SCR[tid];
 #pragma unroll
                         for (int kc = 1; kc < 16; ++kc) s += SCR[kc * SEG + tid];
-                        publish(G5, tag, tid, wg, s + b3);
+                        publish(G5, tag, tid, 2 * f3row + f3half, s + b3);   // granule pair (2 row, 2 row + 1) = the two halves
                     }
                     PH(9);
                 }
@@ -403,29 +405,32 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                 const float nz0 = nrow[(b0 + puc) * 10 + (pj < 10 ? pj : 9)];
                 const float nz1 = nrow[10 * Btot + b0 + puc];
                 PH(10);
-                // gather the 30 logits of every segment: thread (segment er, c = ec < 15) reads logits 2c, 2c+1
+                // gather the 30 logits of every segment: granule pair c = (k < 256 partial + bias, k >= 256 partial) of row c;
+                // thread (segment er, ec) reads rows ec and ec + 16
                 {
                     bool ok = true;
-                    if (er < nb && ec < 15) {
-                        const int voff = er * (H * 8) + ec * 16;
+                    if (er < nb) {
                         const int soff = soff_cl + i * SLOT_BYTES + 4 * LAYER_BYTES;
-                        unsigned spins = 0;
-                        u32x4 x;
-                        for (;;) {
-                            x = __builtin_amdgcn_raw_buffer_load_b128(grs, voff, soff, 16 /* sc1 */);
-                            if (x.y == tag && x.w == tag) break;
-                            ++spins;
-                            if ((spins & 255u) == 0u) {
-                                if (spins > SPIN_LIMIT || ld_agent32(a.status) != 0u) { ok = false; break; }
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const int c = ec + 16 * h2;
+                            if (c < 30 && ok) {
+                                const int voff = er * (H * 8) + c * 16;
+                                unsigned spins = 0;
+                                u32x4 x;
+                                for (;;) {
+                                    x = __builtin_amdgcn_raw_buffer_load_b128(grs, voff, soff, 16 /* sc1 */);
+                                    if (x.y == tag && x.w == tag) break;
+                                    ++spins;
+                                    if ((spins & 255u) == 0u) {
+                                        if (spins > SPIN_LIMIT || ld_agent32(a.status) != 0u) { ok = false; break; }
+                                    }
+                                    __builtin_amdgcn_s_sleep(1);
+                                }
+                                const float lg = __uint_as_float(x.x) + __uint_as_float(x.z);
+                                LOG[er * 32 + c] = lg;
+                                if (a.dbg_logits && wg == 0 && ok) a.dbg_logits[((size_t)t * Btot + b0 + er) * C + c] = lg;
                             }
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                        const float l0 = __uint_as_float(x.x), l1 = __uint_as_float(x.z);
-                        LOG[er * 32 + 2 * ec] = l0;
-                        LOG[er * 32 + 2 * ec + 1] = l1;
-                        if (a.dbg_logits && wg == 0 && ok) {
-                            a.dbg_logits[((size_t)t * Btot + b0 + er) * C + 2 * ec] = l0;
-                            a.dbg_logits[((size_t)t * Btot + b0 + er) * C + 2 * ec + 1] = l1;
                         }
                     }
                     if (!ok) report_failure(a.status, 0x300u | 5u, blockIdx.x, t, tid);

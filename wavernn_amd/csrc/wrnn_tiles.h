@@ -227,4 +227,33 @@ __device__ __forceinline__ bool sweep_stream(__amdgpu_buffer_rsrc_t rs, int soff
     return true;
 }
 
+
+// Half-row sweep: the 8 pieces [8*half, 8*half+8) of every row (k in [256*half, 256*half+256)), one pass of 8 loads.
+__device__ __forceinline__ bool sweep_half(__amdgpu_buffer_rsrc_t rs, int soff, unsigned tag, int nb, int tid, float *dst,
+                                           int half, unsigned *status)
+{
+    const int r = tid >> 4, c = tid & 15;
+    if (r >= nb) return true;
+    const int voff = r * (H * 8) + c * 16 + half * 8 * 256;
+    unsigned spins = 0;
+    u32x4 x[8];
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * 256, soff, 16 /* sc1 */);
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ok &= (x[i].y == tag) & (x[i].w == tag);
+        if (ok) break;
+        ++spins;
+        if ((spins & 255u) == 0u) {
+            if (spins > SPIN_LIMIT || ld_agent32(status) != 0u) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<float2 *>(dst + r * LDC + own_col(8 * half + i, c)) = make_float2(__uint_as_float(x[i].x), __uint_as_float(x[i].z));
+    return true;
+}
+
 }  // namespace wrnn
