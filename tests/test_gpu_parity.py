@@ -356,6 +356,41 @@ def test_generate_corpus_equals_per_utterance_generate(gpu, mode, tmp_path):
             assert np.abs(outs[u] - one).max() <= MOL_TOL
 
 
+def test_config4_corpus_size_on_one_gpu(gpu):
+    """BASELINE config 4's corpus (64 utterances, 300-900 frames, ~479 s of audio -> 942 folded segments x 12,100 steps)
+    as ONE launch on one GPU: size-independent properties only -- it completes (no bounded spin gives up), every
+    waveform has the reference's length, samples stay in [-1, 1], the silenced head (A.5 quirk 1) is zero, the run is
+    deterministic for a fixed device seed."""
+    from wavernn_amd.batch import generate_corpus, plan_utterances
+    from wavernn_amd.model import WaveRNN
+    from wavernn_amd.synthetic import random_state_dict, random_mel, SHIPPED
+    sd = random_state_dict(0, mode='MOL')
+    model = WaveRNN(**SHIPPED, mode='MOL')
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(gpu)
+    lens = np.random.RandomState(2024).randint(300, 901, 64)
+    mels = [torch.from_numpy(random_mel(1000 + u, int(n))).unsqueeze(0).to(gpu) for u, n in enumerate(lens)]
+    plan = plan_utterances([int(n) * 275 for n in lens], 11000, 550)
+    assert plan.n_segments == 942 and int(lens.sum()) == 38358
+    torch.cuda.manual_seed(77)
+    t0 = __import__('time').perf_counter()
+    outs = generate_corpus(model, mels, 11000, 550, True, noise_source='device')
+    dt = __import__('time').perf_counter() - t0
+    eng = model._loop_engine()
+    total = sum(o.shape[0] for o in outs)
+    print(f'config 4 on one GPU: {plan.n_segments} segments, loop {eng.last_loop_kernel()} split {eng.last_loop_split()} '
+          f'{eng.last_loop_ms():.0f} ms, end to end {dt:.2f} s = {total / dt / 22050:.0f}x real time')
+    for o, n in zip(outs, lens):
+        assert o.dtype == np.float64 and o.shape == ((int(n) - 1) * 275,)
+        assert np.isfinite(o).all() and np.abs(o).max() <= 1.0
+        assert not o[:275].any() and o[275:3000].any()
+    torch.cuda.manual_seed(77)
+    again = generate_corpus(model, mels[:4], 11000, 550, True, noise_source='device')
+    torch.cuda.manual_seed(77)
+    again2 = generate_corpus(model, mels[:4], 11000, 550, True, noise_source='device')
+    assert all(np.array_equal(a, b) for a, b in zip(again, again2))
+
+
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_full_size_properties(gpu, mode):
     """BASELINE config 2 geometry (B=12, T=12100): cluster and stream kernels agree, runs are deterministic,
