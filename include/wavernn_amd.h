@@ -193,6 +193,20 @@ int wrnn_pre_upsample(const wrnn_pre *p, const float *mel, int32_t n_frames, flo
                       void *workspace, size_t workspace_bytes, void *stream);
 const char *wrnn_pre_last_error(void);
 
+/*
+ * Post-loop stage on the device, float64 like the reference: `.astype(np.float64)` (:245), `decode_mu_law` (utils/dsp.py:
+ * 98-103; `lut` = the expansion of every class value, computed by the caller with the reference's numpy expression, or NULL
+ * for MOL / mu_law off), `xfade_and_unfold` (:342-405; `fade_in` / `fade_out` = its two overlap-long float64 ramps) and the
+ * truncation + tail fade of :255-258 (`tail` = linspace(1, 0, 20*hop)).  Utterance u owns segments
+ * [first[u], first[u]+folds[u]) of `segments` [n][T] and writes out[out_off[u] .. out_off[u+1]) (= wave_len_u samples).
+ * All pointers are DEVICE pointers.  batched = 0: one segment per utterance, no cross-fade.  Asynchronous on `stream`.
+ */
+int wrnn_post_unfold(const float *segments, int32_t T, int32_t n_utt, const int32_t *first, const int32_t *folds,
+                     const int64_t *out_off, const double *lut, int32_t n_classes, const double *fade_in,
+                     const double *fade_out, int32_t overlap, const double *tail, int32_t tail_len, int32_t batched,
+                     double *out, void *stream);
+const char *wrnn_post_last_error(void);
+
 /* Profiling builds (environment WRNN_PROF=1 at wrnn_generate time, pipelined kernel): copies the per-workgroup phase
  * clocks [256 workgroups][16 phases] (shader cycles summed over the launch; phases listed in wrnn_pipe.hip) to `out`.
  * Synchronises `stream`.  Returns the number of words copied or a negative error. */

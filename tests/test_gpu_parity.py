@@ -171,6 +171,42 @@ def test_pre_loop_kernels_match_reference_golden(gpu, name):
     np.testing.assert_allclose(aux.cpu().numpy()[rows], g['aux_up_strided'], rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize('mode,mu_law,batched', [('RAW', True, True), ('RAW', False, True), ('MOL', False, True), ('RAW', True, False)])
+def test_post_loop_kernel_is_bit_exact(gpu, mode, mu_law, batched):
+    """`wrnn_post_unfold` (float64 gather cast, mu-law table, cross-fade + overlap-add, tail fade on the device) ==
+    the numpy helpers of fold.py (which test_host_logic.py pins to the reference's waveforms), bit for bit."""
+    from wavernn_amd import fold as F
+    from wavernn_amd.batch import plan_utterances
+    from wavernn_amd.post import unfold_on_device
+    rs = np.random.RandomState(7)
+    hop, target, overlap, C = 275, 1100, 55, 512
+    frames = [21, 33, 64] if batched else [24]
+    if batched:
+        plan = plan_utterances([n * hop for n in frames], target, overlap)
+        first, folds, T = plan.first, plan.folds, plan.T
+    else:
+        first, folds, T = np.array([0]), np.array([1]), frames[0] * hop
+    n = int(folds.sum())
+    if mode == 'RAW':
+        idx = rs.randint(0, C, size=(n, T)).astype(np.float32)
+        seg = (np.float32(2.0) * idx / np.float32(C - 1) - np.float32(1.0)).astype(np.float32)
+    else:
+        seg = rs.uniform(-1, 1, size=(n, T)).astype(np.float32)
+    wave_lens = [(f - 1) * hop for f in frames]
+    wav, sl = unfold_on_device(torch.from_numpy(seg).to(gpu), first, folds, wave_lens, overlap, hop, C if mode == 'RAW' else 30,
+                               mu_law, batched)
+    wav = wav.cpu().numpy()
+    for u, (a, b) in enumerate(sl):
+        y = seg[int(first[u]):int(first[u]) + int(folds[u])].astype(np.float64)
+        if mu_law:
+            y = F.decode_mu_law(y, C, False)
+        y = F.xfade_and_unfold(y, target, overlap) if batched else y[0]
+        ref = F.finish_waveform(y, wave_lens[u], hop)
+        assert np.array_equal(wav[a:b], ref), (u, np.abs(wav[a:b] - ref).max())
+    with pytest.raises(ValueError):                                    # reference quirk: wave_len < 20*hop (:258)
+        unfold_on_device(torch.from_numpy(seg).to(gpu), first[:1], folds[:1], [19 * hop], overlap, hop, 30, False, batched)
+
+
 @pytest.mark.parametrize('pre', ['native', 'torch'])
 @pytest.mark.parametrize('name', CASES)
 def test_generate_end_to_end(gpu, name, pre, tmp_path):
@@ -184,6 +220,7 @@ def test_generate_end_to_end(gpu, name, pre, tmp_path):
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
     model = model.to(gpu)
     model.pre_algo = pre
+    model.post_algo = 'native' if pre == 'native' else 'numpy'         # all-HIP path vs PyTorch/numpy around the HIP loop
     mel = random_mel(cfg['mseed'], cfg['frames'])
     torch.manual_seed(cfg['seed'])
     wav = tmp_path / 'o.wav'

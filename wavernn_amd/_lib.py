@@ -21,7 +21,8 @@ EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_
            'wrnn_pack_weight_bytes', 'wrnn_workspace_bytes', 'wrnn_workspace_bytes_segments', 'wrnn_generate',
            'wrnn_generate_segments', 'wrnn_status', 'wrnn_last_loop_ms', 'wrnn_last_loop_kernel',
            'wrnn_last_loop_split', 'wrnn_profile_read', 'wrnn_selftest', 'wrnn_selftest_metric', 'wrnn_pre_create',
-           'wrnn_pre_destroy', 'wrnn_pre_hop', 'wrnn_pre_workspace_bytes', 'wrnn_pre_upsample', 'wrnn_pre_last_error']
+           'wrnn_pre_destroy', 'wrnn_pre_hop', 'wrnn_pre_workspace_bytes', 'wrnn_pre_upsample', 'wrnn_pre_last_error',
+           'wrnn_post_unfold', 'wrnn_post_last_error']
 
 
 class Weights(ctypes.Structure):
@@ -106,6 +107,10 @@ def lib():
     L.wrnn_pre_upsample.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.wrnn_pre_last_error.restype = ctypes.c_char_p
+    L.wrnn_post_unfold.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                   ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    L.wrnn_post_last_error.restype = ctypes.c_char_p
     L.wrnn_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.wrnn_status.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.wrnn_last_loop_ms.argtypes = [ctypes.c_void_p]

@@ -175,11 +175,23 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
         segs = torch.cat(parts)
     else:
         segs = out_local[:plan.n_segments]
-    segs = segs.cpu().numpy().astype(np.float64)
     if was_training:
         model.train()
     if return_segments:
-        return segs, plan
+        return segs.cpu().numpy().astype(np.float64), plan
+    if loop_fn is None and getattr(model, 'post_algo', 'numpy') == 'native' and segs.is_cuda:
+        # post-loop on the device (float64, reference order): one launch for every utterance this rank finishes
+        from .post import unfold_on_device
+        mine_u = [u for u in range(len(frames)) if finish != 'own' or (lo <= plan.first[u] < hi)]
+        outs = [None] * len(frames)
+        if mine_u:
+            wav, sl = unfold_on_device(segs, [int(plan.first[u]) for u in mine_u], [int(plan.folds[u]) for u in mine_u],
+                                       [(frames[u] - 1) * hop for u in mine_u], overlap, hop, model.n_classes, mu_law, True)
+            wav = wav.cpu().numpy()
+            for (a, b), u in zip(sl, mine_u):
+                outs[u] = wav[a:b]
+        return outs
+    segs = segs.cpu().numpy().astype(np.float64)
     outs = []
     for u, n in enumerate(frames):
         if finish == 'own' and not (lo <= plan.first[u] < hi):

@@ -131,6 +131,9 @@ class WaveRNN(nn.Module):
         #: 'native' = the HIP pre-loop kernels (MFMA MelResNet + box-filter up-sampling, wrnn_pre_*);
         #: 'torch' = the nn.Modules below through PyTorch-ROCm (MIOpen)
         self.pre_algo = 'native'
+        #: 'native' = cross-fade / unfold / mu-law / tail fade on the device in float64 (wrnn_post_unfold);
+        #: 'numpy' = the host helpers of fold.py
+        self.post_algo = 'native'
         self._engine = None
         self._engine_key = None
         self._pre = None
@@ -217,14 +220,19 @@ class WaveRNN(nn.Module):
             self.last_loop_ms = eng.last_loop_ms()
             self.last_loop_kernel = eng.last_loop_kernel()
 
-        output = out.cpu().numpy().astype(np.float64)
-        if mu_law:
-            output = _fold.decode_mu_law(output, self.n_classes, False)
-        if batched:
-            output = _fold.xfade_and_unfold(output, target, overlap)
+        if self.post_algo == 'native':
+            from .post import unfold_on_device
+            wav, _ = unfold_on_device(out, [0], [B], [wave_len], overlap, self.hop_length, self.n_classes, mu_law, batched)
+            output = wav.cpu().numpy()
         else:
-            output = output[0]
-        output = _fold.finish_waveform(output, wave_len, self.hop_length)
+            output = out.cpu().numpy().astype(np.float64)
+            if mu_law:
+                output = _fold.decode_mu_law(output, self.n_classes, False)
+            if batched:
+                output = _fold.xfade_and_unfold(output, target, overlap)
+            else:
+                output = output[0]
+            output = _fold.finish_waveform(output, wave_len, self.hop_length)
         save_wav(output, save_path, self.sample_rate)
         self.train()
         return output
