@@ -319,6 +319,22 @@ def test_segment_table_several_utterances(gpu, variant, monkeypatch):
         assert np.abs(got - ref).max() <= MOL_TOL, (u, np.abs(got - ref).max())
 
 
+def test_hoisted_conditioning_mfma_equals_valu(gpu, monkeypatch):
+    """The MFMA form of the hoisted I-layer conditioning (cI) is bitwise the VALU fmaf chain: same loop output, bit for
+    bit, in RAW and MoL (one accumulator chain per tile in ascending k; v_mfma_f32_16x16x4_f32 == 4 chained fmas)."""
+    from wavernn_amd.engine import LoopEngine
+    for mode in ('RAW', 'MOL'):
+        cfg = dict(mode=mode, wseed=34, mseed=134, frames=60, batched=True, target=1100, overlap=55, seed=94)
+        sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
+        eng = LoopEngine(sd, mode, device=gpu)
+        args = (torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride, torch.from_numpy(flat).to(gpu), 275)
+        monkeypatch.setenv('WRNN_COND', 'valu')
+        a = eng.run(*args, algo='cluster').cpu().numpy()
+        monkeypatch.delenv('WRNN_COND')
+        b = eng.run(*args, algo='cluster').cpu().numpy()
+        assert np.array_equal(a, b), (mode, np.abs(a - b).max())
+
+
 @pytest.mark.parametrize('mode,variant', [('MOL', 'auto'), ('RAW', 'auto'), ('MOL', 'pipe-g2')])
 def test_block_sparse_gru_weights(gpu, mode, variant, monkeypatch):
     """BASELINE config 5: the GRU matrices block-pruned to 95 % zeros (16x1 blocks, per gate) run through the dense HIP

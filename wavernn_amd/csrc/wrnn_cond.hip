@@ -9,6 +9,9 @@
 // aux is constant over a mel frame (Stretch2d, :57-61,:84), so c2f/c3f/c4f are frame tables; row NF is the
 // zero-conditioning row the fold's zero padding selects (:326-330).  The fold itself (:336-338) is never
 // materialised: segment b, step t reads position p = seg_pos[b] + t (see LoopArgs).
+#include <stdlib.h>
+#include <string.h>
+
 #include "wrnn_device.h"
 
 namespace wrnn {
@@ -53,6 +56,71 @@ __global__ __launch_bounds__(H) void wrnn_cond_sample_kernel(const CondArgs a)
                 acc = fmaf(wreg[k + 3], x.w, acc);
             }
             if (base + rr < rows) a.cI[(size_t)(base + rr) * H + r] = acc + bias;
+        }
+    }
+}
+
+
+// MFMA form of the same product: one workgroup keeps ALL of I.weight[:,1:] (512 x 112) in registers as A fragments
+// (wave w owns output rows [128w, 128w+128) = 8 row tiles x 7 k-blocks x 4 = 224 registers) and grid-strides over tiles of
+// 16 (t, segment) rows staged in LDS.  One accumulator chain per row tile in ascending k, bias added last: bitwise the
+// fmaf chain of wrnn_cond_sample_kernel (v_mfma_f32_16x16x4_f32 == 4 chained fmas), at the MFMA rate.
+constexpr int CKB = KCOND / 16;        // 7 k-blocks of 16
+constexpr int CLD = KCOND + 4;         // LDS row stride (116 floats, 16-B aligned rows)
+__global__ __launch_bounds__(256, 1) void wrnn_cond_mfma_kernel(const CondArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float in[16 * CLD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fi = lane & 15, kq = lane >> 4;
+    float A[8][4 * CKB];
+    float4 bias[8];
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+        const int row = 128 * w + 16 * tt + fi;
+#pragma unroll
+        for (int r = 0; r < CKB; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) A[tt][4 * r + e] = a.I_cT[(size_t)(16 * r + 4 * kq + e) * H + row];
+        bias[tt] = *reinterpret_cast<const float4 *>(a.I_b + 128 * w + 16 * tt + 4 * kq);
+    }
+    const long rows = (long)a.T * a.B;
+    for (long base = (long)blockIdx.x * 16; base < rows; base += (long)gridDim.x * 16) {
+        __syncthreads();
+        for (int q = tid; q < 16 * KCOND; q += 256) {
+            const int rr = q / KCOND, k = q % KCOND;
+            const long row = base + rr;
+            float val = 0.f;
+            if (row < rows) {
+                const int t = (int)(row / a.B), b = (int)(row % a.B);
+                const int p = a.seg_pos[b] + t;
+                if (p < a.seg_lim[b]) val = (k < MEL) ? a.mels_up[(size_t)p * MEL + k] : a.aux[(size_t)(p / a.hop) * 4 * AUX + (k - MEL)];
+            }
+            in[rr * CLD + k] = val;
+        }
+        __syncthreads();
+        float4 bf[CKB];
+#pragma unroll
+        for (int r = 0; r < CKB; ++r) bf[r] = *reinterpret_cast<const float4 *>(in + fi * CLD + 16 * r + 4 * kq);
+        f32x4 acc[8];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < CKB; ++r) {
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt][4 * r + 0], bf[r].x, acc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt][4 * r + 1], bf[r].y, acc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt][4 * r + 2], bf[r].z, acc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt][4 * r + 3], bf[r].w, acc[tt], 0, 0, 0);
+        }
+        if (base + fi < rows) {
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                const float4 o = make_float4(acc[tt][0] + bias[tt].x, acc[tt][1] + bias[tt].y, acc[tt][2] + bias[tt].z, acc[tt][3] + bias[tt].w);
+                *reinterpret_cast<float4 *>(a.cI + (size_t)(base + fi) * H + 128 * w + 16 * tt + 4 * kq) = o;
+            }
         }
     }
 }
@@ -106,11 +174,19 @@ hipError_t launch_cond(const CondArgs &a, int n_cus, hipStream_t stream)
 {
     hipLaunchKernelGGL(wrnn_cond_frame_kernel, dim3(a.NF + 1), dim3(H), 0, stream, a);
     const long rows = (long)a.T * a.B;
-    long blocks = (rows + CR - 1) / CR;
-    const long cap = (long)n_cus * 4;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(wrnn_cond_sample_kernel, dim3((unsigned)blocks), dim3(H), 0, stream, a);
+    const char *env = getenv("WRNN_COND");
+    if (env && strcmp(env, "valu") == 0) {                    // the VALU form, kept as the on-GPU cross-check
+        long blocks = (rows + CR - 1) / CR;
+        const long cap = (long)n_cus * 4;
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(wrnn_cond_sample_kernel, dim3((unsigned)blocks), dim3(H), 0, stream, a);
+    } else {
+        long blocks = (rows + 15) / 16;
+        if (blocks > n_cus) blocks = n_cus;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(wrnn_cond_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    }
     return hipGetLastError();
 }
 
