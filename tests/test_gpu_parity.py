@@ -320,8 +320,8 @@ def test_segment_table_several_utterances(gpu, variant, monkeypatch):
 
 
 def test_hoisted_conditioning_mfma_equals_valu(gpu, monkeypatch):
-    """The MFMA form of the hoisted I-layer conditioning (cI) is bitwise the VALU fmaf chain: same loop output, bit for
-    bit, in RAW and MoL (one accumulator chain per tile in ascending k; v_mfma_f32_16x16x4_f32 == 4 chained fmas)."""
+    """The MFMA form of the hoisted I-layer conditioning (cI) against the VALU fmaf chain it replaced: identical class
+    indices in RAW, MoL samples within MOL_TOL (the MFMA's 4-term inner sum rounds differently from four chained fmas)."""
     from wavernn_amd.engine import LoopEngine
     for mode in ('RAW', 'MOL'):
         cfg = dict(mode=mode, wseed=34, mseed=134, frames=60, batched=True, target=1100, overlap=55, seed=94)
@@ -332,7 +332,10 @@ def test_hoisted_conditioning_mfma_equals_valu(gpu, monkeypatch):
         a = eng.run(*args, algo='cluster').cpu().numpy()
         monkeypatch.delenv('WRNN_COND')
         b = eng.run(*args, algo='cluster').cpu().numpy()
-        assert np.array_equal(a, b), (mode, np.abs(a - b).max())
+        if mode == 'RAW':
+            assert np.array_equal(a, b), np.abs(a - b).max()
+        else:
+            assert np.abs(a - b).max() <= MOL_TOL, np.abs(a - b).max()
 
 
 @pytest.mark.parametrize('mode,variant', [('MOL', 'auto'), ('RAW', 'auto'), ('MOL', 'pipe-g2')])

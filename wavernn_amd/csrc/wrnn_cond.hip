@@ -63,8 +63,9 @@ __global__ __launch_bounds__(H) void wrnn_cond_sample_kernel(const CondArgs a)
 
 // MFMA form of the same product: one workgroup keeps ALL of I.weight[:,1:] (512 x 112) in registers as A fragments
 // (wave w owns output rows [128w, 128w+128) = 8 row tiles x 7 k-blocks x 4 = 224 registers) and grid-strides over tiles of
-// 16 (t, segment) rows staged in LDS.  One accumulator chain per row tile in ascending k, bias added last: bitwise the
-// fmaf chain of wrnn_cond_sample_kernel (v_mfma_f32_16x16x4_f32 == 4 chained fmas), at the MFMA rate.
+// 16 (t, segment) rows staged in LDS.  One accumulator chain per row tile in ascending k, bias added last -- the same
+// order as wrnn_cond_sample_kernel's fmaf chain up to the rounding inside each 4-term MFMA step (measured: RAW class
+// indices identical, MoL samples within 1e-5; tests/test_gpu_parity.py), at the MFMA rate.
 constexpr int CKB = KCOND / 16;        // 7 k-blocks of 16
 constexpr int CLD = KCOND + 4;         // LDS row stride (116 floats, 16-B aligned rows)
 __global__ __launch_bounds__(256, 1) void wrnn_cond_mfma_kernel(const CondArgs a)
