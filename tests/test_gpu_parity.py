@@ -447,6 +447,32 @@ def test_config4_corpus_size_on_one_gpu(gpu):
     assert all(np.array_equal(a, b) for a, b in zip(again, again2))
 
 
+def test_full_size_pipelined_kernel_vs_stream(gpu, monkeypatch):
+    """Bench geometry (128 segments x 12,100 steps, MoL): the pipelined kernel (auto pick) agrees with the stream kernel
+    (no inter-workgroup traffic at all) within MOL_TOL over the whole free run, and is deterministic."""
+    from wavernn_amd.engine import LoopEngine
+    from wavernn_amd.synthetic import random_state_dict
+    for k in ENV_KEYS:
+        monkeypatch.delenv(k, raising=False)
+    sd = random_state_dict(0, mode='MOL')
+    rs = np.random.RandomState(4)
+    hop, target, overlap, B = 275, 11000, 550, 128
+    T, stride = target + 2 * overlap, 1000
+    L = ((B * stride + T) // hop + 1) * hop
+    mels_up = torch.from_numpy(rs.uniform(0, 1, (L, 80)).astype(np.float32)).to(gpu)
+    aux = torch.from_numpy(rs.uniform(-1, 1, (L // hop, 128)).astype(np.float32)).to(gpu)
+    noise = torch.empty(T, 11 * B).uniform_(1e-5, 1 - 1e-5, generator=torch.Generator().manual_seed(6)).to(gpu)
+    eng = LoopEngine(sd, 'MOL', device=gpu)
+    a = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='auto').cpu().numpy()
+    assert eng.last_loop_kernel() == 'wrnn_pipe_kernel' and eng.last_loop_split() == (8, 4, 2)
+    ms = eng.last_loop_ms()
+    b = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='auto').cpu().numpy()
+    s = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='stream').cpu().numpy()
+    print(f'pipelined loop {ms:.1f} ms for {B}x{T} segment-steps ({B * T / ms / 1e3:.2f} M/s); stream {eng.last_loop_ms():.1f} ms')
+    assert np.array_equal(a, b), 'pipelined kernel is not deterministic'
+    assert np.abs(a).max() <= 1.0 and np.abs(a - s).max() <= MOL_TOL, np.abs(a - s).max()
+
+
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_full_size_properties(gpu, mode):
     """BASELINE config 2 geometry (B=12, T=12100): cluster and stream kernels agree, runs are deterministic,
