@@ -47,8 +47,10 @@ enum {
     WRNN_ALGO_PERSIST = 2,  /* chip-wide persistent kernel: one cooperative launch per group of <= 16 segments */
     WRNN_ALGO_CLUSTER = 3,  /* clustered persistent kernel: 1, 2 or 4 independent CU clusters, each with a full
                                on-chip copy of the weights, all groups of <= 16 segments in ONE launch */
-    WRNN_ALGO_PIPE = 4      /* pipelined clustered kernel (MOL): 4 clusters x up to 3 groups in flight per cluster,
+    WRNN_ALGO_PIPE = 4,     /* pipelined clustered kernel (MOL): 4 clusters x up to 3 groups in flight per cluster,
                                interleaved stage by stage so the inter-CU exchange latency hides behind MFMA work */
+    WRNN_ALGO_SPARSE = 5    /* block-sparse GRU kernel (MOL; BASELINE config 5): needs GRU matrices whose 16x1 block rows
+                               keep <= 64 columns (wrnn_pack_sparse_blocks); 8 XCD-local clusters x 2 groups in flight */
 };
 
 /*
@@ -107,6 +109,9 @@ int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **out);
 void wrnn_pack_destroy(wrnn_pack *p);
 /* bytes of loop weights the reference streams per step (the W of SURVEY.md section 8d) */
 size_t wrnn_pack_weight_bytes(const wrnn_pack *p);
+/* block sparsity of the pack's GRU matrices: the largest number of non-zero 16x1 blocks in any (matrix, gate, 16-row) block
+ * row -- positive when WRNN_ALGO_SPARSE can run this pack (<= 64, MOL), negated when it cannot */
+int wrnn_pack_sparse_blocks(const wrnn_pack *p);
 
 /* Workspace (device bytes) wrnn_generate needs for this geometry. */
 size_t wrnn_workspace_bytes(const wrnn_pack *p, const wrnn_geometry *g);

@@ -15,6 +15,7 @@ from wavernn_amd.synthetic import random_state_dict
 ap = argparse.ArgumentParser()
 ap.add_argument('--T', type=int, default=1500)
 ap.add_argument('--mode', default='MOL')
+ap.add_argument('--prune', type=float, default=0.0, help='block-prune the GRU matrices to this sparsity (config 5)')
 ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'probe.json'))
 ap.add_argument('--B', default='12,64,120,128,180,192,256,360')
 ap.add_argument('--variants', default='u8,p2,p3,auto')
@@ -23,12 +24,16 @@ args = ap.parse_args()
 dev = torch.device('cuda', 0)
 mode, T, hop = args.mode, args.T, 275
 sd = random_state_dict(0, mode=mode)
+if args.prune > 0:
+    from wavernn_amd.prune import block_prune_state_dict
+    sd, _ = block_prune_state_dict(sd, args.prune, (16, 1))
 eng = LoopEngine(sd, mode, device=dev)
 rs = np.random.RandomState(3)
 VARS = {'persist': ('persist', {}), 'u2': ('cluster', {'WRNN_CLUSTER_U': '2'}), 'u4': ('cluster', {'WRNN_CLUSTER_U': '4'}),
         'u8': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '8'}),
         'u8nl16': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '16'}), 'auto': ('auto', {}),
         'p1': ('pipe', {'WRNN_PIPE_G': '1'}), 'p2': ('pipe', {'WRNN_PIPE_G': '2'}), 'p3': ('pipe', {'WRNN_PIPE_G': '3'}),
+        's1': ('sparse', {'WRNN_SPARSE_G': '1'}), 's2': ('sparse', {'WRNN_SPARSE_G': '2'}),
         'p3nl8': ('pipe', {'WRNN_PIPE_G': '3', 'WRNN_PIPE_NL': '8'}), 'p2nl8': ('pipe', {'WRNN_PIPE_G': '2', 'WRNN_PIPE_NL': '8'})}
 rows = []
 for B in [int(x) for x in args.B.split(',')]:
@@ -48,7 +53,7 @@ for B in [int(x) for x in args.B.split(',')]:
             continue
         if v == 'persist' and B > 64:
             continue
-        for k in ('WRNN_CLUSTER_U', 'WRNN_CLUSTER_NL', 'WRNN_PIPE_G', 'WRNN_PIPE_NL'):
+        for k in ('WRNN_CLUSTER_U', 'WRNN_CLUSTER_NL', 'WRNN_PIPE_G', 'WRNN_PIPE_NL', 'WRNN_SPARSE_G'):
             os.environ.pop(k, None)
         os.environ.update(env)
         try:
@@ -60,7 +65,7 @@ for B in [int(x) for x in args.B.split(',')]:
                 ref = o
             err = float(np.abs(o - ref).max())
             u, ncl, gdepth = eng.last_loop_split()
-            rows_g = 15 if gdepth >= 3 else 16
+            rows_g = 15 if (gdepth >= 3 and algo != 'sparse') else 16
             groups = -(-B // rows_g)
             rounds = groups if algo == 'persist' else max(1, -(-groups // max(ncl * max(gdepth, 1), 1)))
             row = dict(variant=v, B=B, T=T, ms=round(ms, 3), us_per_round_step=round(ms * 1e3 / (T * rounds), 3),

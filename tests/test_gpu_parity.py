@@ -58,7 +58,7 @@ VARIANTS = {
 }
 KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'persist': 'wrnn_persist_kernel', 'cluster': 'wrnn_cluster_kernel',
                'pipe': 'wrnn_pipe_kernel'}
-ENV_KEYS = ('WRNN_CLUSTER_U', 'WRNN_CLUSTER_NL', 'WRNN_PIPE_G', 'WRNN_PIPE_NL')
+ENV_KEYS = ('WRNN_CLUSTER_U', 'WRNN_CLUSTER_NL', 'WRNN_PIPE_G', 'WRNN_PIPE_NL', 'WRNN_SPARSE_G', 'WRNN_COND')
 
 
 def _mol_only(variant):
@@ -368,6 +368,35 @@ def test_block_sparse_gru_weights(gpu, mode, variant, monkeypatch):
         assert bad.size == 0, f'first divergence at (b,t)={bad[0]}'
     else:
         assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
+
+
+@pytest.mark.parametrize('frames,target,overlap,g', [(100, 550, 55, 0), (100, 220, 22, 1), (100, 220, 22, 2), (300, 220, 22, 0)])
+def test_block_sparse_kernel_matches_oracle(gpu, frames, target, overlap, g, monkeypatch):
+    """`WRNN_ALGO_SPARSE` (packed 16x1 blocks, gathered B fragments, 8 XCD-local clusters) on 95 %-pruned GRU weights vs the
+    C oracle running the same weights as masked dense matrices: 46 / 114 / 341 segments (one and two rounds, one and two
+    groups in flight).  MoL tolerance (the surviving terms are summed in a different order)."""
+    from oracle import c_oracle as C, wavernn_oracle as O
+    from wavernn_amd.engine import LoopEngine
+    from wavernn_amd.prune import block_prune_state_dict
+    for k in ENV_KEYS:
+        monkeypatch.delenv(k, raising=False)
+    if g:
+        monkeypatch.setenv('WRNN_SPARSE_G', str(g))
+    cfg = dict(mode='MOL', wseed=35, mseed=135, frames=frames, batched=True, target=target, overlap=overlap, seed=95)
+    sd0, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
+    sd, _ = block_prune_state_dict(sd0, 0.95, (16, 1))
+    mels_f, aux_f, _ = O.conditioning(sd, mel, True, target, overlap)
+    ref = C.loop(sd, 'MOL', mels_f, aux_f, noise)
+    eng = LoopEngine(sd, 'MOL', device=gpu)
+    assert 0 < eng.sparse_blocks <= 64
+    dense = LoopEngine(sd0, 'MOL', device=gpu)
+    assert dense.sparse_blocks == -512
+    with pytest.raises(Exception):
+        dense.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride, torch.from_numpy(flat).to(gpu), 275, algo='sparse')
+    out = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
+                  torch.from_numpy(flat).to(gpu), 275, algo='sparse').cpu().numpy()
+    assert eng.last_loop_kernel() == 'wrnn_sparse_kernel' and eng.last_loop_split()[:2] == (16, 8)
+    assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
 
 
 def test_config1_raw_unbatched_one_second(gpu, tmp_path):

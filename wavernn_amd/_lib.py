@@ -13,12 +13,13 @@ SO_PATH = os.path.join(CSRC, 'libwavernn_amd.so')
 
 WRNN_OK = 0
 MODE_RAW, MODE_MOL = 0, 1
-ALGO_AUTO, ALGO_STREAM, ALGO_PERSIST, ALGO_CLUSTER, ALGO_PIPE = 0, 1, 2, 3, 4
-ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'persist': ALGO_PERSIST, 'cluster': ALGO_CLUSTER, 'pipe': ALGO_PIPE}
+ALGO_AUTO, ALGO_STREAM, ALGO_PERSIST, ALGO_CLUSTER, ALGO_PIPE, ALGO_SPARSE = 0, 1, 2, 3, 4, 5
+ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'persist': ALGO_PERSIST, 'cluster': ALGO_CLUSTER, 'pipe': ALGO_PIPE,
+         'sparse': ALGO_SPARSE}
 
 #: every symbol include/wavernn_amd.h declares
 EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_create', 'wrnn_pack_destroy',
-           'wrnn_pack_weight_bytes', 'wrnn_workspace_bytes', 'wrnn_workspace_bytes_segments', 'wrnn_generate',
+           'wrnn_pack_weight_bytes', 'wrnn_pack_sparse_blocks', 'wrnn_workspace_bytes', 'wrnn_workspace_bytes_segments', 'wrnn_generate',
            'wrnn_generate_segments', 'wrnn_status', 'wrnn_last_loop_ms', 'wrnn_last_loop_kernel',
            'wrnn_last_loop_split', 'wrnn_profile_read', 'wrnn_selftest', 'wrnn_selftest_metric', 'wrnn_pre_create',
            'wrnn_pre_destroy', 'wrnn_pre_hop', 'wrnn_pre_workspace_bytes', 'wrnn_pre_upsample', 'wrnn_pre_last_error',
@@ -85,6 +86,7 @@ def lib():
     L.wrnn_pack_destroy.restype = None
     L.wrnn_pack_weight_bytes.argtypes = [ctypes.c_void_p]
     L.wrnn_pack_weight_bytes.restype = ctypes.c_size_t
+    L.wrnn_pack_sparse_blocks.argtypes = [ctypes.c_void_p]
     L.wrnn_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.POINTER(Geometry)]
     L.wrnn_workspace_bytes.restype = ctypes.c_size_t
     L.wrnn_generate.argtypes = [ctypes.c_void_p, ctypes.POINTER(Geometry), ctypes.c_void_p, ctypes.c_void_p,

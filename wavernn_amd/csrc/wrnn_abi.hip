@@ -21,6 +21,8 @@ int cluster_count(int U, int n_cus);
 hipError_t launch_pipe(const LoopArgs &args, int G, int ncl, int nl, hipStream_t stream);
 int pipe_rows(int G);
 int pipe_clusters(int n_cus);
+hipError_t launch_sparse(const LoopArgs &args, int G, int ncl, int nbp, hipStream_t stream);
+int sparse_clusters(int n_cus);
 size_t persist_lds_bytes();
 int selftest_mfma(char *msg, size_t n);
 int selftest_allgather(int n_cus, char *msg, size_t n, float *us_per_round);
@@ -59,6 +61,10 @@ struct wrnn_pack {
     bool timed;
     const char *last_kernel;
     int last_U, last_ncl, last_G;
+    int sp_nbp;                // 0 = the GRU matrices are not block-sparse enough for wrnn_sparse_kernel; else 48 / 64
+    int sp_max_blocks;
+    const float *sp_vals;
+    const int *sp_cols;
 };
 
 extern "C" const char *wrnn_last_error(void) { return g_err; }
@@ -138,6 +144,46 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     const size_t o_fc3T = b.add_T(w->fc3_w, C, H, 0, H);
     const size_t o_c2_wT = b.add_T(w->w_ih2, 3 * H, K2, H, AUX);
     const size_t o_c3_wT = b.add_T(w->fc1_w, H, K2, H, AUX), o_c4_wT = b.add_T(w->fc2_w, H, K2, H, AUX);
+    // ---- block-sparse view of the GRU matrices (16x1 blocks: 16 consecutive rows of one gate x 1 column) -----------
+    // usable by wrnn_sparse_kernel when every block row keeps <= 64 columns (~5 % density keeps ~26 +- 5)
+    int sp_nbp = 0, sp_max = 0;
+    size_t o_spv = 0, o_spc = 0;
+    {
+        const float *mats[4] = {w->w_ih1, w->w_hh1, w->w_ih2, w->w_hh2};
+        const int lds_[4] = {H, H, K2, H};
+        std::vector<std::vector<int>> cols((size_t)4 * 32 * 3);
+        for (int m = 0; m < 4; ++m)
+            for (int wg = 0; wg < 32; ++wg)
+                for (int g = 0; g < 3; ++g) {
+                    std::vector<int> &cv = cols[((size_t)m * 32 + wg) * 3 + g];
+                    const float *base = mats[m] + ((size_t)g * H + 16 * wg) * lds_[m];
+                    for (int c = 0; c < H; ++c) {
+                        bool nz = false;
+                        for (int r = 0; r < 16 && !nz; ++r) nz = base[(size_t)r * lds_[m] + c] != 0.0f;
+                        if (nz) cv.push_back(c);
+                    }
+                    if ((int)cv.size() > sp_max) sp_max = (int)cv.size();
+                }
+        if (sp_max <= 64 && w->mode == WRNN_MODE_MOL) {
+            sp_nbp = sp_max <= 48 ? 48 : 64;
+            o_spv = b.add(nullptr, (size_t)4 * 32 * 3 * sp_nbp * 16);
+            o_spc = b.add(nullptr, (size_t)4 * 32 * 3 * sp_nbp);        // ints stored in the float builder (same width)
+            for (size_t q = 0; q < (size_t)4 * 32 * 3 * sp_nbp * 16; ++q) b.host[o_spv + q] = 0.f;
+            int *ci = reinterpret_cast<int *>(b.host.data() + o_spc);
+            for (size_t q = 0; q < (size_t)4 * 32 * 3 * sp_nbp; ++q) ci[q] = 0;
+            for (int m = 0; m < 4; ++m)
+                for (int wg = 0; wg < 32; ++wg)
+                    for (int g = 0; g < 3; ++g) {
+                        const size_t br = ((size_t)m * 32 + wg) * 3 + g;
+                        const std::vector<int> &cv = cols[br];
+                        const float *base = mats[m] + ((size_t)g * H + 16 * wg) * lds_[m];
+                        for (size_t k = 0; k < cv.size(); ++k) {
+                            ci[br * sp_nbp + k] = cv[k];
+                            for (int r = 0; r < 16; ++r) b.host[o_spv + (br * sp_nbp + k) * 16 + r] = base[(size_t)r * lds_[m] + cv[k]];
+                        }
+                    }
+        }
+    }
     b.add(nullptr, 64);   // tail padding so vector loads past the last array stay inside the allocation
 
     wrnn_pack *p = new wrnn_pack();
@@ -159,6 +205,9 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     p->w_ih1T = base + o_w_ih1T; p->w_hh1T = base + o_w_hh1T; p->w_ih2T = base + o_w_ih2T; p->w_hh2T = base + o_w_hh2T;
     p->fc1T = base + o_fc1T; p->fc2T = base + o_fc2T; p->fc3T = base + o_fc3T;
     p->c2_wT = base + o_c2_wT; p->c3_wT = base + o_c3_wT; p->c4_wT = base + o_c4_wT;
+    p->sp_nbp = sp_nbp; p->sp_max_blocks = sp_max;
+    p->sp_vals = sp_nbp ? base + o_spv : nullptr;
+    p->sp_cols = sp_nbp ? reinterpret_cast<const int *>(base + o_spc) : nullptr;
     hipEventCreate(&p->ev0);
     hipEventCreate(&p->ev1);
     p->timed = false;
@@ -178,6 +227,8 @@ extern "C" void wrnn_pack_destroy(wrnn_pack *p)
 }
 
 extern "C" size_t wrnn_pack_weight_bytes(const wrnn_pack *p) { return p ? p->weight_bytes : 0; }
+
+extern "C" int wrnn_pack_sparse_blocks(const wrnn_pack *p) { return p ? (p->sp_nbp ? p->sp_max_blocks : -p->sp_max_blocks) : 0; }
 
 namespace {
 struct WsLayout {
@@ -295,9 +346,29 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
     // cluster: clustered persistent kernel (all groups in one launch); persist: the chip-wide kernel, one launch
     // per 16-segment group; stream: one workgroup per segment.  auto = cluster where the device admits it.
     const bool shape_ok = (p->mode == WRNN_MODE_MOL) || (p->C == H);
-    enum { K_STREAM, K_PERSIST, K_CLUSTER, K_PIPE } kind = K_STREAM;
+    enum { K_STREAM, K_PERSIST, K_CLUSTER, K_PIPE, K_SPARSE } kind = K_STREAM;
     int U = 0, ncl = 0, G = 0;
-    if ((algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_PIPE) && p->mode == WRNN_MODE_MOL) {
+    if (algo == WRNN_ALGO_SPARSE) {
+        const int scl = sparse_clusters(p->n_cus);
+        if (!p->sp_nbp || scl < 1) {
+            set_err("block-sparse kernel needs MOL, >= 32 CUs and GRU matrices with <= 64 surviving 16x1 blocks per block row "
+                    "(this pack: up to %d)", p->sp_max_blocks);
+            return WRNN_ERR_ARG;
+        }
+        const char *envg = getenv("WRNN_SPARSE_G");
+        const int groups = (B + SEG - 1) / SEG;
+        int g = envg ? atoi(envg) : 0;
+        if (g < 1 || g > SPG) g = groups > scl ? 2 : 1;
+        const int rounds = (groups + scl * g - 1) / (scl * g);
+        const long ng = (long)rounds * scl * g;
+        if ((double)rounds * T >= 4.0e9) { set_err("too many steps"); return WRNN_ERR_ARG; }
+        kind = K_SPARSE; G = g; ncl = scl; U = 16;
+        a.NG = ng < B ? (int)ng : B;
+        a.sp_vals = p->sp_vals; a.sp_cols = p->sp_cols;
+    }
+    if (kind == K_SPARSE) {
+        // chosen above
+    } else if ((algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_PIPE) && p->mode == WRNN_MODE_MOL) {
         // Pipelined kernel: G groups in flight per cluster.  Measured step times on MI355X (profiles/r01g_*): single-depth
         // cluster kernel 25 us per round-step, G = 2 33.7 us, G = 3 (15-row groups) 49.2 us.  One launch costs
         // rounds x step: pick the cheapest depth; auto falls back to the cluster kernel when depth 1 wins.
@@ -335,7 +406,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
         set_err("the pipelined kernel exists for MOL only");
         return WRNN_ERR_ARG;
     }
-    if (kind == K_PIPE) {
+    if (kind == K_PIPE || kind == K_SPARSE) {
         // chosen above
     } else if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_CLUSTER) {
         if (shape_ok && (double)a.NG * T < 4.0e9) {
@@ -373,14 +444,24 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
             return WRNN_ERR_RESIDENCY;
         }
         kind = K_PERSIST;
-    } else if (algo != WRNN_ALGO_STREAM && algo != WRNN_ALGO_PIPE) { set_err("unknown algo %d", algo); return WRNN_ERR_ARG; }
+    } else if (algo != WRNN_ALGO_STREAM && algo != WRNN_ALGO_PIPE && algo != WRNN_ALGO_SPARSE) { set_err("unknown algo %d", algo); return WRNN_ERR_ARG; }
 
-    if (kind == K_PIPE) {
+    if (kind == K_PIPE || kind == K_SPARSE) {
         HIPCHK(launch_noise_mol(noise, (float *)(ws + l.npre), (long)T * 11 * B, B, p->n_cus, stream));
         a.noise_pre = (const float *)(ws + l.npre);
     }
     HIPCHK(hipEventRecord(p->ev0, stream));
-    if (kind == K_PIPE) {
+    if (kind == K_SPARSE) {
+        p->last_kernel = "wrnn_sparse_kernel";
+        p->last_U = U; p->last_ncl = ncl; p->last_G = G;
+        HIPCHK(hipMemsetAsync(ws + l.gran, 0, GRAN_BYTES, stream));
+        hipError_t e = launch_sparse(a, G, ncl, p->sp_nbp, stream);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_err("block-sparse cooperative launch failed: %s", hipGetErrorString(e));
+            return e == hipErrorCooperativeLaunchTooLarge ? WRNN_ERR_RESIDENCY : WRNN_ERR_HIP;
+        }
+    } else if (kind == K_PIPE) {
         p->last_kernel = "wrnn_pipe_kernel";
         p->last_U = U; p->last_ncl = ncl; p->last_G = G;
         HIPCHK(hipMemsetAsync(ws + l.gran, 0, GRAN_BYTES, stream));

@@ -20,7 +20,10 @@ constexpr int LDA = 516;      // padded row stride (floats) of the LDS activatio
 constexpr int NGRAN = 5;      // granule buffers: h1, h2, y1, y2, (RAW) logits
 constexpr int MAXCL = 4;      // cluster kernels: at most 4 independent clusters per chip
 constexpr int MAXG = 3;       // pipelined kernel: at most 3 groups in flight per cluster
-constexpr int GRAN_WORDS = MAXCL * MAXG * NGRAN * SEG * H;   // u64 granules in the workspace
+constexpr int SPCL = 8;       // block-sparse kernel: 8 clusters (one per XCD)
+constexpr int SPG = 2;        // ... with up to 2 groups in flight each
+constexpr int GRAN_WORDS = SPCL * SPG * NGRAN * SEG * H;     // u64 granules in the workspace (>= MAXCL * MAXG * ...)
+static_assert(SPCL * SPG >= MAXCL * MAXG, "granule workspace");
 constexpr int STATUS_WORDS = 16;
 constexpr int NPROF = 16;     // phase counters per workgroup (wrnn_pipe.hip PROF builds)
 constexpr int MAXWG = 256;    // workgroups of a persistent launch
@@ -45,6 +48,9 @@ struct LoopArgs {
     const float *c2f, *c3f, *c4f;       // [NF+1][3H], [NF+1][H], [NF+1][H]  per-frame aux projections + bias
     const float *noise;                 // MOL [T][11*Btot]; RAW [T][Btot][C]
     const float *noise_pre;             // MOL, pipelined kernel: [T][11*Btot] derived variates (wrnn_noise_mol_kernel)
+    // block-sparse GRU pack (wrnn_sparse.hip): matrix m in {ih1,hh1,ih2,hh2}, block row (workgroup wg, gate g), NBP padded blocks
+    const float *sp_vals;               // [4][32][3][NBP][16]  block values (16 rows of one column)
+    const int *sp_cols;                 // [4][32][3][NBP]      their column indices (padding: column 0, zero values)
     const float *force_x;               // optional [Btot][T]
     float *out;                         // [Btot][T]
     float *dbg_logits;                  // optional [T][Btot][C]

@@ -62,6 +62,11 @@ class LoopEngine:
             pass
 
     @property
+    def sparse_blocks(self):
+        """> 0: the block-sparse kernel can run this pack (largest block-row population); <= 0: it cannot."""
+        return int(self.lib.wrnn_pack_sparse_blocks(self._pack))
+
+    @property
     def weight_bytes(self):
         return int(self.lib.wrnn_pack_weight_bytes(self._pack))
 
