@@ -76,7 +76,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--utterances', type=int, default=8, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=641, help='mel frames per utterance')
-    ap.add_argument('--algo', default='auto', choices=['auto', 'pipe', 'cluster', 'persist', 'stream'])
+    ap.add_argument('--algo', default='auto', choices=['auto', 'pipe', 'sparse', 'cluster', 'persist', 'stream'])
+    ap.add_argument('--prune', type=float, default=0.0,
+                    help='BASELINE config 5: block-prune the GRU matrices (16x1 blocks) to this sparsity, e.g. 0.95')
     ap.add_argument('--parity-noise', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -104,6 +106,9 @@ def main():
 
     mode, target, overlap, hop = 'MOL', 11000, 550, 275
     sd = random_state_dict(0, mode=mode)
+    if args.prune > 0:
+        from wavernn_amd.prune import block_prune_state_dict
+        sd, _ = block_prune_state_dict(sd, args.prune, (16, 1))
     model = WaveRNN(**SHIPPED, mode=mode)
     model.num_params = lambda *a, **k: 0
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
@@ -155,7 +160,10 @@ def main():
         # algorithmic bytes per batch step = W + n*836; one launch = T batch steps
         bytes_per_launch = (W + n_local * 836) * T
         achieved = bytes_per_launch / (kms * 1e-3) / 1e9
-        flops_per_launch = 2.0 * 3825152 * n_local * T if mode == 'MOL' else 2.0 * 4071936 * n_local * T
+        wkeys = ('I.weight', 'rnn1.weight_ih_l0', 'rnn1.weight_hh_l0', 'rnn2.weight_ih_l0', 'rnn2.weight_hh_l0', 'fc1.weight',
+                 'fc2.weight', 'fc3.weight')
+        nnz = int(sum(np.count_nonzero(sd[k]) for k in wkeys))      # 3,825,152 for the dense MoL model
+        flops_per_launch = 2.0 * nnz * n_local * T
         tf = flops_per_launch / (kms * 1e-3) / 1e12
         u_per_wg, ncl, depth = eng.last_loop_split()
         traffic = None
@@ -170,7 +178,8 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'realtime_factor': round(value / SAMPLE_RATE, 2),
-            'config': {'workload': f'BASELINE config 2 (MoL WaveRNN, rnn/fc 512, random-init weights, batched fold target={target} '
+            'config': {'workload': (f'BASELINE config 5 (GRU matrices block-pruned to {args.prune:.0%} zeros, 16x1 blocks) = ' if args.prune > 0 else '') +
+                                   f'BASELINE config 2 (MoL WaveRNN, rnn/fc 512, random-init weights, batched fold target={target} '
                                    f'overlap={overlap}) on a batch of {args.utterances} random {args.frames}-frame mels per GPU '
                                    f'-> {n_local} folded segments x T={T} steps in one launch per GPU, '
                                    f'{wave_total // world} output samples per GPU per step',
@@ -192,7 +201,8 @@ def main():
         mfma = {'bound': 'mfma', 'achieved': round(tf, 3), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
                 'frac': round(tf / MFMA_F32_PEAK_TF, 5), 'traffic': traffic, 'kernel': eng.last_loop_kernel(),
                 'kernel_ms': round(kms, 3), 'algorithmic_flops_per_launch': flops_per_launch,
-                'note': 'useful f32 FLOPs of the loop (2 x 3,825,152 weights per segment-step x n x T) / kernel time (HIP events '
+                'weights_nnz': nnz,
+                'note': 'useful f32 FLOPs of the loop (2 x non-zero loop weights per segment-step x n x T) / kernel time (HIP events '
                         'on the launch stream) vs the dense f32 MFMA peak; n >= 50 resident segments puts the loop right of the '
                         'f32 ridge (SURVEY.md 8d)'}
         if n_local >= 50:

@@ -348,7 +348,9 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
     const bool shape_ok = (p->mode == WRNN_MODE_MOL) || (p->C == H);
     enum { K_STREAM, K_PERSIST, K_CLUSTER, K_PIPE, K_SPARSE } kind = K_STREAM;
     int U = 0, ncl = 0, G = 0;
-    if (algo == WRNN_ALGO_SPARSE) {
+    // auto: a pack whose GRU matrices are block-sparse runs on the block-sparse kernel (measured 1.7-2.3x the dense pipelined
+    // kernel on the same weights, profiles/r01r_probe_block_sparse.json); dense packs never qualify (512 blocks per row)
+    if (algo == WRNN_ALGO_SPARSE || (algo == WRNN_ALGO_AUTO && p->sp_nbp && sparse_clusters(p->n_cus) >= 1)) {
         const int scl = sparse_clusters(p->n_cus);
         if (!p->sp_nbp || scl < 1) {
             set_err("block-sparse kernel needs MOL, >= 32 CUs and GRU matrices with <= 64 surviving 16x1 blocks per block row "
