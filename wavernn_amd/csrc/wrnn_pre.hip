@@ -142,10 +142,12 @@ __global__ __launch_bounds__(256) void wrnn_resnet_kernel(const PreArgs a)
 //   out[c][q] = sum_j w[j] * rep(q + j - s),  rep(u) = in[c][u / s] for 0 <= u < n_in*s, else 0 (the conv's zero padding)
 // FIRST: `in` is the un-padded mel [PFEAT][n_in - 2*pad]; frames outside it are the zero padding of :185.
 // LAST:  writes out_t[q - indent][c] for indent <= q < n_out - indent (the crop of :88, transposed to [sample][channel]).
-template <bool FIRST, bool LAST>
+// S > 0: the stretch factor as a compile-time constant (the divisions become multiplies); S = 0: runtime `s_rt`.
+template <bool FIRST, bool LAST, int S>
 __global__ __launch_bounds__(256) void wrnn_upstage_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                           const float *__restrict__ taps, int n_in, int s, int pad, int indent)
+                                                           const float *__restrict__ taps, int n_in, int s_rt, int pad, int indent)
 {
+    const int s = S > 0 ? S : s_rt;
     const long n_out = (long)n_in * s;
     const long total = LAST ? (n_out - 2L * indent) * PFEAT : n_out * PFEAT;
     const int ld_in = FIRST ? n_in - 2 * pad : n_in;
@@ -155,6 +157,7 @@ __global__ __launch_bounds__(256) void wrnn_upstage_kernel(const float *__restri
         if (LAST) { c = (int)(idx % PFEAT); q = idx / PFEAT + indent; }
         else { c = (int)(idx / n_out); q = idx % n_out; }
         float acc = 0.f;
+#pragma unroll
         for (int j = 0; j <= 2 * s; ++j) {
             const long u = q + j - s;
             float v = 0.f;
@@ -279,12 +282,19 @@ extern "C" int wrnn_pre_upsample(const wrnn_pre *p, const float *mel, int32_t n_
     float *s1 = (float *)workspace;                                     // [PFEAT][nf*s0]
     float *s2 = s1 + (size_t)nf * p->scales[0] * PFEAT;                 // [PFEAT][nf*s0*s1]
     auto grid = [](long total) { long b = (total + 255) / 256; return (unsigned)(b > 65535 ? 65535 : (b < 1 ? 1 : b)); };
-    hipLaunchKernelGGL((wrnn_upstage_kernel<true, false>), dim3(grid((long)nf * p->scales[0] * PFEAT)), dim3(256), 0, stream,
-                       mel, s1, p->taps[0], nf, p->scales[0], PPAD, 0);
-    hipLaunchKernelGGL((wrnn_upstage_kernel<false, false>), dim3(grid((long)nf * p->scales[0] * p->scales[1] * PFEAT)), dim3(256), 0,
-                       stream, s1, s2, p->taps[1], nf * p->scales[0], p->scales[1], 0, 0);
-    hipLaunchKernelGGL((wrnn_upstage_kernel<false, true>), dim3(grid((long)n_frames * p->total_scale * PFEAT)), dim3(256), 0, stream,
-                       s2, mels_up, p->taps[2], nf * p->scales[0] * p->scales[1], p->scales[2], 0, PPAD * p->total_scale);
+    const bool shipped = p->scales[0] == 5 && p->scales[1] == 5 && p->scales[2] == 11;       // hparams.py: voc_upsample_factors
+    const unsigned g1 = grid((long)nf * p->scales[0] * PFEAT), g2 = grid((long)nf * p->scales[0] * p->scales[1] * PFEAT);
+    const unsigned g3 = grid((long)n_frames * p->total_scale * PFEAT);
+    const int n2 = nf * p->scales[0], n3 = n2 * p->scales[1], indent = PPAD * p->total_scale;
+    if (shipped) {
+        hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 5>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, 5, PPAD, 0);
+        hipLaunchKernelGGL((wrnn_upstage_kernel<false, false, 5>), dim3(g2), dim3(256), 0, stream, s1, s2, p->taps[1], n2, 5, 0, 0);
+        hipLaunchKernelGGL((wrnn_upstage_kernel<false, true, 11>), dim3(g3), dim3(256), 0, stream, s2, mels_up, p->taps[2], n3, 11, 0, indent);
+    } else {
+        hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 0>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, p->scales[0], PPAD, 0);
+        hipLaunchKernelGGL((wrnn_upstage_kernel<false, false, 0>), dim3(g2), dim3(256), 0, stream, s1, s2, p->taps[1], n2, p->scales[1], 0, 0);
+        hipLaunchKernelGGL((wrnn_upstage_kernel<false, true, 0>), dim3(g3), dim3(256), 0, stream, s2, mels_up, p->taps[2], n3, p->scales[2], 0, indent);
+    }
     PRE_HIP(hipGetLastError());
     return WRNN_OK;
 }
