@@ -119,6 +119,23 @@ __device__ __forceinline__ float mol_sample(float mean, float ls, float u)
     return fminf(x, 1.0f);
 }
 
+// argmax over the 16 lanes of a DPP row with the first-max tie rule (lowest index wins), as an all-reduce in four DPP
+// steps (xor 1, xor 2 inside quads, then half-row mirror and row mirror) instead of eight ds_bpermute shuffles.
+template <int CTRL>
+__device__ __forceinline__ void argmax_dpp_step(float &best, int &bidx)
+{
+    const float ob = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, best), CTRL, 0xF, 0xF, true));
+    const int oi = __builtin_amdgcn_update_dpp(0, bidx, CTRL, 0xF, 0xF, true);
+    if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+}
+__device__ __forceinline__ void argmax_row16(float &best, int &bidx)
+{
+    argmax_dpp_step<0xB1>(best, bidx);     // quad_perm [1,0,3,2]
+    argmax_dpp_step<0x4E>(best, bidx);     // quad_perm [2,3,0,1]
+    argmax_dpp_step<0x141>(best, bidx);    // row_half_mirror
+    argmax_dpp_step<0x140>(best, bidx);    // row_mirror
+}
+
 // frame of conditioning position p (Stretch2d repeats each frame `hop` times; p >= L is the fold's zero pad)
 __device__ __forceinline__ int cond_frame(const int *seg_pos, const int *seg_lim, int b, int t, int hop, int NF)
 {

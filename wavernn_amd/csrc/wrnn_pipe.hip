@@ -458,12 +458,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
                 {   // 16-lane group = one segment (pu), lane pj = mixture
                     float best = (pj < 10) ? mol_gumbel_pre(LOG[pu * 32 + pj], nz0) : -INFINITY;
                     int bidx = pj;
-#pragma unroll
-                    for (int m = 8; m >= 1; m >>= 1) {
-                        const float ob = __shfl_xor(best, m, 16);
-                        const int oi = __shfl_xor(bidx, m, 16);
-                        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-                    }
+                    argmax_row16(best, bidx);
                     if (pj == 0 && pu < nb) {
                         float x = mol_sample_pre(LOG[pu * 32 + 10 + bidx], LOG[pu * 32 + 20 + bidx], nz1);
                         if (wg == 0) a.out[(size_t)(b0 + pu) * T + t] = x;
