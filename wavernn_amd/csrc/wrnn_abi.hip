@@ -343,8 +343,11 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
     a.NG = (B + SEG - 1) / SEG;
 
     // ---- kernel choice --------------------------------------------------------------------------------
-    // cluster: clustered persistent kernel (all groups in one launch); persist: the chip-wide kernel, one launch
-    // per 16-segment group; stream: one workgroup per segment.  auto = cluster where the device admits it.
+    // sparse: block-sparse GRU pack, 8 XCD clusters x <= 2 groups in flight; pipe: MOL, 4 clusters x 2-3 groups in flight;
+    // cluster: 1/2/4 clusters, one group in flight each (all groups in one launch); persist: the chip-wide kernel, one
+    // launch per 16-segment group; stream: one workgroup per segment.
+    // auto = sparse if the pack qualifies, else pipe when a cluster has more than one group to run (MOL), else cluster,
+    // else (device too small / odd class count) stream.
     const bool shape_ok = (p->mode == WRNN_MODE_MOL) || (p->C == H);
     enum { K_STREAM, K_PERSIST, K_CLUSTER, K_PIPE, K_SPARSE } kind = K_STREAM;
     int U = 0, ncl = 0, G = 0;
