@@ -420,7 +420,9 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
             // default split: as many clusters as there are groups to keep busy (fewer, larger clusters have the
             // shorter per-step MFMA chain; more, smaller clusters run more groups at once)
             const int umax = (p->mode == WRNN_MODE_MOL) ? 8 : 4;          // the U = 8 split exists for MOL only
-            const int first = a.NG >= 3 ? umax : (a.NG == 2 ? 4 : 2);
+            // measured (profiles/r01d_probe_pipe_depths.json, B = 12): two clusters x 6 segments 18.5 us per step against 22.6 us
+            // for the chip-wide split with all 12 in one group -- fewer granule rows per sweep win, so never start at U = 2
+            const int first = a.NG >= 3 ? umax : 4;
             const int pref[3] = {first, 4, umax};
             if ((want == 2 || want == 4 || want == 8) && want <= umax) { U = want; ncl = cluster_count(U, p->n_cus); }
             for (int i = 0; i < 3 && ncl < 1; ++i) { U = pref[i]; ncl = cluster_count(U, p->n_cus); }
