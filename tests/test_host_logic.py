@@ -157,3 +157,19 @@ def test_block_prune_mask():
         a = np.abs(W[g * 512:(g + 1) * 512])
         thr = np.sort(a.reshape(-1))[int(a.size * 0.9)]
         assert np.array_equal(M[g * 512:(g + 1) * 512], (a >= thr).astype(np.float32))
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/wavernn_amd.h is the drop-in boundary: it must compile as plain C99 (no C++ in the header, no torch types)."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    src = tmp_path / 'use_header.c'
+    src.write_text('#include "wavernn_amd.h"\n'
+                   'int probe(void) { wrnn_weights w; wrnn_geometry g; wrnn_debug d; wrnn_pre_weights p;\n'
+                   '  (void)w; (void)g; (void)d; (void)p;\n'
+                   '  return WRNN_ABI_VERSION + WRNN_OK + WRNN_MODE_MOL + WRNN_ALGO_SPARSE + (int)sizeof(wrnn_pre_weights); }\n')
+    res = subprocess.run(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-fsyntax-only', '-I', os.path.join(ROOT, 'include'), str(src)],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout
