@@ -14,10 +14,15 @@
 //   * LDS holds one activation tile per group (x = xi, then xi+h1, xi+h1+h2, y1, y2) plus ONE transient tile for
 //     the freshly gathered h (used at once for the residual add and the W_hh.h product of the NEXT step, then free
 //     for the next group).  G = 3 groups of <= 15 segments + the transient tile = 125 KB.
-//   * the 30-row MOL fc3 no longer fits LDS (62 KB replicated): it is DISTRIBUTED -- workgroup r < 30 of the cluster
-//     computes logit row r for all segments of the group (512-long VALU dot products over the gathered y2) and the
-//     30 logits per segment make a 5th, tiny all-gather (240 B per segment).  Sampling stays replicated.
-//   * cI(t+1) is fetched at the start of the sampling stage of each group (no per-group prefetch registers).
+//   * the 30-row MOL fc3 no longer fits LDS (62 KB replicated): it is DISTRIBUTED -- workgroup wg < 60 of the cluster
+//     computes one K-half (wg / 30) of logit row wg % 30 for all segments of the group (256-long VALU dot products over
+//     the gathered half of y2) and the 30 x 2 partial logits per segment make a 5th, tiny all-gather (480 B per segment;
+//     the consumer adds the two halves).  Sampling stays replicated (argmax as a 4-step DPP row all-reduce).
+//   * cI(t+1) is fetched after the last poll of each group's step (vector loads return in order) from rows touched
+//     into L2 one step earlier; the MOL noise arrives pre-transformed (wrnn_noise_mol_kernel); no per-group prefetch
+//     registers exist.
+//   * sweeps stream (8 loads in flight, slot i reloaded with piece i+8 as soon as it is consumed) or take the whole row
+//     slice at once (NL = 16, default); the two row tiles of a GRU matrix share one set of B fragments (mfma_tile2).
 // Register file: 10 weight tiles x 32 = 320 registers per lane, as in the U = 8 cluster kernel.
 #include "wrnn_tiles.h"
 
