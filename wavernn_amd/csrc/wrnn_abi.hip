@@ -195,7 +195,7 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     hipError_t e = hipMalloc((void **)&p->dev, p->dev_bytes);
     if (e != hipSuccess) { set_err("hipMalloc(%zu) failed: %s", p->dev_bytes, hipGetErrorString(e)); delete p; return WRNN_ERR_HIP; }
     e = hipMemcpy(p->dev, b.host.data(), p->dev_bytes, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { set_err("hipMemcpy failed: %s", hipGetErrorString(e)); hipFree(p->dev); delete p; return WRNN_ERR_HIP; }
+    if (e != hipSuccess) { set_err("hipMemcpy failed: %s", hipGetErrorString(e)); (void)hipFree(p->dev); delete p; return WRNN_ERR_HIP; }
     const float *base = (const float *)p->dev;
     p->I_w0 = base + o_I_w0; p->I_b = base + o_I_b; p->I_cT = base + o_I_cT;
     p->w_ih1 = base + o_w_ih1; p->w_hh1 = base + o_w_hh1; p->b_ih1 = base + o_b_ih1; p->b_hh1 = base + o_b_hh1;
@@ -208,8 +208,8 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     p->sp_nbp = sp_nbp; p->sp_max_blocks = sp_max;
     p->sp_vals = sp_nbp ? base + o_spv : nullptr;
     p->sp_cols = sp_nbp ? reinterpret_cast<const int *>(base + o_spc) : nullptr;
-    hipEventCreate(&p->ev0);
-    hipEventCreate(&p->ev1);
+    HIPCHK(hipEventCreate(&p->ev0));
+    HIPCHK(hipEventCreate(&p->ev1));
     p->timed = false;
     p->last_kernel = "";
     p->last_U = 0; p->last_ncl = 0; p->last_G = 0;
@@ -220,9 +220,9 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
 extern "C" void wrnn_pack_destroy(wrnn_pack *p)
 {
     if (!p) return;
-    hipEventDestroy(p->ev0);
-    hipEventDestroy(p->ev1);
-    hipFree(p->dev);
+    (void)hipEventDestroy(p->ev0);
+    (void)hipEventDestroy(p->ev1);
+    (void)hipFree(p->dev);
     delete p;
 }
 

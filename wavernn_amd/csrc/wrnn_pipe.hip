@@ -220,7 +220,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
             // =========================== S1: GRU1 (fatchord_version.py:210) ===========================
 #pragma unroll 1
             for (int i = 0; i < nact; ++i) {
-                const int nb = GEO[2 * i + 1], b0 = GEO[2 * i];
+                const int nb = GEO[2 * i + 1];
                 float *GP = smem + K::OFF_GRP + i * K::GRP;
                 float *ACT = smem + K::OFF_ACT + i * K::TILE;
                 float *GH1 = GP, *HOWN1 = GP + 2 * PGR * SEG;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
             // =========================== S2: GRU2 (:212-214) ==========================================
 #pragma unroll 1
             for (int i = 0; i < nact; ++i) {
-                const int nb = GEO[2 * i + 1], b0 = GEO[2 * i];
+                const int nb = GEO[2 * i + 1];
                 float *GP = smem + K::OFF_GRP + i * K::GRP;
                 float *ACT = smem + K::OFF_ACT + i * K::TILE;
                 float *GH1 = GP, *GH2 = GP + PGR * SEG, *HOWN2 = GP + 2 * PGR * SEG + PU * SEG;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_pipe_kernel(const LoopArgs a)
             // =========================== S3: fc1 + relu (:216-218) ====================================
 #pragma unroll 1
             for (int i = 0; i < nact; ++i) {
-                const int nb = GEO[2 * i + 1], b0 = GEO[2 * i];
+                const int nb = GEO[2 * i + 1];
                 float *GP = smem + K::OFF_GRP + i * K::GRP;
                 float *ACT = smem + K::OFF_ACT + i * K::TILE;
                 float *GH2 = GP + PGR * SEG;

@@ -241,7 +241,7 @@ extern "C" int wrnn_pre_create(const wrnn_pre_weights *w, int device, wrnn_pre *
     hipError_t e = hipMalloc((void **)&p->dev, h.size() * 4);
     if (e != hipSuccess) { delete p; PRE_FAIL(WRNN_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
     e = hipMemcpy(p->dev, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { hipFree(p->dev); delete p; PRE_FAIL(WRNN_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(p->dev); delete p; PRE_FAIL(WRNN_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e)); }
     p->conv_in_w = p->dev + o_cin; p->bn_in = p->dev + o_bnin; p->res_w = p->dev + o_resw; p->res_bn = p->dev + o_resbn;
     p->conv_out_w = p->dev + o_cow; p->conv_out_b = p->dev + o_cob;
     for (int i = 0; i < 3; ++i) p->taps[i] = p->dev + o_t[i];
@@ -252,7 +252,7 @@ extern "C" int wrnn_pre_create(const wrnn_pre_weights *w, int device, wrnn_pre *
 extern "C" void wrnn_pre_destroy(wrnn_pre *p)
 {
     if (!p) return;
-    hipFree(p->dev);
+    (void)hipFree(p->dev);
     delete p;
 }
 
