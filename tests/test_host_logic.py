@@ -173,3 +173,19 @@ def test_header_is_plain_c(tmp_path):
     res = subprocess.run(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-fsyntax-only', '-I', os.path.join(ROOT, 'include'), str(src)],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert res.returncode == 0, res.stdout
+
+
+def test_gen_corpus_input_checks(tmp_path):
+    """the corpus CLI applies the reference's `.npy` mel checks (gen_wavernn.py:48-55) and the 21-frame minimum (:258)."""
+    from wavernn_amd import gen_corpus as G
+    with pytest.raises(ValueError):
+        G.load_mels(tmp_path)                                   # empty directory
+    np.save(tmp_path / 'ok.npy', np.random.RandomState(0).rand(80, 30).astype(np.float32))
+    paths, mels = G.load_mels(tmp_path)
+    assert [p.name for p in paths] == ['ok.npy'] and tuple(mels[0].shape) == (1, 80, 30)
+    for name, arr in (('shape.npy', np.zeros((30, 80), np.float32)), ('range.npy', np.full((80, 30), 2.0, np.float32)),
+                      ('short.npy', np.zeros((80, 20), np.float32))):
+        np.save(tmp_path / name, arr)
+        with pytest.raises(ValueError):
+            G.load_mels(tmp_path)
+        os.remove(tmp_path / name)
