@@ -37,14 +37,50 @@ CASES = [
     dict(name='mol_unbatched_24f', mode='MOL', wseed=12, mseed=103, frames=24, batched=False, target=11000, overlap=550, mu_law=True, seed=79),
     dict(name='mol_batched_100f', mode='MOL', wseed=12, mseed=104, frames=100, batched=True, target=1100, overlap=55, mu_law=True, seed=80),
     dict(name='mol_batched_ragged_53f', mode='MOL', wseed=13, mseed=105, frames=53, batched=True, target=2000, overlap=100, mu_law=False, seed=81),
+    # BASELINE config 2 at its stated inputs: weight seed 0, mel seed 1234, N=481 -> B=12, T=12100, sample seed 77
+    dict(name='mol_batched_481f', mode='MOL', wseed=0, mseed=1234, frames=481, batched=True, target=11000, overlap=550, mu_law=True, seed=77),
+    dict(name='raw_batched_481f', mode='RAW', wseed=0, mseed=1234, frames=481, batched=True, target=11000, overlap=550, mu_law=True, seed=77),
+    # BASELINE config 3, vocoder side (gen_tacotron.py:139-166): the mel comes from the reference's own Tacotron.generate
+    # (seeded random init, steps=800 -> (80,800)), rescaled (m+4)/8 and clipped (:144-145); L = 220,000 = 19*11,550 + 550
+    # exactly -> B = 19 with NO padded fold.  The mel is stored in the fixture (Tacotron is upstream of the path).
+    dict(name='mol_tacotron_800f', mode='MOL', wseed=0, mseed=None, frames=800, batched=True, target=11000, overlap=550, mu_law=True, seed=77,
+         tts_seed=3),
 ]
+
+
+def tacotron_mel(c):
+    """gen_tacotron.py:97-145 with a seeded random-init Tacotron: first line of sentences.txt -> text_to_sequence ->
+    Tacotron.generate(x, steps=frames) -> (m + 4) / 8, clip to [0, 1].  Stubs: unidecode, inflect."""
+    import time
+    un = types.ModuleType('unidecode'); un.unidecode = lambda s: s
+    sys.modules.setdefault('unidecode', un)
+    inf = types.ModuleType('inflect'); inf.engine = lambda: types.SimpleNamespace(number_to_words=lambda *a, **k: 'number')
+    sys.modules.setdefault('inflect', inf)
+    from models.tacotron import Tacotron
+    from utils.text.symbols import symbols
+    from utils.text import text_to_sequence
+    torch.manual_seed(c['tts_seed'])
+    tts = Tacotron(embed_dims=hp.tts_embed_dims, num_chars=len(symbols), encoder_dims=hp.tts_encoder_dims,
+                   decoder_dims=hp.tts_decoder_dims, n_mels=hp.num_mels, fft_bins=hp.num_mels, postnet_dims=hp.tts_postnet_dims,
+                   encoder_K=hp.tts_encoder_K, lstm_dims=hp.tts_lstm_dims, postnet_K=hp.tts_postnet_K,
+                   num_highways=hp.tts_num_highways, dropout=hp.tts_dropout, stop_threshold=hp.tts_stop_threshold)
+    with open(os.path.join(REF, 'sentences.txt')) as f:
+        x = text_to_sequence(f.readline().strip(), hp.tts_cleaner_names)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        _, m, _ = tts.generate(x, steps=c['frames'])
+    print(f'reference Tacotron.generate: {len(x)} symbols -> mel {m.shape} in {time.perf_counter() - t0:.1f} s (CPU, {torch.get_num_threads()} threads)')
+    m = (m + 4) / 8
+    np.clip(m, 0, 1, out=m)
+    assert m.shape == (80, c['frames']), m.shape
+    return np.ascontiguousarray(m, dtype=np.float32)
 
 
 def run_case(c):
     sd_np = random_state_dict(c['wseed'], mode=c['mode'])
     model = WaveRNN(**SHIPPED, mode=c['mode'])
     missing = model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}, strict=True)
-    mel = random_mel(c['mseed'], c['frames'])
+    mel = tacotron_mel(c) if c['mseed'] is None else random_mel(c['mseed'], c['frames'])
     cap = {}
     real_stack = torch.stack
 
@@ -64,15 +100,19 @@ def run_case(c):
     torch.stack = stack
     try:
         torch.manual_seed(c['seed'])
+        import time
+        t0 = time.perf_counter()
         out = model.generate(torch.tensor(mel).unsqueeze(0), '/tmp/_golden.wav', c['batched'], c['target'],
                              c['overlap'], c['mu_law'])
+        c = dict(c, ref_cpu_seconds=round(time.perf_counter() - t0, 2), ref_cpu_threads=torch.get_num_threads())
     finally:
         torch.stack = real_stack
     raw = cap['raw'].transpose(0, 1).contiguous().numpy()       # (B,T) float32, pre-decode (:243)
     mels_up = cap['mels_up'][0].numpy()
     aux_up = cap['aux_up'][0].numpy()
     # keep fixtures small: conditioning is stored strided (every 97th upsampled sample) + full aux frames
-    np.savez_compressed(os.path.join(OUT, c['name'] + '.npz'),
+    extra = {'mel': mel.astype(np.float32)} if c['mseed'] is None else {}
+    np.savez_compressed(os.path.join(OUT, c['name'] + '.npz'), **extra,
                         config=np.array(repr(c)), out=out.astype(np.float64), raw=raw.astype(np.float32),
                         mels_up_strided=mels_up[::97].astype(np.float32), aux_up_strided=aux_up[::97].astype(np.float32),
                         L=np.int64(mels_up.shape[0]))

@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 CASES = ['raw_unbatched_24f', 'raw_batched_60f', 'mol_unbatched_24f', 'mol_batched_100f', 'mol_batched_ragged_53f']
 
+#: BASELINE configs 2 and 3 (vocoder side) at their stated full-size inputs (T = 12,100); reference outputs, see scripts/make_golden.py
+BIG_CASES = ['mol_batched_481f', 'raw_batched_481f', 'mol_tacotron_800f']
+
 #: MoL tolerance (max abs error on samples in [-1,1]) -- BASELINE.md "budget 1e-5"; observed <= 4e-7 CPU-vs-CPU.
 MOL_TOL = 1e-5
 
@@ -13,6 +16,12 @@ def load_case(name):
     g = np.load(os.path.join(GOLDEN, name + '.npz'))
     cfg = ast.literal_eval(str(g['config']))
     return cfg, g
+
+
+def case_mel(cfg, g):
+    """(feat, N) float32 mel of a golden case: seeded random mel, or the stored one (config 3: the reference Tacotron's)."""
+    from wavernn_amd.synthetic import random_mel
+    return np.ascontiguousarray(g['mel'], np.float32) if cfg['mseed'] is None else random_mel(cfg['mseed'], cfg['frames'])
 
 
 def oracle_loop_fn(sd, mode):

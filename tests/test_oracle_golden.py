@@ -6,7 +6,7 @@ import pytest
 from oracle import wavernn_oracle as O
 from oracle import c_oracle as C
 from wavernn_amd.synthetic import random_state_dict, random_mel
-from helpers import CASES, MOL_TOL, load_case
+from helpers import CASES, BIG_CASES, MOL_TOL, load_case, case_mel
 
 
 def test_rng_known_answers(golden_dir):
@@ -84,3 +84,25 @@ def test_fold_examples():
     assert f[:, :, 0].tolist() == [[1, 2, 3, 4], [4, 5, 6, 7], [7, 8, 9, 10]]
     short = O.fold_with_overlap(np.ones((1, 5, 2), np.float32), 8, 2)   # L < target+2*overlap -> one padded fold
     assert short.shape == (1, 12, 2) and short[0, 5:].sum() == 0
+
+
+@pytest.mark.parametrize('name', BIG_CASES)
+def test_c_oracle_matches_reference_full_size(name):
+    """BASELINE configs 2 (N=481 -> B=12) and 3 (vocoder side: N=800 -> B=19, exact fit, no padded fold) at T = 12,100:
+    the C oracle vs the reference's own pre-decode tensor and final waveform.  RAW bit-exact, MoL <= MOL_TOL."""
+    cfg, g = load_case(name)
+    sd = random_state_dict(cfg['wseed'], mode=cfg['mode'])
+    mel = case_mel(cfg, g)
+    mels, aux, wave_len = O.conditioning(sd, mel, cfg['batched'], cfg['target'], cfg['overlap'])
+    B, T, _ = mels.shape
+    assert (B, T) == g['raw'].shape and T == 12100
+    if name == 'mol_tacotron_800f':
+        assert B == 19 and mel.shape == (80, 800) and 800 * 275 == 19 * 11550 + 550      # exact fit: no zero-padded fold
+    noise = O.draw_noise(cfg['seed'], cfg['mode'], B, T)
+    raw = C.loop(sd, cfg['mode'], mels, aux, noise)
+    out = O.finish(raw.copy(), cfg['mode'], 512 if cfg['mode'] == 'RAW' else 30, wave_len, True, cfg['target'], cfg['overlap'], cfg['mu_law'])
+    if cfg['mode'] == 'RAW':
+        assert np.array_equal(raw, g['raw']) and np.array_equal(out, g['out'])
+    else:
+        assert np.abs(raw - g['raw']).max() <= MOL_TOL
+        assert np.abs(out - g['out']).max() <= MOL_TOL
