@@ -12,6 +12,8 @@
  *     (e.g. a torch tensor's data_ptr()); the library BORROWS it for the duration of the call.
  *   - all functions return WRNN_OK (0) or a negative error code; wrnn_last_error() returns a message for the
  *     calling thread's last failure.  Nothing here synchronises the device except the functions that say so.
+ *   - a wrnn_pack is immutable after creation: any number of threads / streams may generate from one pack at the same
+ *     time, each with its own workspace (and timer).  Nothing is read from the environment.
  *   - work is enqueued on the hipStream_t passed as `void* stream` (NULL = default stream).
  *   - arithmetic type: float32 (same as the reference).  No CPU fallback exists: without a HIP device every
  *     compute entry point fails with WRNN_ERR_NO_DEVICE.
@@ -26,7 +28,7 @@
 extern "C" {
 #endif
 
-#define WRNN_ABI_VERSION 2
+#define WRNN_ABI_VERSION 3
 
 enum {
     WRNN_OK = 0,
@@ -42,13 +44,12 @@ enum { WRNN_MODE_RAW = 0, WRNN_MODE_MOL = 1 };  /* reference: WaveRNN(mode='RAW'
 
 /* Loop kernel selection. */
 enum {
-    WRNN_ALGO_AUTO = 0,     /* pipelined / clustered persistent kernel when the device admits it, else stream */
-    WRNN_ALGO_STREAM = 1,   /* one workgroup per folded segment, weights streamed from L2/MALL each step */
-    WRNN_ALGO_PERSIST = 2,  /* chip-wide persistent kernel: one cooperative launch per group of <= 16 segments */
-    WRNN_ALGO_CLUSTER = 3,  /* clustered persistent kernel: 1, 2 or 4 independent CU clusters, each with a full
-                               on-chip copy of the weights, all groups of <= 16 segments in ONE launch */
-    WRNN_ALGO_PIPE = 4,     /* pipelined clustered kernel (MOL): 4 clusters x up to 3 groups in flight per cluster,
-                               interleaved stage by stage so the inter-CU exchange latency hides behind MFMA work */
+    WRNN_ALGO_AUTO = 0,     /* block-sparse kernel when the pack qualifies, else the role-split loop kernel, else stream */
+    WRNN_ALGO_STREAM = 1,   /* one workgroup per folded segment, weights streamed from L2/MALL each step: the generic fallback
+                               (any class count, any device size) and the on-GPU cross-check */
+    WRNN_ALGO_LOOP = 2,     /* role-split pipelined persistent kernel (RAW and MOL): up to 4 clusters of 64 CUs, each with a full
+                               fp32 copy of the loop weights in registers, up to 8 groups of <= 16 segments in flight per cluster,
+                               tag-free activation exchange in MFMA-fragment order (csrc/wrnn_loop.hip) */
     WRNN_ALGO_SPARSE = 5    /* block-sparse GRU kernel (MOL; BASELINE config 5): needs GRU matrices whose 16x1 block rows
                                keep <= 64 columns (wrnn_pack_sparse_blocks); 8 XCD-local clusters x 2 groups in flight */
 };
@@ -92,11 +93,41 @@ typedef struct wrnn_geometry {
     int32_t n_frames; /* rows of `aux` (= L / hop) */
 } wrnn_geometry;
 
-/* Optional test hooks (all may be NULL). */
-typedef struct wrnn_debug {
-    const float *force_x;  /* device [B,T]: teacher forcing -- value fed back as x_{t} instead of the sample */
-    float *logits;         /* device [T,B,C]: pre-sampling logits of every step (fc3 output, :223) */
-} wrnn_debug;
+/* HIP-event timer owned by the CALLER (one per in-flight call): wrnn_generate* records an event pair around every loop-kernel
+ * launch it enqueues.  Keeps the weight pack immutable, so one pack can serve several streams / threads at once. */
+typedef struct wrnn_timer wrnn_timer;
+
+/* What a wrnn_generate* call decided (filled synchronously, before the call returns). */
+typedef struct wrnn_run_info {
+    const char *kernel;      /* "wrnn_loop_kernel" / "wrnn_sparse_kernel" / "wrnn_stream_kernel" */
+    int32_t units_per_wg;    /* hidden units per workgroup (16; stream: 0) */
+    int32_t clusters;        /* independent CU clusters, each holding one copy of the weights */
+    int32_t depth;           /* groups of <= 16 segments in flight per cluster */
+    int32_t rounds;          /* rounds of clusters x depth groups the segments were cut into */
+    int32_t slab_steps;      /* steps of hoisted conditioning materialised at a time (loop kernel; others: T) */
+    int32_t launches;        /* loop-kernel launches enqueued */
+} wrnn_run_info;
+
+/*
+ * Per-call options (replaces the environment variables ABI v2 read at call time).  Zero-initialise, set struct_bytes =
+ * sizeof(wrnn_options); NULL options = all defaults.  Everything here is read during the call only.
+ */
+typedef struct wrnn_options {
+    int32_t struct_bytes;
+    int32_t algo;            /* WRNN_ALGO_*                                                                  (default AUTO) */
+    int32_t depth;           /* groups in flight per cluster, 1..8 (sparse: 1..2); 0 = the library picks */
+    int32_t clusters;        /* loop kernel: clusters to use (1, 2 or 4); 0 = the library picks */
+    int32_t cond_valu;       /* stream / sparse kernels: 1 = hoisted conditioning on VALU instead of MFMA (cross-check) */
+    int32_t slab_steps;      /* loop kernel: conditioning slab length in steps; 0 = sized to ~96 MB */
+    int32_t t_begin, t_end;  /* run steps [t_begin, t_end) of the T; 0,0 = all.  t_begin > 0 CONTINUES the call that ended at
+                                t_begin on the same workspace (loop kernel only); `noise` then covers [t_begin, t_end) only,
+                                `out` / force_x / logits always the whole [.., T] tensors */
+    int32_t reserved;
+    const float *force_x;    /* test hook, device [n,T]: value fed back as x_t instead of the sample (teacher forcing) */
+    float *logits;           /* test hook, device [T,n,C]: fc3 output of every step (:223) */
+    wrnn_timer *timer;       /* optional: time the loop kernel(s) of this call */
+    wrnn_run_info *info;     /* optional out */
+} wrnn_options;
 
 const char *wrnn_last_error(void);
 int wrnn_abi_version(void);
@@ -113,8 +144,9 @@ size_t wrnn_pack_weight_bytes(const wrnn_pack *p);
  * row -- positive when WRNN_ALGO_SPARSE can run this pack (<= 64, MOL), negated when it cannot */
 int wrnn_pack_sparse_blocks(const wrnn_pack *p);
 
-/* Workspace (device bytes) wrnn_generate needs for this geometry. */
-size_t wrnn_workspace_bytes(const wrnn_pack *p, const wrnn_geometry *g);
+/* Workspace (device bytes) wrnn_generate needs for this geometry under these options (NULL = defaults).  With the loop
+ * kernel it does not grow with T: conditioning is produced in slabs (942 segments x 12,100 steps: < 1 GB). */
+size_t wrnn_workspace_bytes(const wrnn_pack *p, const wrnn_geometry *g, const wrnn_options *opt);
 
 /*
  * The loop: replaces fatchord_version.py:192-245 (state init, the `for i in range(seq_len)` body incl.
@@ -132,8 +164,8 @@ size_t wrnn_workspace_bytes(const wrnn_pack *p, const wrnn_geometry *g);
  * the kernels completed (bounded spins never hang: they give up and report).
  */
 int wrnn_generate(const wrnn_pack *p, const wrnn_geometry *g, const float *mels_up, const float *aux,
-                  const float *noise, float *out, void *workspace, size_t workspace_bytes, int algo,
-                  const wrnn_debug *dbg, void *stream);
+                  const float *noise, float *out, void *workspace, size_t workspace_bytes, const wrnn_options *opt,
+                  void *stream);
 
 /*
  * The same loop over an explicit SEGMENT TABLE: segment b, step t reads conditioning position
@@ -149,21 +181,29 @@ int wrnn_generate(const wrnn_pack *p, const wrnn_geometry *g, const float *mels_
 int wrnn_generate_segments(const wrnn_pack *p, int32_t n_segments, int32_t T, const int32_t *seg_pos,
                            const int32_t *seg_lim, int32_t L, int32_t hop, int32_t n_frames,
                            const float *mels_up, const float *aux, const float *noise, float *out,
-                           void *workspace, size_t workspace_bytes, int algo, const wrnn_debug *dbg, void *stream);
-size_t wrnn_workspace_bytes_segments(const wrnn_pack *p, int32_t n_segments, int32_t T, int32_t n_frames);
+                           void *workspace, size_t workspace_bytes, const wrnn_options *opt, void *stream);
+size_t wrnn_workspace_bytes_segments(const wrnn_pack *p, int32_t n_segments, int32_t T, int32_t n_frames,
+                                     const wrnn_options *opt);
+
+/* What wrnn_generate_segments WOULD run for this many segments under these options (kernel, split, rounds, slab length),
+ * without launching anything.  `launches` is left 0. */
+int wrnn_plan_segments(const wrnn_pack *p, int32_t n_segments, int32_t T, const wrnn_options *opt, wrnn_run_info *out);
 
 /* Synchronises `stream`, reads the kernel status words from `workspace`.  WRNN_OK or WRNN_ERR_KERNEL. */
 int wrnn_status(void *workspace, void *stream);
 
-/* Milliseconds the last wrnn_generate on this pack spent in its loop kernel(s) (HIP events on `stream`;
- * synchronises).  <0 if unavailable. */
-float wrnn_last_loop_ms(const wrnn_pack *p);
-/* name of the loop kernel the last wrnn_generate launched
- * ("wrnn_pipe_kernel" / "wrnn_cluster_kernel" / "wrnn_persist_kernel" / "wrnn_stream_kernel") */
-const char *wrnn_last_loop_kernel(const wrnn_pack *p);
-/* how that kernel split the chip: hidden units per workgroup, number of independent clusters and groups of segments in
- * flight per cluster (0,0,0 = stream) */
-int wrnn_last_loop_split(const wrnn_pack *p, int *units_per_wg, int *clusters, int *groups_in_flight);
+/* Test hook: one exchanged activation layer (0 h1, 1 h2, 2 y1, 3 y2, 4 RAW logits) of (cluster, slot) at ring position `ring`
+ * (= step % 3) of the loop kernel's exchange buffer, un-permuted from MFMA-fragment order into host_out[16 segments][512].
+ * Call after a run with the same (n_segments, T, n_frames, opt).  Synchronises the device. */
+int wrnn_debug_read_exchange(const wrnn_pack *p, void *workspace, int32_t n_segments, int32_t T, int32_t n_frames,
+                             const wrnn_options *opt, int cluster, int slot, int layer, int ring, float *host_out);
+
+/* Timer objects (see wrnn_options.timer).  wrnn_timer_ms synchronises on the recorded events and returns the SUM of the
+ * loop-kernel launch durations of the last call that used the timer (<0 if none); wrnn_timer_launches their count. */
+int wrnn_timer_create(int device, wrnn_timer **out);
+void wrnn_timer_destroy(wrnn_timer *t);
+float wrnn_timer_ms(wrnn_timer *t);
+int wrnn_timer_launches(const wrnn_timer *t);
 
 /*
  * Pre-loop stage: `UpsampleNetwork.forward` (fatchord_version.py:82-89) = MelResNet (:31-48) + ResBlocks (:13-28) on
@@ -211,11 +251,6 @@ int wrnn_post_unfold(const float *segments, int32_t T, int32_t n_utt, const int3
                      const double *fade_out, int32_t overlap, const double *tail, int32_t tail_len, int32_t batched,
                      double *out, void *stream);
 const char *wrnn_post_last_error(void);
-
-/* Profiling builds (environment WRNN_PROF=1 at wrnn_generate time, pipelined kernel): copies the per-workgroup phase
- * clocks [256 workgroups][16 phases] (shader cycles summed over the launch; phases listed in wrnn_pipe.hip) to `out`.
- * Synchronises `stream`.  Returns the number of words copied or a negative error. */
-int wrnn_profile_read(void *workspace, unsigned long long *out, int max_words, void *stream);
 
 /* Self tests of the device primitives (MFMA fragment layout, inter-workgroup granule all-gather).
  * Synchronous.  WRNN_OK or an error with a message. */

@@ -17,8 +17,8 @@ ap.add_argument('--T', type=int, default=1500)
 ap.add_argument('--mode', default='MOL')
 ap.add_argument('--prune', type=float, default=0.0, help='block-prune the GRU matrices to this sparsity (config 5)')
 ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'probe.json'))
-ap.add_argument('--B', default='12,64,120,128,180,192,256,360')
-ap.add_argument('--variants', default='u8,p2,p3,auto')
+ap.add_argument('--B', default='12,24,64,128,192,256,512')
+ap.add_argument('--variants', default='auto,g1,g2,g4,g8')
 args = ap.parse_args()
 
 dev = torch.device('cuda', 0)
@@ -29,12 +29,11 @@ if args.prune > 0:
     sd, _ = block_prune_state_dict(sd, args.prune, (16, 1))
 eng = LoopEngine(sd, mode, device=dev)
 rs = np.random.RandomState(3)
-VARS = {'persist': ('persist', {}), 'u2': ('cluster', {'WRNN_CLUSTER_U': '2'}), 'u4': ('cluster', {'WRNN_CLUSTER_U': '4'}),
-        'u8': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '8'}),
-        'u8nl16': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '16'}), 'auto': ('auto', {}),
-        'p1': ('pipe', {'WRNN_PIPE_G': '1'}), 'p2': ('pipe', {'WRNN_PIPE_G': '2'}), 'p3': ('pipe', {'WRNN_PIPE_G': '3'}),
-        's1': ('sparse', {'WRNN_SPARSE_G': '1'}), 's2': ('sparse', {'WRNN_SPARSE_G': '2'}),
-        'p3nl8': ('pipe', {'WRNN_PIPE_G': '3', 'WRNN_PIPE_NL': '8'}), 'p2nl8': ('pipe', {'WRNN_PIPE_G': '2', 'WRNN_PIPE_NL': '8'})}
+#: name -> wrnn_options (LoopEngine.run keyword arguments)
+VARS = {'auto': dict(algo='auto'), 'stream': dict(algo='stream'), 'g1': dict(algo='loop', depth=1), 'g2': dict(algo='loop', depth=2),
+        'g3': dict(algo='loop', depth=3), 'g4': dict(algo='loop', depth=4), 'g6': dict(algo='loop', depth=6), 'g8': dict(algo='loop', depth=8),
+        'c1g1': dict(algo='loop', clusters=1, depth=1), 'c2g1': dict(algo='loop', clusters=2, depth=1), 'c1g2': dict(algo='loop', clusters=1, depth=2),
+        's1': dict(algo='sparse', depth=1), 's2': dict(algo='sparse', depth=2)}
 rows = []
 for B in [int(x) for x in args.B.split(',')]:
     stride = 64
@@ -48,28 +47,21 @@ for B in [int(x) for x in args.B.split(',')]:
         noise = torch.empty(T, B, 512, device=dev).exponential_(1)
     ref = None
     for v in args.variants.split(','):
-        algo, env = VARS[v]
-        if mode == 'RAW' and (v.startswith('u8') or v.startswith('p')) and v != 'persist':
-            continue
-        if v == 'persist' and B > 64:
-            continue
-        for k in ('WRNN_CLUSTER_U', 'WRNN_CLUSTER_NL', 'WRNN_PIPE_G', 'WRNN_PIPE_NL', 'WRNN_SPARSE_G'):
-            os.environ.pop(k, None)
-        os.environ.update(env)
+        opts = VARS[v]
         try:
-            out = eng.run(mels_up, aux, B, T, stride, noise, hop, algo=algo)
-            out = eng.run(mels_up, aux, B, T, stride, noise, hop, algo=algo)
+            depth = opts.get('depth', 0)
+            if depth > 1 and B <= 64 * (depth - 1) and opts['algo'] == 'loop':
+                continue                                              # the extra slots would stay empty: same run as a shallower depth
+            out = eng.run(mels_up, aux, B, T, stride, noise, hop, **opts)
+            out = eng.run(mels_up, aux, B, T, stride, noise, hop, **opts)
             ms = eng.last_loop_ms()
             o = out.cpu().numpy()
             if ref is None:
                 ref = o
             err = float(np.abs(o - ref).max())
-            u, ncl, gdepth = eng.last_loop_split()
-            rows_g = 15 if (gdepth >= 3 and algo != 'sparse') else 16
-            groups = -(-B // rows_g)
-            rounds = groups if algo == 'persist' else max(1, -(-groups // max(ncl * max(gdepth, 1), 1)))
-            row = dict(variant=v, B=B, T=T, ms=round(ms, 3), us_per_round_step=round(ms * 1e3 / (T * rounds), 3),
-                       seg_steps_per_s=round(B * T / (ms * 1e-3)), split=[u, ncl, gdepth], max_dev_vs_first=err)
+            info = eng.last_run_info()
+            row = dict(variant=v, B=B, T=T, ms=round(ms, 3), us_per_round_step=round(ms * 1e3 / (T * max(info['rounds'], 1)), 3),
+                       seg_steps_per_s=round(B * T / (ms * 1e-3)), info=info, max_dev_vs_first=err)
         except Exception as e:
             row = dict(variant=v, B=B, error=str(e)[:200])
         rows.append(row)

@@ -68,16 +68,16 @@ def test_no_device_is_an_error_not_a_fallback(L):
 
 def test_null_handles_are_rejected(L):
     g = _lib.Geometry(1, 10, 0, 275, 275, 1)
-    assert L.wrnn_workspace_bytes(None, ctypes.byref(g)) == 0
-    assert L.wrnn_workspace_bytes_segments(None, 1, 10, 1) == 0
+    assert L.wrnn_workspace_bytes(None, ctypes.byref(g), None) == 0
+    assert L.wrnn_workspace_bytes_segments(None, 1, 10, 1, None) == 0
     assert L.wrnn_pack_weight_bytes(None) == 0
-    assert L.wrnn_generate(None, ctypes.byref(g), None, None, None, None, None, 0, 0, None, None) == ERR_ARG
-    assert L.wrnn_generate_segments(None, 1, 10, None, None, 275, 275, 1, None, None, None, None, None, 0, 0, None, None) == ERR_ARG
+    assert L.wrnn_generate(None, ctypes.byref(g), None, None, None, None, None, 0, None, None) == ERR_ARG
+    assert L.wrnn_generate_segments(None, 1, 10, None, None, 275, 275, 1, None, None, None, None, None, 0, None, None) == ERR_ARG
     assert L.wrnn_status(None, None) == ERR_ARG
-    assert L.wrnn_last_loop_ms(None) < 0
-    assert L.wrnn_last_loop_kernel(None) == b''
-    assert L.wrnn_last_loop_split(None, None, None, None) == ERR_ARG
-    assert L.wrnn_profile_read(None, None, 0, None) == ERR_ARG
+    assert L.wrnn_timer_ms(None) < 0 and L.wrnn_timer_launches(None) == 0
+    assert L.wrnn_plan_segments(None, 1, 10, None, None) == ERR_ARG
+    assert L.wrnn_debug_read_exchange(None, None, 1, 10, 1, None, 0, 0, 0, 0, None) == ERR_ARG
+    L.wrnn_timer_destroy(None)
     assert L.wrnn_pre_hop(None) == 0 and L.wrnn_pre_workspace_bytes(None, 10) == 0
     assert L.wrnn_pre_upsample(None, None, 10, None, None, None, 0, None) == ERR_ARG
     L.wrnn_pack_destroy(None)

@@ -43,41 +43,22 @@ def _inputs(cfg):
     return sd, mel, mels_up, aux, (B, T, stride), noise, np.ascontiguousarray(flat, np.float32)
 
 
-#: loop-kernel variants: name -> (algo, environment overrides read by the C ABI at call time)
+#: loop-kernel variants: name -> wrnn_options (LoopEngine.run keyword arguments); nothing is read from the environment
 VARIANTS = {
-    'stream': ('stream', {}),
-    'persist': ('persist', {}),
-    'cluster-u2': ('cluster', {'WRNN_CLUSTER_U': '2'}),
-    'cluster-u4': ('cluster', {'WRNN_CLUSTER_U': '4'}),
-    'cluster-u8': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '8'}),
-    'cluster-u8-nl16': ('cluster', {'WRNN_CLUSTER_U': '8', 'WRNN_CLUSTER_NL': '16'}),
-    'pipe-g1': ('pipe', {'WRNN_PIPE_G': '1'}),
-    'pipe-g2': ('pipe', {'WRNN_PIPE_G': '2'}),
-    'pipe-g3': ('pipe', {'WRNN_PIPE_G': '3'}),
-    'pipe-g3-nl8': ('pipe', {'WRNN_PIPE_G': '3', 'WRNN_PIPE_NL': '8'}),
+    'stream': dict(algo='stream'),
+    'loop': dict(algo='loop'),                                        # the split the library picks
+    'loop-g1': dict(algo='loop', depth=1),
+    'loop-g2-slabs': dict(algo='loop', depth=2, slab_steps=97),       # several conditioning slabs: state saved / restored
+    'loop-c1-g3': dict(algo='loop', clusters=1, depth=3, slab_steps=160),
+    'loop-c2-g2': dict(algo='loop', clusters=2, depth=2),
 }
-KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'persist': 'wrnn_persist_kernel', 'cluster': 'wrnn_cluster_kernel',
-               'pipe': 'wrnn_pipe_kernel'}
-ENV_KEYS = ('WRNN_CLUSTER_U', 'WRNN_CLUSTER_NL', 'WRNN_PIPE_G', 'WRNN_PIPE_NL', 'WRNN_SPARSE_G', 'WRNN_COND')
-
-
-def _mol_only(variant):
-    return variant.startswith('cluster-u8') or variant.startswith('pipe')
-
-
-def _select(monkeypatch, variant):
-    algo, env = VARIANTS[variant]
-    for k in ENV_KEYS:
-        monkeypatch.delenv(k, raising=False)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    return algo
+KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'loop': 'wrnn_loop_kernel', 'sparse': 'wrnn_sparse_kernel'}
 
 
 def test_device_selftests(gpu):
     from wavernn_amd import _lib
     L = _lib.lib()
-    assert L.wrnn_abi_version() == 2
+    assert L.wrnn_abi_version() == 3
     assert L.wrnn_device_cus(0) > 0
     _lib.check(L.wrnn_selftest(0, 1), 'mfma selftest')
     print(L.wrnn_last_error().decode())
@@ -85,25 +66,87 @@ def test_device_selftests(gpu):
     print(L.wrnn_last_error().decode())
 
 
+@pytest.mark.parametrize('mode', ['MOL', 'RAW'])
+def test_exchange_layers_match_oracle(gpu, mode):
+    """Stage-level check of the loop kernel (test hook `wrnn_debug_read_exchange`): after a 3-step run of 40 segments
+    (3 groups on 3 clusters) the exchanged h1 / h2 of every step still sit in the 3-deep ring, in MFMA-fragment order;
+    un-permuted they must equal the numpy oracle's GRU states -- localises a wrong stage instead of a wrong waveform."""
+    from oracle import wavernn_oracle as O
+    from wavernn_amd.engine import LoopEngine
+    cfg = dict(mode=mode, wseed=37, mseed=137, frames=100, batched=True, target=480, overlap=60, seed=97)
+    sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
+    T = 3
+    nz = (noise[0][:T], noise[1][:T]) if mode == 'MOL' else noise[:T]
+    fl = np.ascontiguousarray(np.concatenate([nz[0].reshape(T, B * 10), nz[1].reshape(T, B)], axis=1) if mode == 'MOL' else nz, np.float32)
+    mels_f, aux_f, _ = O.conditioning(sd, mel, True, cfg['target'], cfg['overlap'])
+    rec = {}
+    ref = O.loop(sd, mode, mels_f[:, :T], aux_f[:, :T], nz, collect=rec)
+    eng = LoopEngine(sd, mode, device=gpu)
+    out, logits = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
+                          torch.from_numpy(fl).to(gpu), 275, algo='loop', depth=1, want_logits=True)
+    info = eng.last_run_info()
+    assert info['kernel'] == 'wrnn_loop_kernel' and info['clusters'] == 4 and info['rounds'] == 1
+    NG = (B + 15) // 16
+    for t in range(T):
+        for g in range(NG):
+            b0, b1 = (g * B) // NG, ((g + 1) * B) // NG
+            for layer, key in ((0, 'h1'), (1, 'h2')):
+                got = eng.read_exchange(g % 4, g // 4, layer, t % 3)[:b1 - b0]
+                np.testing.assert_allclose(got, rec[key][t][b0:b1], rtol=0, atol=2e-6, err_msg=f'{key} step {t} group {g}')
+        np.testing.assert_allclose(logits[t].cpu().numpy(), rec['logits'][t], rtol=0, atol=2e-5, err_msg=f'logits step {t}')
+    if mode == 'RAW':
+        assert np.array_equal(out.cpu().numpy(), ref)
+    else:
+        assert np.abs(out.cpu().numpy() - ref).max() <= MOL_TOL
+
+
+@pytest.mark.parametrize('mode', ['MOL', 'RAW'])
+def test_step_ranges_continue_bit_exactly(gpu, mode):
+    """`wrnn_options.t_begin / t_end`: the loop run as three calls over [0, 200), [200, 201), [201, T), each with only its
+    own rows of noise, equals the single call bit for bit (the per-group state lives in the workspace between calls)."""
+    from wavernn_amd.engine import LoopEngine
+    cfg = dict(mode=mode, wseed=38, mseed=138, frames=60, batched=True, target=550, overlap=55, seed=98)
+    sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
+    eng = LoopEngine(sd, mode, device=gpu)
+    mu, au, nz = torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), torch.from_numpy(flat).to(gpu)
+    whole = eng.run(mu, au, B, T, stride, nz, 275, algo='loop', slab_steps=128).cpu().numpy()
+    out = None
+    for t0, t1 in ((0, 200), (200, 201), (201, T)):
+        out = eng.run(mu, au, B, T, stride, nz[t0:t1].contiguous(), 275, algo='loop', slab_steps=128, t_range=(t0, t1), out=out)
+    assert np.array_equal(out.cpu().numpy(), whole)
+    with pytest.raises(Exception):
+        eng.run(mu, au, B, T, stride, nz[:10].contiguous(), 275, algo='stream', t_range=(0, 10))
+
+
+def test_workspace_does_not_grow_with_steps(gpu):
+    """conditioning is produced in slabs, so the loop workspace for BASELINE config 4's whole corpus (942
+    segments x 12,100 steps) stays under 1 GB (it was 23 GB with the materialised cI) and does not depend on T."""
+    from wavernn_amd.engine import LoopEngine
+    from wavernn_amd.synthetic import random_state_dict
+    eng = LoopEngine(random_state_dict(0, mode='MOL'), 'MOL', device=gpu)
+    w = eng.workspace_bytes(942, 12100, 38358)
+    assert 0 < w < (1 << 30), w
+    assert eng.workspace_bytes(942, 121000, 38358) == w
+    assert eng.workspace_bytes(128, 12100, 5128) < (320 << 20)
+    print(f'workspace: 942 segments {w / 2**20:.0f} MiB, 128 segments {eng.workspace_bytes(128, 12100, 5128) / 2**20:.0f} MiB; '
+          f'plan {eng.plan(942, 12100)}')
+
+
 @pytest.mark.parametrize('variant', list(VARIANTS))
 @pytest.mark.parametrize('name', CASES)
-def test_loop_matches_reference_golden(gpu, name, variant, monkeypatch):
+def test_loop_matches_reference_golden(gpu, name, variant):
     """Free-running loop kernel vs the reference's own pre-decode [B,T] tensor (golden) and vs the C oracle."""
     from oracle import c_oracle as C
     from wavernn_amd.engine import LoopEngine
     cfg, g = load_case(name)
-    if cfg['mode'] == 'RAW' and _mol_only(variant):
-        pytest.skip('the U = 8 split / the pipelined kernel exist for MOL only')
-    algo = _select(monkeypatch, variant)
+    opts = VARIANTS[variant]
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     eng = LoopEngine(sd, cfg['mode'], device=gpu)
     out = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
-                  torch.from_numpy(flat).to(gpu), 275, algo=algo).cpu().numpy()
-    assert eng.last_loop_kernel() == KERNEL_NAME[algo]
-    if algo == 'cluster':
-        assert eng.last_loop_split()[0] == int(VARIANTS[variant][1]['WRNN_CLUSTER_U'])
-    if algo == 'pipe':
-        assert eng.last_loop_split()[2] == int(VARIANTS[variant][1]['WRNN_PIPE_G'])
+                  torch.from_numpy(flat).to(gpu), 275, **opts).cpu().numpy()
+    assert eng.last_loop_kernel() == KERNEL_NAME[opts['algo']]
+    if opts.get('depth'):
+        assert eng.last_loop_split()[2] == opts['depth']
     mels_f, aux_f, _ = __import__('oracle.wavernn_oracle', fromlist=['x']).conditioning(sd, mel, cfg['batched'], cfg['target'], cfg['overlap'])
     ref = C.loop(sd, cfg['mode'], mels_f, aux_f, noise)
     if cfg['mode'] == 'RAW':
@@ -115,24 +158,21 @@ def test_loop_matches_reference_golden(gpu, name, variant, monkeypatch):
         assert np.abs(out - ref).max() <= MOL_TOL
 
 
-@pytest.mark.parametrize('variant', ['stream', 'persist', 'cluster-u4', 'cluster-u8', 'pipe-g2'])
+@pytest.mark.parametrize('variant', ['stream', 'loop', 'loop-g2-slabs'])
 @pytest.mark.parametrize('name', ['raw_batched_60f', 'mol_batched_100f'])
-def test_teacher_forced_logits(gpu, name, variant, monkeypatch):
+def test_teacher_forced_logits(gpu, name, variant):
     """Feed the reference's samples back (teacher forcing) and compare every step's fc3 logits with the C
     oracle run the same way: isolates kernel arithmetic from chaotic divergence.  Tolerance 1e-4 abs on O(1) logits."""
     from oracle import c_oracle as C, wavernn_oracle as O
     from wavernn_amd.engine import LoopEngine
     cfg, g = load_case(name)
-    if cfg['mode'] == 'RAW' and _mol_only(variant):
-        pytest.skip('the U = 8 split / the pipelined kernel exist for MOL only')
-    algo = _select(monkeypatch, variant)
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     mels_f, aux_f, _ = O.conditioning(sd, mel, cfg['batched'], cfg['target'], cfg['overlap'])
     _, ref_logits = C.loop(sd, cfg['mode'], mels_f, aux_f, noise, want_logits=True)     # free run == golden path
     eng = LoopEngine(sd, cfg['mode'], device=gpu)
     out, logits = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
-                          torch.from_numpy(flat).to(gpu), 275, algo=algo, force_x=torch.from_numpy(g['raw']),
-                          want_logits=True)
+                          torch.from_numpy(flat).to(gpu), 275, force_x=torch.from_numpy(g['raw']),
+                          want_logits=True, **VARIANTS[variant])
     err = np.abs(logits.cpu().numpy() - ref_logits).max()
     assert err <= 1e-4, err
 
@@ -238,26 +278,22 @@ def test_generate_end_to_end(gpu, name, pre, tmp_path):
     assert np.array_equal(torch.empty(4).uniform_(0, 1).numpy(), st.uniform_(4, 0, 1))
 
 
-@pytest.mark.parametrize('variant', ['cluster-u2', 'cluster-u4', 'cluster-u8', 'cluster-u8-nl16', 'persist', 'pipe-g1', 'pipe-g2',
-                                     'pipe-g3', 'pipe-g3-nl8'])
+@pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'loop-c2-g2'])
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
-def test_many_segments_all_clusters(gpu, mode, variant, monkeypatch):
-    """46 folded segments (the last one zero-padded): 4 groups on the 4-cluster split, 4 groups = two per cluster on the
-    2-cluster split (run one after the other inside ONE launch), 3 launches for the chip-wide kernel -- against the
-    C oracle.  RAW bit-exact, MoL <= MOL_TOL."""
+def test_many_segments_all_clusters(gpu, mode, variant):
+    """46 folded segments (the last one zero-padded) = 3 groups: one per cluster, all three in flight on one cluster, two
+    rounds (clusters x depth < 3 groups), several conditioning slabs -- against the C oracle.  RAW bit-exact, MoL <= MOL_TOL."""
     from oracle import c_oracle as C, wavernn_oracle as O
     from wavernn_amd.engine import LoopEngine
-    if mode == 'RAW' and _mol_only(variant):
-        pytest.skip('the U = 8 split / the pipelined kernel exist for MOL only')
     cfg = dict(mode=mode, wseed=31, mseed=131, frames=100, batched=True, target=550, overlap=55, seed=91)
-    algo = _select(monkeypatch, variant)
+    opts = VARIANTS[variant]
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     assert (B, T) == (46, 660)
     mels_f, aux_f, _ = O.conditioning(sd, mel, True, cfg['target'], cfg['overlap'])
     ref = C.loop(sd, mode, mels_f, aux_f, noise)
     eng = LoopEngine(sd, mode, device=gpu)
     out = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
-                  torch.from_numpy(flat).to(gpu), 275, algo=algo).cpu().numpy()
+                  torch.from_numpy(flat).to(gpu), 275, **opts).cpu().numpy()
     if mode == 'RAW':
         bad = np.argwhere(out != ref)
         assert bad.size == 0, f'first divergence at (b,t)={bad[0]}'
@@ -265,35 +301,34 @@ def test_many_segments_all_clusters(gpu, mode, variant, monkeypatch):
         assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
 
 
-@pytest.mark.parametrize('variant', ['cluster-u8', 'pipe-g1', 'pipe-g2', 'pipe-g3'])
-def test_more_segments_than_slots(gpu, variant, monkeypatch):
-    """114 segments x 264 steps (MoL): more 16-segment groups than the 4 clusters hold at once, so the single-depth
-    kernels run two rounds back to back inside one launch (tags keep counting) and the deeper pipelines fill every
-    slot -- against the C oracle."""
+@pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3'])
+def test_more_segments_than_slots(gpu, variant):
+    """114 segments x 264 steps (MoL) = 8 groups: two rounds at depth 1 (state buffers per round), one round at depth 2,
+    three rounds of 3 on one cluster -- against the C oracle."""
     from oracle import c_oracle as C, wavernn_oracle as O
     from wavernn_amd.engine import LoopEngine
     cfg = dict(mode='MOL', wseed=32, mseed=132, frames=100, batched=True, target=220, overlap=22, seed=92)
-    algo = _select(monkeypatch, variant)
+    opts = VARIANTS[variant]
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     assert (B, T) == (114, 264)
     mels_f, aux_f, _ = O.conditioning(sd, mel, True, cfg['target'], cfg['overlap'])
     ref = C.loop(sd, 'MOL', mels_f, aux_f, noise)
     eng = LoopEngine(sd, 'MOL', device=gpu)
     out = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
-                  torch.from_numpy(flat).to(gpu), 275, algo=algo).cpu().numpy()
-    assert eng.last_loop_kernel() == KERNEL_NAME[algo]
+                  torch.from_numpy(flat).to(gpu), 275, **opts).cpu().numpy()
+    assert eng.last_loop_kernel() == KERNEL_NAME[opts['algo']]
+    print(variant, eng.last_run_info())
     assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
 
 
-@pytest.mark.parametrize('variant', ['stream', 'cluster-u4', 'cluster-u8', 'pipe-g2', 'pipe-g3'])
-def test_segment_table_several_utterances(gpu, variant, monkeypatch):
+@pytest.mark.parametrize('variant', ['stream', 'loop', 'loop-g2-slabs'])
+def test_segment_table_several_utterances(gpu, variant):
     """`run_segments`: three utterances of different length, conditioning concatenated, ONE launch -- every utterance's
     segments must equal that utterance generated alone (C oracle on its own folded conditioning)."""
     from oracle import c_oracle as C, wavernn_oracle as O
     from wavernn_amd.engine import LoopEngine
     from wavernn_amd.synthetic import random_state_dict, random_mel
     from wavernn_amd.batch import plan_utterances, pack_noise
-    algo = _select(monkeypatch, variant)
     mode, target, overlap, hop = 'MOL', 550, 55, 275
     sd = random_state_dict(41, mode=mode)
     frames = [23, 40, 31]
@@ -313,13 +348,13 @@ def test_segment_table_several_utterances(gpu, variant, monkeypatch):
     flat = pack_noise(mode, plan, [np.concatenate([a.reshape(plan.T, -1), b.reshape(plan.T, -1)], axis=1) for a, b in noises])
     eng = LoopEngine(sd, mode, device=gpu)
     out = eng.run_segments(torch.from_numpy(np.concatenate(ups)).to(gpu), torch.from_numpy(np.concatenate(auxs)).to(gpu),
-                           plan.seg_pos, plan.seg_lim, plan.T, torch.from_numpy(flat).to(gpu), hop, algo=algo).cpu().numpy()
+                           plan.seg_pos, plan.seg_lim, plan.T, torch.from_numpy(flat).to(gpu), hop, **VARIANTS[variant]).cpu().numpy()
     for u, ref in enumerate(refs):
         got = out[plan.first[u]:plan.first[u] + plan.folds[u]]
         assert np.abs(got - ref).max() <= MOL_TOL, (u, np.abs(got - ref).max())
 
 
-def test_hoisted_conditioning_mfma_equals_valu(gpu, monkeypatch):
+def test_hoisted_conditioning_mfma_equals_valu(gpu):
     """The MFMA form of the hoisted I-layer conditioning (cI) against the VALU fmaf chain it replaced: identical class
     indices in RAW, MoL samples within MOL_TOL (the MFMA's 4-term inner sum rounds differently from four chained fmas)."""
     from wavernn_amd.engine import LoopEngine
@@ -328,30 +363,25 @@ def test_hoisted_conditioning_mfma_equals_valu(gpu, monkeypatch):
         sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
         eng = LoopEngine(sd, mode, device=gpu)
         args = (torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride, torch.from_numpy(flat).to(gpu), 275)
-        monkeypatch.setenv('WRNN_COND', 'valu')
-        a = eng.run(*args, algo='cluster').cpu().numpy()
-        monkeypatch.delenv('WRNN_COND')
-        b = eng.run(*args, algo='cluster').cpu().numpy()
+        a = eng.run(*args, algo='stream', cond_valu=True).cpu().numpy()
+        b = eng.run(*args, algo='stream').cpu().numpy()
+        c = eng.run(*args, algo='loop').cpu().numpy()                 # ... and the fragment-order slab form of the loop kernel
+        assert (np.array_equal(b, c) if mode == 'RAW' else np.abs(b - c).max() <= MOL_TOL)
         if mode == 'RAW':
             assert np.array_equal(a, b), np.abs(a - b).max()
         else:
             assert np.abs(a - b).max() <= MOL_TOL, np.abs(a - b).max()
 
 
-@pytest.mark.parametrize('mode,variant', [('MOL', 'auto'), ('RAW', 'auto'), ('MOL', 'pipe-g2')])
-def test_block_sparse_gru_weights(gpu, mode, variant, monkeypatch):
+@pytest.mark.parametrize('mode,variant', [('MOL', 'auto'), ('RAW', 'auto'), ('MOL', 'loop')])
+def test_block_sparse_gru_weights(gpu, mode, variant):
     """BASELINE config 5: the GRU matrices block-pruned to 95 % zeros (16x1 blocks, per gate) run through the dense HIP
     kernels as masked weights and must equal the oracle on the same pruned weights."""
     from oracle import c_oracle as C, wavernn_oracle as O
     from wavernn_amd.engine import LoopEngine
     from wavernn_amd.prune import block_prune_state_dict
     from wavernn_amd.synthetic import random_state_dict
-    if variant == 'auto':
-        for k in ENV_KEYS:
-            monkeypatch.delenv(k, raising=False)
-        algo = 'auto'
-    else:
-        algo = _select(monkeypatch, variant)
+    algo = variant
     cfg = dict(mode=mode, wseed=33, mseed=133, frames=100, batched=True, target=550, overlap=55, seed=93)
     sd0, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     sd, density = block_prune_state_dict(sd0, 0.95, (16, 1))
@@ -371,17 +401,13 @@ def test_block_sparse_gru_weights(gpu, mode, variant, monkeypatch):
 
 
 @pytest.mark.parametrize('frames,target,overlap,g', [(100, 550, 55, 0), (100, 220, 22, 1), (100, 220, 22, 2), (300, 220, 22, 0)])
-def test_block_sparse_kernel_matches_oracle(gpu, frames, target, overlap, g, monkeypatch):
+def test_block_sparse_kernel_matches_oracle(gpu, frames, target, overlap, g):
     """`WRNN_ALGO_SPARSE` (packed 16x1 blocks, gathered B fragments, 8 XCD-local clusters) on 95 %-pruned GRU weights vs the
     C oracle running the same weights as masked dense matrices: 46 / 114 / 341 segments (one and two rounds, one and two
     groups in flight).  MoL tolerance (the surviving terms are summed in a different order)."""
     from oracle import c_oracle as C, wavernn_oracle as O
     from wavernn_amd.engine import LoopEngine
     from wavernn_amd.prune import block_prune_state_dict
-    for k in ENV_KEYS:
-        monkeypatch.delenv(k, raising=False)
-    if g:
-        monkeypatch.setenv('WRNN_SPARSE_G', str(g))
     cfg = dict(mode='MOL', wseed=35, mseed=135, frames=frames, batched=True, target=target, overlap=overlap, seed=95)
     sd0, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     sd, _ = block_prune_state_dict(sd0, 0.95, (16, 1))
@@ -394,7 +420,7 @@ def test_block_sparse_kernel_matches_oracle(gpu, frames, target, overlap, g, mon
     with pytest.raises(Exception):
         dense.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride, torch.from_numpy(flat).to(gpu), 275, algo='sparse')
     out = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
-                  torch.from_numpy(flat).to(gpu), 275, algo='sparse').cpu().numpy()
+                  torch.from_numpy(flat).to(gpu), 275, algo='sparse', depth=g).cpu().numpy()
     assert eng.last_loop_kernel() == 'wrnn_sparse_kernel' and eng.last_loop_split()[:2] == (16, 8)
     assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
 
@@ -476,13 +502,11 @@ def test_config4_corpus_size_on_one_gpu(gpu):
     assert all(np.array_equal(a, b) for a, b in zip(again, again2))
 
 
-def test_full_size_pipelined_kernel_vs_stream(gpu, monkeypatch):
-    """Bench geometry (128 segments x 12,100 steps, MoL): the pipelined kernel (auto pick) agrees with the stream kernel
+def test_full_size_loop_kernel_vs_stream(gpu):
+    """Bench geometry (128 segments x 12,100 steps, MoL): the loop kernel (auto pick) agrees with the stream kernel
     (no inter-workgroup traffic at all) within MOL_TOL over the whole free run, and is deterministic."""
     from wavernn_amd.engine import LoopEngine
     from wavernn_amd.synthetic import random_state_dict
-    for k in ENV_KEYS:
-        monkeypatch.delenv(k, raising=False)
     sd = random_state_dict(0, mode='MOL')
     rs = np.random.RandomState(4)
     hop, target, overlap, B = 275, 11000, 550, 128
@@ -493,18 +517,19 @@ def test_full_size_pipelined_kernel_vs_stream(gpu, monkeypatch):
     noise = torch.empty(T, 11 * B).uniform_(1e-5, 1 - 1e-5, generator=torch.Generator().manual_seed(6)).to(gpu)
     eng = LoopEngine(sd, 'MOL', device=gpu)
     a = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='auto').cpu().numpy()
-    assert eng.last_loop_kernel() == 'wrnn_pipe_kernel' and eng.last_loop_split() == (8, 4, 2)
+    assert eng.last_loop_kernel() == 'wrnn_loop_kernel' and eng.last_loop_split() == (16, 4, 2)
     ms = eng.last_loop_ms()
+    print(eng.last_run_info())
     b = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='auto').cpu().numpy()
     s = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='stream').cpu().numpy()
-    print(f'pipelined loop {ms:.1f} ms for {B}x{T} segment-steps ({B * T / ms / 1e3:.2f} M/s); stream {eng.last_loop_ms():.1f} ms')
-    assert np.array_equal(a, b), 'pipelined kernel is not deterministic'
+    print(f'loop kernel {ms:.1f} ms for {B}x{T} segment-steps ({B * T / ms / 1e3:.2f} M/s); stream {eng.last_loop_ms():.1f} ms')
+    assert np.array_equal(a, b), 'loop kernel is not deterministic'
     assert np.abs(a).max() <= 1.0 and np.abs(a - s).max() <= MOL_TOL, np.abs(a - s).max()
 
 
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_full_size_properties(gpu, mode):
-    """BASELINE config 2 geometry (B=12, T=12100): cluster and stream kernels agree, runs are deterministic,
+    """BASELINE config 2 geometry (B=12, T=12100): loop and stream kernels agree, runs are deterministic,
     samples stay in [-1,1] (RAW: on the 512-level grid)."""
     from wavernn_amd.engine import LoopEngine
     from wavernn_amd.synthetic import random_state_dict
@@ -525,14 +550,14 @@ def test_full_size_properties(gpu, mode):
     ms, split = eng.last_loop_ms(), eng.last_loop_split()
     b = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='auto').cpu().numpy()
     s = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='stream').cpu().numpy()
-    print(f'{mode} cluster loop (split {split}) {ms:.1f} ms for {B}x{T} segment-steps; stream {eng.last_loop_ms():.1f} ms')
-    assert np.array_equal(a, b), 'persistent kernel is not deterministic'
+    print(f'{mode} loop kernel (split {split}) {ms:.1f} ms for {B}x{T} segment-steps; stream {eng.last_loop_ms():.1f} ms')
+    assert np.array_equal(a, b), 'loop kernel is not deterministic'
     assert np.abs(a).max() <= 1.0
     if mode == 'RAW':
         lv = (a + 1.0) * 511.0 / 2.0
         assert np.abs(lv - np.round(lv)).max() < 1e-3
         bad = np.argwhere(a != s)
-        assert bad.size == 0, f'persist vs stream first divergence at {bad[0]}'
+        assert bad.size == 0, f'loop vs stream first divergence at {bad[0]}'
     else:
         assert np.abs(a - s).max() <= MOL_TOL
 

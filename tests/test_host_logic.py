@@ -23,7 +23,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.wrnn_abi_version() == 2
+    assert L.wrnn_abi_version() == 3
     # no GPU here: compute entry points must fail loudly, never fall back to the host
     if not torch.cuda.is_available():
         assert L.wrnn_device_cus(0) < 0
@@ -167,8 +167,8 @@ def test_header_is_plain_c(tmp_path):
         pytest.skip('gcc not available')
     src = tmp_path / 'use_header.c'
     src.write_text('#include "wavernn_amd.h"\n'
-                   'int probe(void) { wrnn_weights w; wrnn_geometry g; wrnn_debug d; wrnn_pre_weights p;\n'
-                   '  (void)w; (void)g; (void)d; (void)p;\n'
+                   'int probe(void) { wrnn_weights w; wrnn_geometry g; wrnn_options o; wrnn_run_info ri; wrnn_pre_weights p;\n'
+                   '  (void)w; (void)g; (void)o; (void)ri; (void)p;\n'
                    '  return WRNN_ABI_VERSION + WRNN_OK + WRNN_MODE_MOL + WRNN_ALGO_SPARSE + (int)sizeof(wrnn_pre_weights); }\n')
     res = subprocess.run(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-fsyntax-only', '-I', os.path.join(ROOT, 'include'), str(src)],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -13,15 +13,15 @@ SO_PATH = os.path.join(CSRC, 'libwavernn_amd.so')
 
 WRNN_OK = 0
 MODE_RAW, MODE_MOL = 0, 1
-ALGO_AUTO, ALGO_STREAM, ALGO_PERSIST, ALGO_CLUSTER, ALGO_PIPE, ALGO_SPARSE = 0, 1, 2, 3, 4, 5
-ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'persist': ALGO_PERSIST, 'cluster': ALGO_CLUSTER, 'pipe': ALGO_PIPE,
-         'sparse': ALGO_SPARSE}
+ABI_VERSION = 3
+ALGO_AUTO, ALGO_STREAM, ALGO_LOOP, ALGO_SPARSE = 0, 1, 2, 5
+ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'loop': ALGO_LOOP, 'sparse': ALGO_SPARSE}
 
 #: every symbol include/wavernn_amd.h declares
 EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_create', 'wrnn_pack_destroy',
            'wrnn_pack_weight_bytes', 'wrnn_pack_sparse_blocks', 'wrnn_workspace_bytes', 'wrnn_workspace_bytes_segments', 'wrnn_generate',
-           'wrnn_generate_segments', 'wrnn_status', 'wrnn_last_loop_ms', 'wrnn_last_loop_kernel',
-           'wrnn_last_loop_split', 'wrnn_profile_read', 'wrnn_selftest', 'wrnn_selftest_metric', 'wrnn_pre_create',
+           'wrnn_generate_segments', 'wrnn_plan_segments', 'wrnn_status', 'wrnn_timer_create', 'wrnn_timer_destroy', 'wrnn_timer_ms',
+           'wrnn_timer_launches', 'wrnn_debug_read_exchange', 'wrnn_selftest', 'wrnn_selftest_metric', 'wrnn_pre_create',
            'wrnn_pre_destroy', 'wrnn_pre_hop', 'wrnn_pre_workspace_bytes', 'wrnn_pre_upsample', 'wrnn_pre_last_error',
            'wrnn_post_unfold', 'wrnn_post_last_error']
 
@@ -42,8 +42,21 @@ class Geometry(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('B', 'T', 'stride', 'L', 'hop', 'n_frames')]
 
 
-class Debug(ctypes.Structure):
-    _fields_ = [('force_x', ctypes.c_void_p), ('logits', ctypes.c_void_p)]
+class RunInfo(ctypes.Structure):
+    _fields_ = [('kernel', ctypes.c_char_p)] + \
+               [(n, ctypes.c_int32) for n in ('units_per_wg', 'clusters', 'depth', 'rounds', 'slab_steps', 'launches')]
+
+
+class Options(ctypes.Structure):
+    """wrnn_options (include/wavernn_amd.h): per-call options; nothing is read from the environment."""
+    _fields_ = [(n, ctypes.c_int32) for n in ('struct_bytes', 'algo', 'depth', 'clusters', 'cond_valu', 'slab_steps', 't_begin',
+                                              't_end', 'reserved')] + \
+               [('force_x', ctypes.c_void_p), ('logits', ctypes.c_void_p), ('timer', ctypes.c_void_p),
+                ('info', ctypes.POINTER(RunInfo))]
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.struct_bytes = ctypes.sizeof(Options)
 
 
 class WrnnError(RuntimeError):
@@ -87,19 +100,28 @@ def lib():
     L.wrnn_pack_weight_bytes.argtypes = [ctypes.c_void_p]
     L.wrnn_pack_weight_bytes.restype = ctypes.c_size_t
     L.wrnn_pack_sparse_blocks.argtypes = [ctypes.c_void_p]
-    L.wrnn_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.POINTER(Geometry)]
+    L.wrnn_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.POINTER(Geometry), ctypes.POINTER(Options)]
     L.wrnn_workspace_bytes.restype = ctypes.c_size_t
     L.wrnn_generate.argtypes = [ctypes.c_void_p, ctypes.POINTER(Geometry), ctypes.c_void_p, ctypes.c_void_p,
-                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
-                                ctypes.POINTER(Debug), ctypes.c_void_p]
-    L.wrnn_workspace_bytes_segments.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(Options),
+                                ctypes.c_void_p]
+    L.wrnn_workspace_bytes_segments.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.POINTER(Options)]
     L.wrnn_workspace_bytes_segments.restype = ctypes.c_size_t
     L.wrnn_generate_segments.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
-                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
-                                         ctypes.POINTER(Debug), ctypes.c_void_p]
-    L.wrnn_last_loop_split.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
-                                       ctypes.POINTER(ctypes.c_int)]
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                         ctypes.POINTER(Options), ctypes.c_void_p]
+    L.wrnn_plan_segments.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(Options), ctypes.POINTER(RunInfo)]
+    L.wrnn_timer_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.wrnn_timer_destroy.argtypes = [ctypes.c_void_p]
+    L.wrnn_timer_destroy.restype = None
+    L.wrnn_timer_ms.argtypes = [ctypes.c_void_p]
+    L.wrnn_timer_ms.restype = ctypes.c_float
+    L.wrnn_timer_launches.argtypes = [ctypes.c_void_p]
+    L.wrnn_debug_read_exchange.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.POINTER(Options), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_void_p]
     L.wrnn_pre_create.argtypes = [ctypes.POINTER(PreWeights), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     L.wrnn_pre_destroy.argtypes = [ctypes.c_void_p]
     L.wrnn_pre_destroy.restype = None
@@ -113,12 +135,7 @@ def lib():
                                    ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                    ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     L.wrnn_post_last_error.restype = ctypes.c_char_p
-    L.wrnn_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.wrnn_status.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    L.wrnn_last_loop_ms.argtypes = [ctypes.c_void_p]
-    L.wrnn_last_loop_ms.restype = ctypes.c_float
-    L.wrnn_last_loop_kernel.argtypes = [ctypes.c_void_p]
-    L.wrnn_last_loop_kernel.restype = ctypes.c_char_p
     L.wrnn_selftest.argtypes = [ctypes.c_int, ctypes.c_int]
     L.wrnn_selftest_metric.restype = ctypes.c_float
     _lib = L

@@ -104,8 +104,29 @@ def pack_noise(mode: str, plan: Plan, per_utt, lo: int = 0, hi: Optional[int] = 
     return out.contiguous() if is_torch else np.ascontiguousarray(out)
 
 
+def chunk_utterances(plan: Plan, lo: int, hi: int, max_segments: int):
+    """Cut the utterances that own segments in [lo, hi) into consecutive chunks whose segment count in [lo, hi) stays
+    <= max_segments (a single longer utterance makes its own chunk).  Returns [(utterances, seg_lo, seg_hi)]."""
+    chunks, cur, cur_lo, cur_hi = [], [], None, None
+    for u in range(len(plan.lengths)):
+        a, b = max(lo, int(plan.first[u])), min(hi, int(plan.first[u] + plan.folds[u]))
+        if a >= b:
+            continue
+        if cur and (b - cur_lo) > max_segments:
+            chunks.append((cur, cur_lo, cur_hi))
+            cur, cur_lo = [], None
+        if cur_lo is None:
+            cur_lo = a
+        cur.append(u)
+        cur_hi = b
+    if cur:
+        chunks.append((cur, cur_lo, cur_hi))
+    return chunks
+
+
 def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bool, seeds: Optional[Sequence[int]] = None,
-                    group=None, loop_fn=None, return_segments=False, noise_source='cpu', finish='all', check=True):
+                    group=None, loop_fn=None, return_segments=False, noise_source='cpu', finish='all', check=True,
+                    max_segments_per_launch: int = 4096):
     """Generate every utterance of `mels` (each (1, feat, N_u) or (feat, N_u)) with `model` (a `wavernn_amd.WaveRNN`),
     batched, sharding the folded segments over the ranks of `group` (None = single process).
 
@@ -117,11 +138,18 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
     runs on a GPU; not comparable with a CPU run; `seeds` unused).  finish='all': every rank unfolds every utterance;
     'own': a rank unfolds only the utterances whose first segment lies in its block (None elsewhere in the list).
 
+    The rank's block is processed in chunks of whole utterances of at most `max_segments_per_launch` segments, so the
+    conditioning (320 B per audio sample) and the sampling noise of only one chunk are resident at a time; the loop's own
+    workspace does not grow with the corpus (conditioning slabs, `wrnn_workspace_bytes_segments`).
+
     loop_fn(mels_up, aux, seg_pos, seg_lim, T, noise, hop) -> (n, T) tensor replaces the HIP loop (tests inject a CPU
     stand-in to exercise the sharding / gather logic under gloo); the default is the model's LoopEngine.
     """
     import torch.distributed as dist
     from .rng import draw_noise
+    if noise_source == 'cpu' and seeds is None:
+        raise ValueError("noise_source='cpu' (parity noise) needs `seeds` (one per utterance); "
+                         "pass noise_source='device' to draw from the device generator instead")
     world = dist.get_world_size(group) if group is not None else 1
     rank = dist.get_rank(group) if group is not None else 0
     device = next(model.parameters()).device
@@ -138,36 +166,44 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
     n_max = max(h - l for l, h in shard_bounds(plan.n_segments, world))
 
     out_local = torch.zeros(n_max, plan.T, dtype=torch.float32, device=device)
-    if hi > lo:
-        mine = [u for u in range(len(mels)) if plan.first[u] < hi and plan.first[u] + plan.folds[u] > lo]
-        with torch.no_grad():
-            ups, auxs, noise = [], [], [None] * len(mels)
+    native_pre = loop_fn is None and getattr(model, 'pre_algo', 'torch') == 'native' and device.type == 'cuda'
+    with torch.no_grad():
+        for utts, clo, chi in (chunk_utterances(plan, lo, hi, max_segments_per_launch) if hi > lo else []):
+            # conditioning of the utterances this chunk touches, concatenated (each starts on a frame boundary)
+            noise = [None] * len(mels)
             local_off, off = {}, 0
-            for u in mine:                                   # only the utterances this block touches
-                mu, au, _ = model.conditioning(mels[u])
-                ups.append(mu)
-                auxs.append(au)
+            for u in utts:
                 local_off[u] = off
-                off += mu.size(0)
-                if noise_source == 'cpu':
+                off += frames[u] * hop
+            if native_pre:     # the pre-loop kernels write straight into their slices of the concatenated buffers
+                mels_up = torch.empty(off, mels[utts[0]].size(1), dtype=torch.float32, device=device)
+                aux = torch.empty(off // hop, 4 * model.aux_dims, dtype=torch.float32, device=device)
+                pre = model._pre_engine()
+                for u in utts:
+                    a0 = local_off[u]
+                    pre.upsample(mels[u].to(device).float(), mels_up=mels_up[a0:a0 + frames[u] * hop], aux=aux[a0 // hop:a0 // hop + frames[u]])
+            else:
+                ups, auxs = zip(*[model.conditioning(mels[u])[:2] for u in utts])
+                mels_up, aux = torch.cat(ups).contiguous(), torch.cat(auxs).contiguous()
+            if noise_source == 'cpu':
+                for u in utts:
                     g = torch.Generator(device='cpu').manual_seed(int(seeds[u]))
                     noise[u] = draw_noise(mode, int(plan.folds[u]), plan.T, model.n_classes, model.rnn_dims, model.aux_dims,
                                           'cpu', 'cpu', generator=g)
-            mels_up, aux = torch.cat(ups).contiguous(), torch.cat(auxs).contiguous()
-            # this block's segment table, rebased onto the conditioning of the utterances it touches
-            rebase = np.array([local_off[int(u)] - int(plan.offsets[int(u)]) for u in plan.seg_utt[lo:hi]], dtype=np.int64)
-            seg_pos = (plan.seg_pos[lo:hi].astype(np.int64) + rebase).astype(np.int32)
-            seg_lim = (plan.seg_lim[lo:hi].astype(np.int64) + rebase).astype(np.int32)
+            # this chunk's segment table, rebased onto the conditioning of the utterances it touches
+            rebase = np.array([local_off[int(u)] - int(plan.offsets[int(u)]) for u in plan.seg_utt[clo:chi]], dtype=np.int64)
+            seg_pos = (plan.seg_pos[clo:chi].astype(np.int64) + rebase).astype(np.int32)
+            seg_lim = (plan.seg_lim[clo:chi].astype(np.int64) + rebase).astype(np.int32)
             if noise_source == 'cpu':
-                nz = pack_noise(mode, plan, noise, lo, hi).to(device)
+                nz = pack_noise(mode, plan, noise, clo, chi).to(device)
             else:
-                nz = draw_noise(mode, hi - lo, plan.T, model.n_classes, model.rnn_dims, model.aux_dims, device, 'device')
+                nz = draw_noise(mode, chi - clo, plan.T, model.n_classes, model.rnn_dims, model.aux_dims, device, 'device')
             if loop_fn is None:
                 eng = model._loop_engine()
-                res = eng.run_segments(mels_up, aux, seg_pos, seg_lim, plan.T, nz, hop, algo=model.loop_algo, check=check)
+                eng.run_segments(mels_up, aux, seg_pos, seg_lim, plan.T, nz, hop, algo=model.loop_algo, check=check,
+                                 out=out_local[clo - lo:chi - lo])
             else:
-                res = loop_fn(mels_up, aux, seg_pos, seg_lim, plan.T, nz, hop)
-            out_local[:hi - lo] = res
+                out_local[clo - lo:chi - lo] = loop_fn(mels_up, aux, seg_pos, seg_lim, plan.T, nz, hop)
     if world > 1:
         gathered = [torch.empty_like(out_local) for _ in range(world)]
         dist.all_gather(gathered, out_local, group=group)    # the ONE collective of the path: finished audio only

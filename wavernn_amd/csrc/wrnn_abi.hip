@@ -12,18 +12,17 @@
 #include "wrnn_device.h"
 
 namespace wrnn {
-hipError_t launch_cond(const CondArgs &a, int n_cus, hipStream_t stream);
+hipError_t launch_cond(const CondArgs &a, int n_cus, bool valu, hipStream_t stream);
+hipError_t launch_cond_frames(const CondArgs &a, hipStream_t stream);
+hipError_t launch_cond_frag(const CondArgs &a, int n_cus, hipStream_t stream);
 hipError_t launch_noise_mol(const float *in, float *out, long n, int B, int n_cus, hipStream_t stream);
 hipError_t launch_stream(const LoopArgs &args, int mode, hipStream_t stream);
-hipError_t launch_persist(const LoopArgs &args, int U, int mode, hipStream_t stream);
-hipError_t launch_cluster(const LoopArgs &args, int U, int ncl, int mode, int nl, hipStream_t stream);
-int cluster_count(int U, int n_cus);
-hipError_t launch_pipe(const LoopArgs &args, int G, int ncl, int nl, hipStream_t stream);
-int pipe_rows(int G);
-int pipe_clusters(int n_cus);
+hipError_t launch_loop(const LoopArgs &args, int ncl, int mode, hipStream_t stream);
+int loop_max_depth(int mode);
+int loop_clusters(int n_cus);
+size_t loop_state_floats(int G);
 hipError_t launch_sparse(const LoopArgs &args, int G, int ncl, int nbp, hipStream_t stream);
 int sparse_clusters(int n_cus);
-size_t persist_lds_bytes();
 int selftest_mfma(char *msg, size_t n);
 int selftest_allgather(int n_cus, char *msg, size_t n, float *us_per_round);
 }  // namespace wrnn
@@ -57,10 +56,6 @@ struct wrnn_pack {
     const float *w_ih1, *w_hh1, *b_ih1, *b_hh1, *w_ih2, *w_hh2, *b_ih2, *b_hh2;
     const float *fc1_w, *fc1_b, *fc2_w, *fc2_b, *fc3_w, *fc3_b;
     const float *w_ih1T, *w_hh1T, *w_ih2T, *w_hh2T, *fc1T, *fc2T, *fc3T, *c2_wT, *c3_wT, *c4_wT;
-    hipEvent_t ev0, ev1;
-    bool timed;
-    const char *last_kernel;
-    int last_U, last_ncl, last_G;
     int sp_nbp;                // 0 = the GRU matrices are not block-sparse enough for wrnn_sparse_kernel; else 48 / 64
     int sp_max_blocks;
     const float *sp_vals;
@@ -208,11 +203,6 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     p->sp_nbp = sp_nbp; p->sp_max_blocks = sp_max;
     p->sp_vals = sp_nbp ? base + o_spv : nullptr;
     p->sp_cols = sp_nbp ? reinterpret_cast<const int *>(base + o_spc) : nullptr;
-    HIPCHK(hipEventCreate(&p->ev0));
-    HIPCHK(hipEventCreate(&p->ev1));
-    p->timed = false;
-    p->last_kernel = "";
-    p->last_U = 0; p->last_ncl = 0; p->last_G = 0;
     *out = p;
     return WRNN_OK;
 }
@@ -220,8 +210,6 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
 extern "C" void wrnn_pack_destroy(wrnn_pack *p)
 {
     if (!p) return;
-    (void)hipEventDestroy(p->ev0);
-    (void)hipEventDestroy(p->ev1);
     (void)hipFree(p->dev);
     delete p;
 }
@@ -230,25 +218,178 @@ extern "C" size_t wrnn_pack_weight_bytes(const wrnn_pack *p) { return p ? p->wei
 
 extern "C" int wrnn_pack_sparse_blocks(const wrnn_pack *p) { return p ? (p->sp_nbp ? p->sp_max_blocks : -p->sp_max_blocks) : 0; }
 
+struct wrnn_timer {
+    int device;
+    std::vector<hipEvent_t> ev;     // pairs (start, stop), grown on demand and reused
+    int used;                       // events recorded by the last call
+};
+
+extern "C" int wrnn_timer_create(int device, wrnn_timer **out)
+{
+    if (!out) { set_err("NULL argument"); return WRNN_ERR_ARG; }
+    const int cus = wrnn_device_cus(device);
+    if (cus < 0) return cus;
+    wrnn_timer *t = new wrnn_timer();
+    t->device = device;
+    t->used = 0;
+    *out = t;
+    return WRNN_OK;
+}
+
+extern "C" void wrnn_timer_destroy(wrnn_timer *t)
+{
+    if (!t) return;
+    for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
+    delete t;
+}
+
+extern "C" int wrnn_timer_launches(const wrnn_timer *t) { return t ? t->used / 2 : 0; }
+
+extern "C" float wrnn_timer_ms(wrnn_timer *t)
+{
+    if (!t || t->used < 2) return -1.f;
+    float total = 0.f;
+    for (int i = 0; i + 1 < t->used; i += 2) {
+        if (hipEventSynchronize(t->ev[i + 1]) != hipSuccess) return -1.f;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t->ev[i], t->ev[i + 1]) != hipSuccess) return -1.f;
+        total += ms;
+    }
+    return total;
+}
+
 namespace {
+int timer_mark(wrnn_timer *t, hipStream_t stream)
+{
+    if (!t) return WRNN_OK;
+    if (t->used == (int)t->ev.size()) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        t->ev.push_back(e);
+    }
+    HIPCHK(hipEventRecord(t->ev[t->used], stream));
+    t->used += 1;
+    return WRNN_OK;
+}
+
+enum Kind { K_STREAM, K_LOOP, K_SPARSE };
+
+// what a call will run: kernel, split, rounds, slab length
+struct Plan {
+    Kind kind;
+    int ncl, G, rounds, per_round, slab, ngr_max;
+    int t0, t1;
+};
+
 struct WsLayout {
-    size_t status, prof, gran, segs, c2f, c3f, c4f, cI, npre, total;
+    size_t status, segs, c2f, c3f, c4f;
+    size_t gran, cI, npre;              // stream / sparse kernels: granules, whole-T conditioning, derived MOL noise
+    size_t xbuf, state, cIf;            // loop kernel: exchange buffer, per-round state, conditioning slab
+    size_t total;
 };
 constexpr size_t GRAN_BYTES = (size_t)GRAN_WORDS * sizeof(u64);
 size_t al(size_t x) { return (x + 255) / 256 * 256; }
-WsLayout ws_layout(int B, int T, int n_frames, bool mol = true)
+
+const wrnn_options *norm_options(const wrnn_options *opt, wrnn_options *tmp)
+{
+    memset(tmp, 0, sizeof *tmp);
+    if (opt) {
+        size_t n = opt->struct_bytes > 0 ? (size_t)opt->struct_bytes : sizeof *tmp;
+        if (n > sizeof *tmp) n = sizeof *tmp;
+        memcpy(tmp, opt, n);
+    }
+    tmp->struct_bytes = (int32_t)sizeof *tmp;
+    return tmp;
+}
+
+// kernel choice: sparse if the pack qualifies, else the loop kernel (RAW with 512 classes or MOL, >= 64 CUs), else stream
+int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
+{
+    const bool shape_ok = (p->mode == WRNN_MODE_MOL) || (p->C == H);
+    pl->t0 = o->t_begin; pl->t1 = o->t_end;
+    if (pl->t0 == 0 && pl->t1 == 0) pl->t1 = T;
+    if (pl->t0 < 0 || pl->t1 > T || pl->t0 >= pl->t1) { set_err("bad step range [%d, %d) of T=%d", pl->t0, pl->t1, T); return WRNN_ERR_ARG; }
+    const int algo = o->algo;
+    if (algo != WRNN_ALGO_AUTO && algo != WRNN_ALGO_STREAM && algo != WRNN_ALGO_LOOP && algo != WRNN_ALGO_SPARSE) {
+        set_err("unknown algo %d", algo);
+        return WRNN_ERR_ARG;
+    }
+    const int groups = (B + SEG - 1) / SEG;
+    pl->kind = K_STREAM; pl->ncl = 0; pl->G = 0; pl->rounds = 1; pl->per_round = B; pl->slab = T; pl->ngr_max = groups;
+    if (algo == WRNN_ALGO_SPARSE || (algo == WRNN_ALGO_AUTO && p->sp_nbp && sparse_clusters(p->n_cus) >= 1)) {
+        const int scl = sparse_clusters(p->n_cus);
+        if (!p->sp_nbp || scl < 1) {
+            set_err("block-sparse kernel needs MOL, >= 32 CUs and GRU matrices with <= 64 surviving 16x1 blocks per block row "
+                    "(this pack: up to %d)", p->sp_max_blocks);
+            return WRNN_ERR_ARG;
+        }
+        int g = o->depth;
+        if (g < 1 || g > SPG) g = groups > scl ? 2 : 1;
+        pl->kind = K_SPARSE; pl->ncl = scl; pl->G = g;
+        pl->rounds = (groups + scl * g - 1) / (scl * g);
+        if ((double)pl->rounds * T >= 4.0e9) { set_err("too many steps"); return WRNN_ERR_ARG; }
+    } else if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_LOOP) {
+        int ncl = loop_clusters(p->n_cus);
+        if (shape_ok && ncl >= 1) {
+            if (o->clusters == 1 || o->clusters == 2 || o->clusters == 4) ncl = o->clusters < ncl ? o->clusters : ncl;
+            else if (groups < ncl) { int c2 = 1; while (c2 < groups) c2 *= 2; if (c2 < ncl) ncl = c2; }   // no more clusters than groups (rounded up to 1, 2, 4)
+            const int gmax = loop_max_depth(p->mode);
+            int g = o->depth;
+            if (g < 1 || g > gmax) {
+                // as deep as the segments fill evenly: rounds = ceil(groups / (ncl * gmax)), then the shallowest depth that
+                // still needs only that many rounds (deeper pipelines hide the exchange latency; empty slots cost nothing)
+                const int rounds = (groups + ncl * gmax - 1) / (ncl * gmax);
+                g = (groups + ncl * rounds - 1) / (ncl * rounds);
+                if (g < 1) g = 1;
+                if (g > gmax) g = gmax;
+            }
+            pl->kind = K_LOOP; pl->ncl = ncl; pl->G = g;
+            pl->rounds = (groups + ncl * g - 1) / (ncl * g);
+            // balanced rounds of whole segments; every round is cut into <= ncl * g groups of <= 16
+            pl->per_round = (B + pl->rounds - 1) / pl->rounds;
+            pl->ngr_max = (pl->per_round + SEG - 1) / SEG;
+            if (pl->ngr_max > ncl * g) { pl->rounds += 1; pl->per_round = (B + pl->rounds - 1) / pl->rounds; pl->ngr_max = (pl->per_round + SEG - 1) / SEG; }
+            int slab = o->slab_steps;
+            if (slab < 1) {
+                slab = (int)((96u << 20) / ((size_t)pl->ngr_max * SEG * H * sizeof(float)));
+                if (slab < 16) slab = 16;
+                if (slab > 1024) slab = 1024;
+            }
+            if (slab > T) slab = T;
+            pl->slab = slab;
+        } else if (algo == WRNN_ALGO_LOOP) {
+            set_err("the loop kernel needs >= 64 CUs and (MOL or RAW with 512 classes); device has %d CUs, C=%d", p->n_cus, p->C);
+            return WRNN_ERR_RESIDENCY;
+        }
+    }
+    if (pl->kind != K_LOOP && (pl->t0 != 0 || pl->t1 != T)) {
+        set_err("a partial step range [%d, %d) needs the loop kernel", pl->t0, pl->t1);
+        return WRNN_ERR_ARG;
+    }
+    return WRNN_OK;
+}
+
+WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frames)
 {
     WsLayout l;
+    memset(&l, 0, sizeof l);
     size_t o = 0;
     l.status = o; o = al(o + STATUS_WORDS * sizeof(unsigned));
-    l.prof = o;   o = al(o + (size_t)MAXWG * NPROF * sizeof(u64));     // fixed offset: wrnn_profile_read finds it
-    l.gran = o;   o = al(o + GRAN_BYTES);
     l.segs = o;   o = al(o + (size_t)2 * B * sizeof(int));
     l.c2f = o;    o = al(o + (size_t)(n_frames + 1) * 3 * H * sizeof(float));
     l.c3f = o;    o = al(o + (size_t)(n_frames + 1) * H * sizeof(float));
     l.c4f = o;    o = al(o + (size_t)(n_frames + 1) * H * sizeof(float));
-    l.cI = o;     o = al(o + (size_t)T * B * H * sizeof(float));
-    l.npre = o;   if (mol) o = al(o + (size_t)T * 11 * B * sizeof(float));   // derived MOL noise (pipelined kernel)
+    const bool mol = p->mode == WRNN_MODE_MOL;
+    if (pl.kind == K_LOOP) {
+        l.xbuf = o;  o = al(o + XBUF_FLOATS * sizeof(float));
+        l.state = o; o = al(o + (size_t)pl.rounds * loop_state_floats(pl.G) * sizeof(float));
+        l.cIf = o;   o = al(o + (size_t)pl.slab * pl.ngr_max * SEG * H * sizeof(float));
+        l.npre = o;  if (mol) o = al(o + (size_t)pl.slab * 11 * B * sizeof(float));      // derived MOL noise of one slab
+    } else {
+        l.gran = o;  o = al(o + GRAN_BYTES);
+        l.cI = o;    o = al(o + (size_t)T * B * H * sizeof(float));
+        l.npre = o;  if (mol && pl.kind == K_SPARSE) o = al(o + (size_t)T * 11 * B * sizeof(float));
+    }
     l.total = o;
     return l;
 }
@@ -280,34 +421,69 @@ int check_segments(int B, int T, const int32_t *seg_pos, const int32_t *seg_lim,
 }
 }  // namespace
 
-extern "C" size_t wrnn_workspace_bytes(const wrnn_pack *p, const wrnn_geometry *g)
-{
-    if (!p || check_geometry(g) != WRNN_OK) return 0;
-    return ws_layout(g->B, g->T, g->n_frames).total;
-}
-
-extern "C" size_t wrnn_workspace_bytes_segments(const wrnn_pack *p, int32_t n_segments, int32_t T, int32_t n_frames)
+extern "C" size_t wrnn_workspace_bytes_segments(const wrnn_pack *p, int32_t n_segments, int32_t T, int32_t n_frames,
+                                                const wrnn_options *opt)
 {
     if (!p || n_segments < 1 || T < 1 || n_frames < 1) return 0;
-    return ws_layout(n_segments, T, n_frames).total;
+    wrnn_options tmp;
+    const wrnn_options *o = norm_options(opt, &tmp);
+    Plan pl;
+    wrnn_options whole = *o;                 // the workspace of a partial-range call is the whole call's
+    whole.t_begin = 0; whole.t_end = 0;
+    if (make_plan(p, n_segments, T, &whole, &pl) != WRNN_OK) return 0;
+    return ws_layout(p, pl, n_segments, T, n_frames).total;
 }
 
-extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T, const int32_t *seg_pos,
+extern "C" int wrnn_plan_segments(const wrnn_pack *p, int32_t n_segments, int32_t T, const wrnn_options *opt, wrnn_run_info *out)
+{
+    if (!p || !out || n_segments < 1 || T < 1) { set_err("bad argument"); return WRNN_ERR_ARG; }
+    wrnn_options tmp;
+    wrnn_options whole = *norm_options(opt, &tmp);
+    whole.t_begin = 0; whole.t_end = 0;
+    Plan pl;
+    int rc = make_plan(p, n_segments, T, &whole, &pl);
+    if (rc != WRNN_OK) return rc;
+    memset(out, 0, sizeof *out);
+    out->kernel = pl.kind == K_LOOP ? "wrnn_loop_kernel" : (pl.kind == K_SPARSE ? "wrnn_sparse_kernel" : "wrnn_stream_kernel");
+    out->units_per_wg = pl.kind == K_STREAM ? 0 : 16;
+    out->clusters = pl.ncl; out->depth = pl.G; out->rounds = pl.rounds; out->slab_steps = pl.slab;
+    return WRNN_OK;
+}
+
+extern "C" size_t wrnn_workspace_bytes(const wrnn_pack *p, const wrnn_geometry *g, const wrnn_options *opt)
+{
+    if (!p || check_geometry(g) != WRNN_OK) return 0;
+    return wrnn_workspace_bytes_segments(p, g->B, g->T, g->n_frames, opt);
+}
+
+extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, const int32_t *seg_pos,
                                       const int32_t *seg_lim, int32_t L, int32_t hop, int32_t n_frames,
                                       const float *mels_up, const float *aux, const float *noise, float *out,
-                                      void *workspace, size_t workspace_bytes, int algo, const wrnn_debug *dbg,
-                                      void *stream_)
+                                      void *workspace, size_t workspace_bytes, const wrnn_options *opt, void *stream_)
 {
-    wrnn_pack *p = const_cast<wrnn_pack *>(pc);
     if (!p || !mels_up || !aux || !noise || !out || !workspace) { set_err("NULL argument"); return WRNN_ERR_ARG; }
     int rc = check_segments(B, T, seg_pos, seg_lim, L, hop, n_frames);
     if (rc != WRNN_OK) return rc;
-    const WsLayout l = ws_layout(B, T, n_frames);
+    wrnn_options tmp;
+    const wrnn_options *o = norm_options(opt, &tmp);
+    Plan pl;
+    {   // plan for the WHOLE call (a continuation must land on the same split and workspace layout)
+        wrnn_options whole = *o;
+        whole.t_begin = 0; whole.t_end = 0;
+        if ((rc = make_plan(p, B, T, &whole, &pl)) != WRNN_OK) return rc;
+        pl.t0 = o->t_begin; pl.t1 = o->t_end;
+        if (pl.t0 == 0 && pl.t1 == 0) pl.t1 = T;
+        if (pl.t0 < 0 || pl.t1 > T || pl.t0 >= pl.t1) { set_err("bad step range [%d, %d) of T=%d", pl.t0, pl.t1, T); return WRNN_ERR_ARG; }
+        if (pl.kind != K_LOOP && (pl.t0 != 0 || pl.t1 != T)) { set_err("a partial step range needs the loop kernel"); return WRNN_ERR_ARG; }
+    }
+    const WsLayout l = ws_layout(p, pl, B, T, n_frames);
     if (workspace_bytes < l.total) { set_err("workspace %zu < required %zu", workspace_bytes, l.total); return WRNN_ERR_WORKSPACE; }
     if (((uintptr_t)workspace & 255) != 0) { set_err("workspace must be 256-byte aligned"); return WRNN_ERR_ARG; }
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(hipSetDevice(p->device));
     char *ws = (char *)workspace;
+    wrnn_timer *timer = o->timer;
+    if (timer) timer->used = 0;
 
     HIPCHK(hipMemsetAsync(ws + l.status, 0, STATUS_WORDS * sizeof(unsigned), stream));
     // segment table -> device (pageable source: the runtime stages it before returning)
@@ -316,12 +492,13 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
     const int *d_pos = (const int *)(ws + l.segs), *d_lim = d_pos + B;
 
     CondArgs c;
+    memset(&c, 0, sizeof c);
     c.mels_up = mels_up; c.aux = aux; c.I_cT = p->I_cT; c.I_b = p->I_b; c.c2_wT = p->c2_wT; c.b_ih2 = p->b_ih2;
     c.c3_wT = p->c3_wT; c.fc1_b = p->fc1_b; c.c4_wT = p->c4_wT; c.fc2_b = p->fc2_b;
-    c.cI = (float *)(ws + l.cI); c.c2f = (float *)(ws + l.c2f); c.c3f = (float *)(ws + l.c3f); c.c4f = (float *)(ws + l.c4f);
+    c.c2f = (float *)(ws + l.c2f); c.c3f = (float *)(ws + l.c3f); c.c4f = (float *)(ws + l.c4f);
     c.seg_pos = d_pos; c.seg_lim = d_lim;
     c.B = B; c.T = T; c.hop = hop; c.NF = n_frames;
-    HIPCHK(launch_cond(c, p->n_cus, stream));
+    HIPCHK(launch_cond_frames(c, stream));
 
     LoopArgs a;
     memset(&a, 0, sizeof a);
@@ -330,208 +507,101 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *pc, int32_t B, int32_t T,
     a.fc3_w = p->fc3_w; a.fc3_b = p->fc3_b;
     a.w_ih1T = p->w_ih1T; a.w_hh1T = p->w_hh1T; a.w_ih2T = p->w_ih2T; a.w_hh2T = p->w_hh2T;
     a.fc1T = p->fc1T; a.fc2T = p->fc2T; a.fc3T = p->fc3T;
-    a.cI = c.cI; a.c2f = c.c2f; a.c3f = c.c3f; a.c4f = c.c4f;
-    a.noise = noise; a.force_x = dbg ? dbg->force_x : nullptr; a.out = out; a.dbg_logits = dbg ? dbg->logits : nullptr;
-    a.gran = (u64 *)(ws + l.gran); a.status = (unsigned *)(ws + l.status);
-    a.prof = nullptr;
-    if (getenv("WRNN_PROF") && atoi(getenv("WRNN_PROF")) != 0) {
-        a.prof = (u64 *)(ws + l.prof);
-        HIPCHK(hipMemsetAsync(ws + l.prof, 0, (size_t)MAXWG * NPROF * sizeof(u64), stream));
-    }
+    a.c2f = c.c2f; a.c3f = c.c3f; a.c4f = c.c4f;
+    a.noise = noise; a.force_x = o->force_x; a.out = out; a.dbg_logits = o->logits;
+    a.status = (unsigned *)(ws + l.status);
     a.seg_pos = d_pos; a.seg_lim = d_lim;
     a.Btot = B; a.T = T; a.hop = hop; a.NF = n_frames; a.C = p->C;
     a.NG = (B + SEG - 1) / SEG;
+    a.Nall = B;
 
-    // ---- kernel choice --------------------------------------------------------------------------------
-    // sparse: block-sparse GRU pack, 8 XCD clusters x <= 2 groups in flight; pipe: MOL, 4 clusters x 2-3 groups in flight;
-    // cluster: 1/2/4 clusters, one group in flight each (all groups in one launch); persist: the chip-wide kernel, one
-    // launch per 16-segment group; stream: one workgroup per segment.
-    // auto = sparse if the pack qualifies, else pipe when a cluster has more than one group to run (MOL), else cluster,
-    // else (device too small / odd class count) stream.
-    const bool shape_ok = (p->mode == WRNN_MODE_MOL) || (p->C == H);
-    enum { K_STREAM, K_PERSIST, K_CLUSTER, K_PIPE, K_SPARSE } kind = K_STREAM;
-    int U = 0, ncl = 0, G = 0;
-    // auto: a pack whose GRU matrices are block-sparse runs on the block-sparse kernel (measured 1.7-2.3x the dense pipelined
-    // kernel on the same weights, profiles/r01r_probe_block_sparse.json); dense packs never qualify (512 blocks per row)
-    if (algo == WRNN_ALGO_SPARSE || (algo == WRNN_ALGO_AUTO && p->sp_nbp && sparse_clusters(p->n_cus) >= 1)) {
-        const int scl = sparse_clusters(p->n_cus);
-        if (!p->sp_nbp || scl < 1) {
-            set_err("block-sparse kernel needs MOL, >= 32 CUs and GRU matrices with <= 64 surviving 16x1 blocks per block row "
-                    "(this pack: up to %d)", p->sp_max_blocks);
-            return WRNN_ERR_ARG;
-        }
-        const char *envg = getenv("WRNN_SPARSE_G");
-        const int groups = (B + SEG - 1) / SEG;
-        int g = envg ? atoi(envg) : 0;
-        if (g < 1 || g > SPG) g = groups > scl ? 2 : 1;
-        const int rounds = (groups + scl * g - 1) / (scl * g);
-        const long ng = (long)rounds * scl * g;
-        if ((double)rounds * T >= 4.0e9) { set_err("too many steps"); return WRNN_ERR_ARG; }
-        kind = K_SPARSE; G = g; ncl = scl; U = 16;
-        a.NG = ng < B ? (int)ng : B;
-        a.sp_vals = p->sp_vals; a.sp_cols = p->sp_cols;
-    }
-    if (kind == K_SPARSE) {
-        // chosen above
-    } else if ((algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_PIPE) && p->mode == WRNN_MODE_MOL) {
-        // Pipelined kernel: G groups in flight per cluster.  Measured step times on MI355X (profiles/r01g_*): single-depth
-        // cluster kernel 25 us per round-step, G = 2 33.7 us, G = 3 (15-row groups) 49.2 us.  One launch costs
-        // rounds x step: pick the cheapest depth; auto falls back to the cluster kernel when depth 1 wins.
-        const int pcl = pipe_clusters(p->n_cus);
-        const char *envg = getenv("WRNN_PIPE_G");
-        int g = envg ? atoi(envg) : 0;
-        if (pcl >= 1) {
-            static const double step_us[MAXG + 1] = {0.0, 25.0, 33.7, 49.2};
-            if (g < 1 || g > MAXG) {
-                double best = 1e30;
-                for (int c = 1; c <= MAXG; ++c) {
-                    const int rows_c = pipe_rows(c);
-                    const int rounds_c = ((B + rows_c - 1) / rows_c + pcl * c - 1) / (pcl * c);
-                    const double cost = rounds_c * step_us[c];
-                    if (cost < best - 1e-9) { best = cost; g = c; }
-                }
-                if (g == 1 && algo == WRNN_ALGO_AUTO) g = 0;             // the cluster kernel is the better depth-1 kernel
-            }
-            if (g >= 1) {
-                const int rows = pipe_rows(g);
-                const int groups = (B + rows - 1) / rows;
-                const int rounds = (groups + pcl * g - 1) / (pcl * g);
-                const long ng = (long)rounds * pcl * g;
-                if ((double)rounds * T < 4.0e9) {
-                    kind = K_PIPE; G = g; ncl = pcl; U = 8;
-                    a.NG = ng < B ? (int)ng : B;
-                }
-            }
-        }
-        if (kind != K_PIPE && algo == WRNN_ALGO_PIPE) {
-            set_err("pipelined kernel needs >= 64 CUs and MOL mode; device has %d CUs", p->n_cus);
-            return WRNN_ERR_RESIDENCY;
-        }
-    } else if (algo == WRNN_ALGO_PIPE) {
-        set_err("the pipelined kernel exists for MOL only");
-        return WRNN_ERR_ARG;
-    }
-    if (kind == K_PIPE || kind == K_SPARSE) {
-        // chosen above
-    } else if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_CLUSTER) {
-        if (shape_ok && (double)a.NG * T < 4.0e9) {
-            const char *envu = getenv("WRNN_CLUSTER_U");
-            const int want = envu ? atoi(envu) : 0;
-            // default split: as many clusters as there are groups to keep busy (fewer, larger clusters have the
-            // shorter per-step MFMA chain; more, smaller clusters run more groups at once)
-            const int umax = (p->mode == WRNN_MODE_MOL) ? 8 : 4;          // the U = 8 split exists for MOL only
-            // measured (profiles/r01d_probe_pipe_depths.json, B = 12): two clusters x 6 segments 18.5 us per step against 22.6 us
-            // for the chip-wide split with all 12 in one group -- fewer granule rows per sweep win, so never start at U = 2
-            const int first = a.NG >= 3 ? umax : 4;
-            const int pref[3] = {first, 4, umax};
-            if ((want == 2 || want == 4 || want == 8) && want <= umax) { U = want; ncl = cluster_count(U, p->n_cus); }
-            for (int i = 0; i < 3 && ncl < 1; ++i) { U = pref[i]; ncl = cluster_count(U, p->n_cus); }
-            if (ncl >= 1) {
-                kind = K_CLUSTER;
-                // balance: the launch takes `rounds` group-runs per cluster however the segments are cut, so cut
-                // them into rounds*ncl groups (smaller groups = fewer granule rows per sweep, every cluster busy)
-                const int rounds = (a.NG + ncl - 1) / ncl;
-                a.NG = rounds * ncl < B ? rounds * ncl : B;
-            }
-        }
-        if (kind != K_CLUSTER && algo == WRNN_ALGO_CLUSTER) {
-            set_err("cluster kernel needs >= 64 CUs and (MOL or RAW with 512 classes); device has %d CUs, C=%d", p->n_cus, p->C);
-            return WRNN_ERR_RESIDENCY;
-        }
-    } else if (algo == WRNN_ALGO_PERSIST) {
-        const char *envu = getenv("WRNN_PERSIST_U");
-        if (shape_ok) {
-            if (envu && (atoi(envu) == 2 || atoi(envu) == 4)) U = atoi(envu);
-            else if (p->n_cus >= H / 2) U = 2;
-            else if (p->n_cus >= H / 4) U = 4;
-        }
-        if (U != 0 && p->n_cus < H / U) U = 0;
-        if (U == 0) {
-            set_err("persistent kernel needs >= 128 CUs and (MOL or RAW with 512 classes); device has %d CUs, C=%d", p->n_cus, p->C);
-            return WRNN_ERR_RESIDENCY;
-        }
-        kind = K_PERSIST;
-    } else if (algo != WRNN_ALGO_STREAM && algo != WRNN_ALGO_PIPE && algo != WRNN_ALGO_SPARSE) { set_err("unknown algo %d", algo); return WRNN_ERR_ARG; }
+    wrnn_run_info info;
+    memset(&info, 0, sizeof info);
+    info.clusters = pl.ncl; info.depth = pl.G; info.rounds = pl.rounds; info.slab_steps = pl.slab;
 
-    if (kind == K_PIPE || kind == K_SPARSE) {
-        HIPCHK(launch_noise_mol(noise, (float *)(ws + l.npre), (long)T * 11 * B, B, p->n_cus, stream));
-        a.noise_pre = (const float *)(ws + l.npre);
-    }
-    HIPCHK(hipEventRecord(p->ev0, stream));
-    if (kind == K_SPARSE) {
-        p->last_kernel = "wrnn_sparse_kernel";
-        p->last_U = U; p->last_ncl = ncl; p->last_G = G;
-        HIPCHK(hipMemsetAsync(ws + l.gran, 0, GRAN_BYTES, stream));
-        hipError_t e = launch_sparse(a, G, ncl, p->sp_nbp, stream);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            set_err("block-sparse cooperative launch failed: %s", hipGetErrorString(e));
-            return e == hipErrorCooperativeLaunchTooLarge ? WRNN_ERR_RESIDENCY : WRNN_ERR_HIP;
-        }
-    } else if (kind == K_PIPE) {
-        p->last_kernel = "wrnn_pipe_kernel";
-        p->last_U = U; p->last_ncl = ncl; p->last_G = G;
-        HIPCHK(hipMemsetAsync(ws + l.gran, 0, GRAN_BYTES, stream));
-        const char *envn = getenv("WRNN_PIPE_NL");
-        hipError_t e = launch_pipe(a, G, ncl, envn ? atoi(envn) : 16, stream);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            set_err("pipelined cooperative launch failed: %s", hipGetErrorString(e));
-            return e == hipErrorCooperativeLaunchTooLarge ? WRNN_ERR_RESIDENCY : WRNN_ERR_HIP;
-        }
-    } else if (kind == K_CLUSTER) {
-        p->last_kernel = "wrnn_cluster_kernel";
-        p->last_U = U; p->last_ncl = ncl; p->last_G = 1;
-        HIPCHK(hipMemsetAsync(ws + l.gran, 0, GRAN_BYTES, stream));
-        const char *envn = getenv("WRNN_CLUSTER_NL");
-        hipError_t e = launch_cluster(a, U, ncl, p->mode, envn ? atoi(envn) : 0, stream);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            if (algo == WRNN_ALGO_AUTO) {
-                fprintf(stderr, "[wavernn_amd] cluster launch refused (%s); using the stream kernel\n", hipGetErrorString(e));
-                kind = K_STREAM;
+    if (pl.kind == K_LOOP) {
+        // ---- role-split loop kernel: for every slab of steps { derived noise; for every round { conditioning slab; loop } } ----
+        info.kernel = "wrnn_loop_kernel"; info.units_per_wg = 16;
+        const bool mol = p->mode == WRNN_MODE_MOL;
+        a.xbuf = (float *)(ws + l.xbuf);
+        a.cIf = (const float *)(ws + l.cIf);
+        a.G = pl.G;
+        c.cI = (float *)(ws + l.cIf);
+        for (int s0 = pl.t0; s0 < pl.t1; s0 += pl.slab) {
+            const int s1 = s0 + pl.slab < pl.t1 ? s0 + pl.slab : pl.t1;
+            if (mol) {   // noise rows are relative to t_begin (wrnn_options.t_begin)
+                HIPCHK(launch_noise_mol(noise + (size_t)(s0 - pl.t0) * 11 * B, (float *)(ws + l.npre), (long)(s1 - s0) * 11 * B, B, p->n_cus, stream));
+                a.noise_pre = (const float *)(ws + l.npre);
+                a.noise_t0 = s0;
             } else {
-                set_err("cluster cooperative launch failed: %s", hipGetErrorString(e));
-                return e == hipErrorCooperativeLaunchTooLarge ? WRNN_ERR_RESIDENCY : WRNN_ERR_HIP;
+                a.noise_t0 = pl.t0;
+            }
+            for (int r = 0; r < pl.rounds; ++r) {
+                const int rb0 = (int)(((long)r * B) / pl.rounds), rb1 = (int)(((long)(r + 1) * B) / pl.rounds);
+                const int nr = rb1 - rb0;
+                if (nr < 1) continue;
+                const int ngr = (nr + SEG - 1) / SEG;
+                c.t0 = s0; c.t1 = s1; c.rb0 = rb0; c.B = nr; c.NG = ngr;
+                HIPCHK(launch_cond_frag(c, p->n_cus, stream));
+                HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, XBUF_FLOATS * sizeof(float), stream));     // every word = the sentinel
+                a.state = (float *)(ws + l.state) + (size_t)r * loop_state_floats(pl.G);
+                a.t0 = s0; a.t1 = s1; a.cI_t0 = s0; a.rb0 = rb0; a.Btot = nr; a.NG = ngr; a.resume = s0 > 0 ? 1 : 0;
+                if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
+                hipError_t e = launch_loop(a, pl.ncl, p->mode, stream);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    set_err("loop kernel cooperative launch failed: %s", hipGetErrorString(e));
+                    return e == hipErrorCooperativeLaunchTooLarge ? WRNN_ERR_RESIDENCY : WRNN_ERR_HIP;
+                }
+                if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
+                info.launches += 1;
             }
         }
-    } else if (kind == K_PERSIST) {
-        p->last_kernel = "wrnn_persist_kernel";
-        p->last_U = U; p->last_ncl = 1; p->last_G = 1;
-        for (int b0 = 0; b0 < B; b0 += SEG) {
-            a.b0 = b0;
-            a.nb = (B - b0 < SEG) ? (B - b0) : SEG;
-            HIPCHK(hipMemsetAsync(ws + l.gran, 0, (size_t)NGRAN * SEG * H * sizeof(u64), stream));
-            hipError_t e = launch_persist(a, U, p->mode, stream);
+    } else {
+        // ---- stream / block-sparse kernels: whole-T conditioning in [t][segment][H] order, one launch --------------------
+        c.cI = (float *)(ws + l.cI);
+        a.cI = c.cI;
+        a.gran = (u64 *)(ws + l.gran);
+        HIPCHK(launch_cond(c, p->n_cus, o->cond_valu != 0, stream));
+        if (pl.kind == K_SPARSE) {
+            info.kernel = "wrnn_sparse_kernel"; info.units_per_wg = 16;
+            const long ng = (long)pl.rounds * pl.ncl * pl.G;
+            a.NG = ng < B ? (int)ng : B;
+            a.sp_vals = p->sp_vals; a.sp_cols = p->sp_cols;
+            HIPCHK(launch_noise_mol(noise, (float *)(ws + l.npre), (long)T * 11 * B, B, p->n_cus, stream));
+            a.noise_pre = (const float *)(ws + l.npre);
+            HIPCHK(hipMemsetAsync(ws + l.gran, 0, GRAN_BYTES, stream));
+            if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
+            hipError_t e = launch_sparse(a, pl.G, pl.ncl, p->sp_nbp, stream);
             if (e != hipSuccess) {
                 (void)hipGetLastError();
-                set_err("persistent cooperative launch failed: %s", hipGetErrorString(e));
+                set_err("block-sparse cooperative launch failed: %s", hipGetErrorString(e));
                 return e == hipErrorCooperativeLaunchTooLarge ? WRNN_ERR_RESIDENCY : WRNN_ERR_HIP;
             }
+        } else {
+            info.kernel = "wrnn_stream_kernel";
+            a.b0 = 0;
+            a.nb = B;
+            if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
+            HIPCHK(launch_stream(a, p->mode, stream));
         }
+        if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
+        info.launches = 1;
     }
-    if (kind == K_STREAM) {
-        p->last_kernel = "wrnn_stream_kernel";
-        p->last_U = 0; p->last_ncl = 0; p->last_G = 0;
-        a.b0 = 0;
-        a.nb = B;
-        HIPCHK(launch_stream(a, p->mode, stream));
-    }
-    HIPCHK(hipEventRecord(p->ev1, stream));
-    p->timed = true;
+    if (o->info) *o->info = info;
     return WRNN_OK;
 }
 
-extern "C" int wrnn_generate(const wrnn_pack *pc, const wrnn_geometry *g, const float *mels_up, const float *aux,
-                             const float *noise, float *out, void *workspace, size_t workspace_bytes, int algo,
-                             const wrnn_debug *dbg, void *stream_)
+extern "C" int wrnn_generate(const wrnn_pack *p, const wrnn_geometry *g, const float *mels_up, const float *aux,
+                             const float *noise, float *out, void *workspace, size_t workspace_bytes, const wrnn_options *opt,
+                             void *stream_)
 {
     int rc = check_geometry(g);
     if (rc != WRNN_OK) return rc;
     std::vector<int32_t> pos(g->B), lim(g->B, g->L);
     for (int b = 0; b < g->B; ++b) pos[b] = b * g->stride;
-    return wrnn_generate_segments(pc, g->B, g->T, pos.data(), lim.data(), g->L, g->hop, g->n_frames, mels_up, aux,
-                                  noise, out, workspace, workspace_bytes, algo, dbg, stream_);
+    return wrnn_generate_segments(p, g->B, g->T, pos.data(), lim.data(), g->L, g->hop, g->n_frames, mels_up, aux,
+                                  noise, out, workspace, workspace_bytes, opt, stream_);
 }
 
 extern "C" int wrnn_status(void *workspace, void *stream)
@@ -541,40 +611,38 @@ extern "C" int wrnn_status(void *workspace, void *stream)
     unsigned st[STATUS_WORDS];
     HIPCHK(hipMemcpy(st, workspace, sizeof st, hipMemcpyDeviceToHost));
     if (st[0] != 0 || st[1] != 0) {
-        set_err("loop kernel gave up: code 0x%x (layer %u) workgroup %u step %u thread %u", st[1], st[1] & 0xff, st[2], st[3], st[4]);
+        set_err("loop kernel gave up: code 0x%x (phase %u) workgroup %u step %u thread %u", st[1], st[1] & 0xff, st[2], st[3], st[4]);
         return WRNN_ERR_KERNEL;
     }
     return WRNN_OK;
 }
 
-extern "C" int wrnn_profile_read(void *workspace, unsigned long long *out, int max_words, void *stream)
+// Test hook: one exchanged layer (0 h1, 1 h2, 2 y1, 3 y2, 4 RAW logits) of (cluster, slot) at ring position `ring` of the loop
+// kernel's exchange buffer, un-permuted from fragment order to host [16 segments][512].  Synchronises.
+extern "C" int wrnn_debug_read_exchange(const wrnn_pack *p, void *workspace, int32_t n_segments, int32_t T, int32_t n_frames,
+                                        const wrnn_options *opt, int cluster, int slot, int layer, int ring, float *host_out)
 {
-    if (!workspace || !out || max_words < 1) { set_err("bad argument"); return WRNN_ERR_ARG; }
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    size_t n = (size_t)MAXWG * NPROF;
-    if ((size_t)max_words < n) n = (size_t)max_words;
-    const size_t off = (STATUS_WORDS * sizeof(unsigned) + 255) / 256 * 256;
-    HIPCHK(hipMemcpy(out, (char *)workspace + off, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return (int)n;
-}
-
-extern "C" float wrnn_last_loop_ms(const wrnn_pack *p)
-{
-    if (!p || !p->timed) return -1.f;
-    if (hipEventSynchronize(p->ev1) != hipSuccess) return -1.f;
-    float ms = -1.f;
-    if (hipEventElapsedTime(&ms, p->ev0, p->ev1) != hipSuccess) return -1.f;
-    return ms;
-}
-
-extern "C" const char *wrnn_last_loop_kernel(const wrnn_pack *p) { return p ? p->last_kernel : ""; }
-
-extern "C" int wrnn_last_loop_split(const wrnn_pack *p, int *units_per_wg, int *clusters, int *groups_in_flight)
-{
-    if (!p) { set_err("NULL pack"); return WRNN_ERR_ARG; }
-    if (units_per_wg) *units_per_wg = p->last_U;
-    if (clusters) *clusters = p->last_ncl;
-    if (groups_in_flight) *groups_in_flight = p->last_G;
+    if (!p || !workspace || !host_out) { set_err("NULL argument"); return WRNN_ERR_ARG; }
+    wrnn_options tmp;
+    wrnn_options whole = *norm_options(opt, &tmp);
+    whole.t_begin = 0; whole.t_end = 0;
+    Plan pl;
+    int rc = make_plan(p, n_segments, T, &whole, &pl);
+    if (rc != WRNN_OK) return rc;
+    if (pl.kind != K_LOOP || cluster < 0 || cluster >= MAXCL || slot < 0 || slot >= LMAXG || layer < 0 || layer >= NXLAYER || ring < 0 || ring >= XRING) {
+        set_err("no such exchange layer");
+        return WRNN_ERR_ARG;
+    }
+    const WsLayout l = ws_layout(p, pl, n_segments, T, n_frames);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<float> frag((size_t)SEG * H);
+    const size_t off = ((((size_t)cluster * LMAXG + slot) * NXLAYER + layer) * XRING + ring) * SEG * H;
+    HIPCHK(hipMemcpy(frag.data(), (char *)workspace + l.xbuf + off * sizeof(float), frag.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int j = 0; j < SEG; ++j)
+        for (int k = 0; k < H; ++k) {
+            const int w = k >> 7, r = (k >> 4) & 7, kq = (k >> 2) & 3, e = k & 3;
+            host_out[(size_t)j * H + k] = frag[(size_t)(((w * 8 + r) * 64 + kq * 16 + j) * 4 + e)];
+        }
     return WRNN_OK;
 }
 

@@ -126,6 +126,66 @@ __global__ __launch_bounds__(256, 1) void wrnn_cond_mfma_kernel(const CondArgs a
     }
 }
 
+// The same product for the role-split loop kernel (wrnn_loop.hip): one SLAB of steps [t0, t1) of one ROUND of segments
+// [rb0, rb0 + B) cut into NG groups, written in the loop kernel's MFMA-fragment order: tile (t, g) = 16 segments x 512 columns
+// as [wave][k-block][lane][4] -- which is exactly what lane `lane` of wave w holds in acc[tt] (4 consecutive columns
+// 128 w + 16 tt + 4 kq .. of segment fi), so every store instruction writes 1 KB contiguously.  Same arithmetic and order
+// as wrnn_cond_mfma_kernel (bit-identical values); rows of segments beyond a group's count get zero conditioning.
+__global__ __launch_bounds__(256, 1) void wrnn_cond_frag_kernel(const CondArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float in[16 * CLD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fi = lane & 15, kq = lane >> 4;
+    float A[8][4 * CKB];
+    float4 bias[8];
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+        const int row = 128 * w + 16 * tt + fi;
+#pragma unroll
+        for (int r = 0; r < CKB; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) A[tt][4 * r + e] = a.I_cT[(size_t)(16 * r + 4 * kq + e) * H + row];
+        bias[tt] = *reinterpret_cast<const float4 *>(a.I_b + 128 * w + 16 * tt + 4 * kq);
+    }
+    const long tiles = (long)(a.t1 - a.t0) * a.NG;
+    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int t = a.t0 + (int)(tile / a.NG), g = (int)(tile % a.NG);
+        const int b0 = a.rb0 + (int)(((long)g * a.B) / a.NG), nb = a.rb0 + (int)(((long)(g + 1) * a.B) / a.NG) - b0;
+        __syncthreads();
+        for (int q = tid; q < 16 * KCOND; q += 256) {
+            const int rr = q / KCOND, k = q % KCOND;
+            float val = 0.f;
+            if (rr < nb) {
+                const int p = a.seg_pos[b0 + rr] + t;
+                if (p < a.seg_lim[b0 + rr]) val = (k < MEL) ? a.mels_up[(size_t)p * MEL + k] : a.aux[(size_t)(p / a.hop) * 4 * AUX + (k - MEL)];
+            }
+            in[rr * CLD + k] = val;
+        }
+        __syncthreads();
+        float4 bf[CKB];
+#pragma unroll
+        for (int r = 0; r < CKB; ++r) bf[r] = *reinterpret_cast<const float4 *>(in + fi * CLD + 16 * r + 4 * kq);
+        f32x4 acc[8];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < CKB; ++r) {
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt][4 * r + 0], bf[r].x, acc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt][4 * r + 1], bf[r].y, acc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt][4 * r + 2], bf[r].z, acc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt][4 * r + 3], bf[r].w, acc[tt], 0, 0, 0);
+        }
+        float4 *dst = reinterpret_cast<float4 *>(a.cI + (size_t)tile * (SEG * H)) + (w * 8) * 64 + lane;
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt)
+            dst[tt * 64] = make_float4(acc[tt][0] + bias[tt].x, acc[tt][1] + bias[tt].y, acc[tt][2] + bias[tt].z, acc[tt][3] + bias[tt].w);
+    }
+}
+
 // one block per frame (block NF = zero-conditioning row)
 __global__ __launch_bounds__(H) void wrnn_cond_frame_kernel(const CondArgs a)
 {
@@ -171,12 +231,28 @@ hipError_t launch_noise_mol(const float *in, float *out, long n, int B, int n_cu
     return hipGetLastError();
 }
 
-hipError_t launch_cond(const CondArgs &a, int n_cus, hipStream_t stream)
+// per-frame aux tables c2f / c3f / c4f (once per call)
+hipError_t launch_cond_frames(const CondArgs &a, hipStream_t stream)
 {
     hipLaunchKernelGGL(wrnn_cond_frame_kernel, dim3(a.NF + 1), dim3(H), 0, stream, a);
+    return hipGetLastError();
+}
+
+// one slab [a.t0, a.t1) of one round (a.rb0, a.B segments, a.NG groups) of cI in fragment order -> a.cI
+hipError_t launch_cond_frag(const CondArgs &a, int n_cus, hipStream_t stream)
+{
+    long blocks = (long)(a.t1 - a.t0) * a.NG;
+    if (blocks > n_cus) blocks = n_cus;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wrnn_cond_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// whole-T cI in [t][segment][H] order (stream / block-sparse kernels); valu = the VALU form, kept as the on-GPU cross-check
+hipError_t launch_cond(const CondArgs &a, int n_cus, bool valu, hipStream_t stream)
+{
     const long rows = (long)a.T * a.B;
-    const char *env = getenv("WRNN_COND");
-    if (env && strcmp(env, "valu") == 0) {                    // the VALU form, kept as the on-GPU cross-check
+    if (valu) {
         long blocks = (rows + CR - 1) / CR;
         const long cap = (long)n_cus * 4;
         if (blocks > cap) blocks = cap;

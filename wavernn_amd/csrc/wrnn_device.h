@@ -24,6 +24,11 @@ constexpr int SPCL = 8;       // block-sparse kernel: 8 clusters (one per XCD)
 constexpr int SPG = 2;        // ... with up to 2 groups in flight each
 constexpr int GRAN_WORDS = SPCL * SPG * NGRAN * SEG * H;     // u64 granules in the workspace (>= MAXCL * MAXG * ...)
 static_assert(SPCL * SPG >= MAXCL * MAXG, "granule workspace");
+// role-split loop kernel (wrnn_loop.hip): tag-free exchange buffer [cluster][slot][layer h1 h2 y1 y2 lg][ring][SEG*H floats]
+constexpr int LMAXG = 8;      // slots (groups in flight) per cluster the exchange buffer is sized for
+constexpr int NXLAYER = 5;
+constexpr int XRING = 3;
+constexpr size_t XBUF_FLOATS = (size_t)MAXCL * LMAXG * NXLAYER * XRING * SEG * H;
 constexpr int STATUS_WORDS = 16;
 constexpr int NPROF = 16;     // phase counters per workgroup (wrnn_pipe.hip PROF builds)
 constexpr int MAXWG = 256;    // workgroups of a persistent launch
@@ -64,6 +69,13 @@ struct LoopArgs {
     const int *seg_pos, *seg_lim;       // [Btot]
     int Btot, b0, nb, T, hop, NF, C;
     int NG;                             // cluster kernel: number of <= SEG-segment groups the Btot segments form
+    // ---- role-split loop kernel (wrnn_loop.hip): one ROUND of segments [rb0, rb0 + Btot) of a call with Nall segments, steps
+    //      [t0, t1); NG = groups of the round, G = groups in flight per cluster
+    float *xbuf;                        // [XBUF_FLOATS] exchange buffer, sentinel-filled before every launch
+    float *state;                       // [clusters*64][G][LGRP] per-group state carried between launches of one round
+    const float *cIf;                   // [t1 - cI_t0 ...][NG][SEG*H] hoisted conditioning of the round in fragment order (slab)
+    int t0, t1, cI_t0, noise_t0;        // noise / noise_pre row 0 is step noise_t0, cIf row 0 is step cI_t0
+    int rb0, Nall, G, resume;           // resume != 0: restore the per-group state instead of the zero initial state
 };
 
 
@@ -80,6 +92,7 @@ struct CondArgs {
     float *cI, *c2f, *c3f, *c4f;
     const int *seg_pos, *seg_lim;       // [B] (see LoopArgs)
     int B, T, hop, NF;
+    int t0, t1, rb0, NG;                // fragment-order slab form (wrnn_cond_frag_kernel): steps [t0, t1) of the round [rb0, rb0 + B)
 };
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -52,9 +52,17 @@ class LoopEngine:
         self._pack = pack
         self._ws = None
         self.n_cus = self.lib.wrnn_device_cus(self.device.index or 0)
+        timer = ctypes.c_void_p()
+        _lib.check(self.lib.wrnn_timer_create(self.device.index or 0, ctypes.byref(timer)), 'wrnn_timer_create')
+        self._timer = timer
+        self._info = _lib.RunInfo()
+        self._last_opts = None
 
     def __del__(self):
         try:
+            if getattr(self, '_timer', None):
+                self.lib.wrnn_timer_destroy(self._timer)
+                self._timer = None
             if getattr(self, '_pack', None):
                 self.lib.wrnn_pack_destroy(self._pack)
                 self._pack = None
@@ -70,21 +78,43 @@ class LoopEngine:
     def weight_bytes(self):
         return int(self.lib.wrnn_pack_weight_bytes(self._pack))
 
-    def run(self, mels_up, aux, B, T, stride, noise, hop, algo='auto', force_x=None, want_logits=False, check=True):
+    def run(self, mels_up, aux, B, T, stride, noise, hop, **kw):
         """One utterance: segment b reads conditioning position b*stride + t (`fold_with_overlap` geometry,
         reference :293-340; unbatched: B=1, T=L, stride=0).  See `run_segments`."""
         L = mels_up.shape[0]
         seg_pos = np.arange(B, dtype=np.int32) * np.int32(stride)
         seg_lim = np.full(B, L, dtype=np.int32)
-        return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo=algo, force_x=force_x,
-                                 want_logits=want_logits, check=check)
+        return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, **kw)
 
-    def run_segments(self, mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='auto', force_x=None,
-                     want_logits=False, check=True):
+    def options(self, algo='auto', depth=0, clusters=0, slab_steps=0, cond_valu=False, t_range=None):
+        o = _lib.Options()
+        o.algo = _lib.ALGOS[algo]
+        o.depth, o.clusters, o.slab_steps, o.cond_valu = int(depth), int(clusters), int(slab_steps), int(bool(cond_valu))
+        if t_range is not None:
+            o.t_begin, o.t_end = int(t_range[0]), int(t_range[1])
+        return o
+
+    def plan(self, n_segments, T, **kw):
+        """What a run over this many segments would launch (`wrnn_plan_segments`): dict(kernel, clusters, depth, rounds, ...)."""
+        o, i = self.options(**kw), _lib.RunInfo()
+        _lib.check(self.lib.wrnn_plan_segments(self._pack, n_segments, T, ctypes.byref(o), ctypes.byref(i)), 'wrnn_plan_segments')
+        return dict(kernel=(i.kernel or b'').decode(), units_per_wg=int(i.units_per_wg), clusters=int(i.clusters), depth=int(i.depth),
+                    rounds=int(i.rounds), slab_steps=int(i.slab_steps))
+
+    def workspace_bytes(self, n_segments, T, n_frames, **kw):
+        o = self.options(**kw)
+        return int(self.lib.wrnn_workspace_bytes_segments(self._pack, n_segments, T, n_frames, ctypes.byref(o)))
+
+    def run_segments(self, mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='auto', force_x=None, want_logits=False,
+                     check=True, depth=0, clusters=0, slab_steps=0, cond_valu=False, t_range=None, out=None, logits=None):
         """mels_up (L,feat) / aux (n_frames,4*aux_dims) / noise: float32 CUDA tensors; seg_pos / seg_lim: host
         int32 arrays (B,) -- segment b, step t reads position seg_pos[b]+t, zero conditioning from seg_lim[b] on
         (several utterances: concatenated conditioning).  Returns out (B,T) CUDA [and logits (T,B,C)].
-        Enqueues on the current stream; `check=True` synchronises and raises if a kernel gave up."""
+        Enqueues on the current stream; `check=True` synchronises and raises if a kernel gave up.
+
+        depth / clusters / slab_steps / cond_valu: `wrnn_options` (0 = the library picks).  t_range=(t0, t1) runs only those
+        steps; t0 > 0 continues the previous call on this engine's workspace (pass the same `out`; `noise` then holds the
+        rows of [t0, t1) only) -- how long RAW runs draw their noise in chunks instead of T*B*C floats at once."""
         for name, t_ in (('mels_up', mels_up), ('aux', aux), ('noise', noise)):
             if not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()):
                 raise ValueError(f'{name} must be a contiguous float32 CUDA tensor')
@@ -96,55 +126,70 @@ class LoopEngine:
         L = mels_up.shape[0]
         if mels_up.shape[1] != self.feat_dims or aux.shape[1] != 4 * self.aux_dims:
             raise ValueError('conditioning shape mismatch')
-        need = T * 11 * B if self.mode == 'MOL' else T * B * self.n_classes
+        t0, t1 = (0, T) if t_range is None else (int(t_range[0]), int(t_range[1]))
+        need = (t1 - t0) * 11 * B if self.mode == 'MOL' else (t1 - t0) * B * self.n_classes
         if noise.numel() != need:
             raise ValueError(f'noise has {noise.numel()} elements, expected {need}')
         n_frames = int(aux.shape[0])
-        nbytes = int(self.lib.wrnn_workspace_bytes_segments(self._pack, B, T, n_frames))
+        o = self.options(algo, depth, clusters, slab_steps, cond_valu, t_range)
+        nbytes = int(self.lib.wrnn_workspace_bytes_segments(self._pack, B, T, n_frames, ctypes.byref(o)))
         if nbytes == 0:
-            raise _lib.WrnnError('bad geometry')
+            raise _lib.WrnnError('bad geometry / options: ' + self.lib.wrnn_last_error().decode())
         if self._ws is None or self._ws.numel() < nbytes:
+            if t0 > 0:
+                raise _lib.WrnnError('continuing a call needs the workspace of the call it continues')
             self._ws = None
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        out = torch.empty(B, T, dtype=torch.float32, device=self.device)
-        dbg = _lib.Debug(None, None)
-        logits = None
+        if out is None:
+            out = torch.empty(B, T, dtype=torch.float32, device=self.device)
         if force_x is not None:
             force_x = force_x.to(self.device, torch.float32).contiguous()
             assert force_x.shape == (B, T)
-            dbg.force_x = force_x.data_ptr()
+            o.force_x = force_x.data_ptr()
         if want_logits:
-            logits = torch.empty(T, B, self.n_classes, dtype=torch.float32, device=self.device)
-            dbg.logits = logits.data_ptr()
+            if logits is None:
+                logits = torch.empty(T, B, self.n_classes, dtype=torch.float32, device=self.device)
+            o.logits = logits.data_ptr()
+        o.timer = self._timer
+        o.info = ctypes.pointer(self._info)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.wrnn_generate_segments(self._pack, B, T, seg_pos.ctypes.data, seg_lim.ctypes.data, L, hop, n_frames,
                                              mels_up.data_ptr(), aux.data_ptr(), noise.data_ptr(), out.data_ptr(),
-                                             self._ws.data_ptr(), self._ws.numel(), _lib.ALGOS[algo], ctypes.byref(dbg), stream)
+                                             self._ws.data_ptr(), self._ws.numel(), ctypes.byref(o), stream)
         _lib.check(rc, 'wrnn_generate_segments')
+        self._last_opts = (B, T, n_frames, self.options(algo, depth, clusters, slab_steps, cond_valu, None))
         if check:
             _lib.check(self.lib.wrnn_status(self._ws.data_ptr(), stream), 'loop kernel')
         return (out, logits) if want_logits else out
 
-    def last_loop_split(self):
-        """(hidden units per workgroup, independent clusters, groups in flight per cluster) of the last loop kernel;
-        (0, 0, 0) for the stream kernel."""
-        u, c, g = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-        _lib.check(self.lib.wrnn_last_loop_split(self._pack, ctypes.byref(u), ctypes.byref(c), ctypes.byref(g)),
-                   'wrnn_last_loop_split')
-        return u.value, c.value, g.value
-
-    def read_profile(self):
-        """Phase clocks of the last launch made with WRNN_PROF=1 (pipelined kernel): uint64 array [256 workgroups, 16 phases]
-        of shader cycles (see wrnn_pipe.hip).  Synchronises."""
-        out = np.zeros((256, 16), dtype=np.uint64)
+    def status(self):
+        """Synchronise the current stream and raise if a loop kernel of the last call gave up (for `check=False` calls)."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        n = self.lib.wrnn_profile_read(self._ws.data_ptr(), out.ctypes.data, out.size, stream)
-        if n < 0:
-            _lib.check(n, 'wrnn_profile_read')
-        return out
+        _lib.check(self.lib.wrnn_status(self._ws.data_ptr(), stream), 'loop kernel')
+
+    def read_exchange(self, cluster, slot, layer, ring):
+        """Test hook: one exchanged layer (0 h1, 1 h2, 2 y1, 3 y2, 4 RAW logits) of the last loop-kernel call as a host
+        array [16 segments, 512] (wrnn_debug_read_exchange)."""
+        B, T, n_frames, o = self._last_opts
+        host = np.zeros((16, 512), np.float32)
+        _lib.check(self.lib.wrnn_debug_read_exchange(self._pack, self._ws.data_ptr(), B, T, n_frames, ctypes.byref(o), cluster,
+                                                     slot, layer, ring, host.ctypes.data), 'wrnn_debug_read_exchange')
+        return host
+
+    def last_loop_split(self):
+        """(hidden units per workgroup, independent clusters, groups in flight per cluster) of the last call;
+        (0, 0, 0) for the stream kernel."""
+        i = self._info
+        return int(i.units_per_wg), int(i.clusters), int(i.depth)
+
+    def last_run_info(self):
+        i = self._info
+        return dict(kernel=(i.kernel or b'').decode(), units_per_wg=int(i.units_per_wg), clusters=int(i.clusters), depth=int(i.depth),
+                    rounds=int(i.rounds), slab_steps=int(i.slab_steps), launches=int(i.launches))
 
     def last_loop_ms(self):
-        return float(self.lib.wrnn_last_loop_ms(self._pack))
+        """Sum of the loop-kernel launch durations of the last call (HIP events on the launch stream; synchronises)."""
+        return float(self.lib.wrnn_timer_ms(self._timer))
 
     def last_loop_kernel(self):
-        return self.lib.wrnn_last_loop_kernel(self._pack).decode()
+        return (self._info.kernel or b'').decode()

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from . import fold as _fold
 from .dsp import save_wav
 from .engine import LoopEngine, LOOP_KEYS
-from .rng import draw_noise
+from .rng import burn_ctor_draws, draw_steps
 
 
 class ResBlock(nn.Module):
@@ -126,7 +126,7 @@ class WaveRNN(nn.Module):
         #: 'cpu' = consume torch's global CPU generator exactly like the reference's CPU run (parity);
         #: 'device' = device Philox generator (what the reference does when it runs on a GPU)
         self.noise_source = 'cpu'
-        #: 'auto' | 'pipe' | 'cluster' | 'persist' | 'stream'
+        #: 'auto' | 'loop' | 'sparse' | 'stream'  (WRNN_ALGO_*, include/wavernn_amd.h)
         self.loop_algo = 'auto'
         #: 'native' = the HIP pre-loop kernels (MFMA MelResNet + box-filter up-sampling, wrnn_pre_*);
         #: 'torch' = the nn.Modules below through PyTorch-ROCm (MIOpen)
@@ -134,6 +134,8 @@ class WaveRNN(nn.Module):
         #: 'native' = cross-fade / unfold / mu-law / tail fade on the device in float64 (wrnn_post_unfold);
         #: 'numpy' = the host helpers of fold.py
         self.post_algo = 'native'
+        #: upper bound on the sampling noise resident at once (bytes); longer runs draw it slice by slice
+        self.noise_chunk_bytes = 128 << 20
         self._engine = None
         self._engine_key = None
         self._pre = None
@@ -164,9 +166,21 @@ class WaveRNN(nn.Module):
         return self.fc3(x)
 
     # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _fingerprint(tensors):
+        """Cheap content fingerprint of device tensors: catches in-place edits made through `.data` (what the reference's
+        pruning notebook does: `p.data.mul_(mask)`), which bump neither data_ptr nor `_version` of the parameter."""
+        flat = torch.cat([t.detach().reshape(-1).view(torch.int32) for t in tensors]).to(torch.int64)
+        return tuple(torch.stack([flat.sum(), (flat * flat).sum(), (flat[1:] * flat[:-1]).sum()]).tolist())
+
+    def invalidate_engines(self):
+        """Drop the cached device weight packs (they are also rebuilt automatically when the weights' content changes)."""
+        self._engine = self._pre = self._engine_key = self._pre_key = None
+
     def _loop_engine(self):
         sd = {k: v for k, v in self.state_dict().items() if k in LOOP_KEYS.values()}
-        key = tuple((k, v.data_ptr(), v._version, str(v.device)) for k, v in sorted(sd.items()))
+        key = tuple((k, v.data_ptr(), str(v.device), tuple(v.shape)) for k, v in sorted(sd.items()))
+        key = key + self._fingerprint([v for _, v in sorted(sd.items())])
         if self._engine is None or key != self._engine_key:
             dev = next(self.parameters()).device
             self._engine = LoopEngine(sd, self.mode, device=dev)
@@ -176,7 +190,8 @@ class WaveRNN(nn.Module):
     def _pre_engine(self):
         from .pre import PreEngine
         sd = {k: v for k, v in self.state_dict().items() if k.startswith('upsample.')}
-        key = tuple((k, v.data_ptr(), v._version, str(v.device)) for k, v in sorted(sd.items()))
+        fl = [v for _, v in sorted(sd.items()) if v.dtype == torch.float32]
+        key = tuple((k, v.data_ptr(), str(v.device), tuple(v.shape)) for k, v in sorted(sd.items())) + self._fingerprint(fl)
         if self._pre is None or key != self._pre_key:
             self._pre = PreEngine(sd, device=next(self.parameters()).device)
             self._pre_key = key
@@ -214,10 +229,21 @@ class WaveRNN(nn.Module):
                 T, stride = target + 2 * overlap, target + overlap
             else:
                 B, T, stride = 1, L, 0
-            noise = draw_noise(self.mode, B, T, self.n_classes, self.rnn_dims, self.aux_dims, device, self.noise_source)
             eng = self._loop_engine()
-            out = eng.run(mels_up, aux, B, T, stride, noise, self.hop_length, algo=self.loop_algo)
-            self.last_loop_ms = eng.last_loop_ms()
+            burn_ctor_draws(self.rnn_dims, self.aux_dims, self.noise_source)
+            # the sampling noise is drawn and uploaded in slices of steps (RAW: B * n_classes floats per step), each slice
+            # continuing the loop where the previous one stopped (wrnn_options.t_begin / t_end)
+            per_step = B * (11 if self.mode == 'MOL' else self.n_classes) * 4
+            resumable = eng.plan(B, T, algo=self.loop_algo)['kernel'] == 'wrnn_loop_kernel'
+            chunk = max(1, min(T, self.noise_chunk_bytes // per_step)) if resumable else T
+            out, ms = None, 0.0
+            for t0 in range(0, T, chunk):
+                t1 = min(T, t0 + chunk)
+                noise = draw_steps(self.mode, B, t1 - t0, self.n_classes, device, self.noise_source)
+                out = eng.run(mels_up, aux, B, T, stride, noise, self.hop_length, algo=self.loop_algo, out=out,
+                              t_range=None if (t0 == 0 and t1 == T) else (t0, t1))
+                ms += eng.last_loop_ms()
+            self.last_loop_ms = ms
             self.last_loop_kernel = eng.last_loop_kernel()
 
         if self.post_algo == 'native':

@@ -22,21 +22,37 @@ def gru_cell_ctor_draws(rnn_dims, aux_dims):
     return one(h) + one(h + aux_dims)
 
 
-def draw_noise(mode, B, T, n_classes, rnn_dims, aux_dims, device, source='cpu', generator=None):
-    """MOL -> (T, 11*B) U(1e-5, 1-1e-5); RAW -> (T, B, n_classes) Exp(1).  float32 on `device`."""
+def burn_ctor_draws(rnn_dims, aux_dims, source='cpu', generator=None):
+    """The RNG side effect of `get_gru_cell` x 2 (reference :178-179, :273-279) -- once per generate() call."""
+    if source != 'cpu':
+        return
+    if generator is None:
+        torch.nn.GRUCell(rnn_dims, rnn_dims)                 # same RNG side effect as get_gru_cell(self.rnn1)
+        torch.nn.GRUCell(rnn_dims + aux_dims, rnn_dims)      # ... and get_gru_cell(self.rnn2)
+    else:
+        torch.empty(gru_cell_ctor_draws(rnn_dims, aux_dims), dtype=torch.float32).uniform_(0, 1, generator=generator)
+
+
+def draw_steps(mode, B, steps, n_classes, device, source='cpu', generator=None):
+    """Noise of `steps` consecutive loop steps, continuing the stream: MOL -> (steps, 11*B) U(1e-5, 1-1e-5); RAW -> (steps, B,
+    n_classes) Exp(1).  CPU fills are serial in memory order, so chunked draws equal one big draw (= the reference's
+    per-step draws); this is what lets long RAW runs upload their noise in slices instead of T*B*C floats at once."""
     if source == 'cpu':
-        if generator is None:
-            torch.nn.GRUCell(rnn_dims, rnn_dims)                 # same RNG side effect as get_gru_cell(self.rnn1)
-            torch.nn.GRUCell(rnn_dims + aux_dims, rnn_dims)      # ... and get_gru_cell(self.rnn2)
-        else:
-            torch.empty(gru_cell_ctor_draws(rnn_dims, aux_dims), dtype=torch.float32).uniform_(0, 1, generator=generator)
         if mode == 'MOL':
-            n = torch.empty(T, 11 * B, dtype=torch.float32).uniform_(1e-5, 1.0 - 1e-5, generator=generator)
+            n = torch.empty(steps, 11 * B, dtype=torch.float32).uniform_(1e-5, 1.0 - 1e-5, generator=generator)
         else:
-            n = torch.empty(T, B, n_classes, dtype=torch.float32).exponential_(1, generator=generator)
+            n = torch.empty(steps, B, n_classes, dtype=torch.float32).exponential_(1, generator=generator)
         return n.to(device, non_blocking=False)
     if source == 'device':
         if mode == 'MOL':
-            return torch.empty(T, 11 * B, dtype=torch.float32, device=device).uniform_(1e-5, 1.0 - 1e-5)
-        return torch.empty(T, B, n_classes, dtype=torch.float32, device=device).exponential_(1)
+            return torch.empty(steps, 11 * B, dtype=torch.float32, device=device).uniform_(1e-5, 1.0 - 1e-5)
+        return torch.empty(steps, B, n_classes, dtype=torch.float32, device=device).exponential_(1)
     raise ValueError(f'unknown noise source {source!r}')
+
+
+def draw_noise(mode, B, T, n_classes, rnn_dims, aux_dims, device, source='cpu', generator=None):
+    """MOL -> (T, 11*B) U(1e-5, 1-1e-5); RAW -> (T, B, n_classes) Exp(1).  float32 on `device`."""
+    if source not in ('cpu', 'device'):
+        raise ValueError(f'unknown noise source {source!r}')
+    burn_ctor_draws(rnn_dims, aux_dims, source, generator)
+    return draw_steps(mode, B, T, n_classes, device, source, generator)
