@@ -69,6 +69,16 @@ def cpu_baseline(sd, mode, frames, target, overlap, budget_s):
                 realtime_factor=round(useful / SAMPLE_RATE, 4))
 
 
+def source_sha16():
+    """Hash of the kernel + host sources a measurement belongs to (keys profiles/traffic_latest.json to the code it measured)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'wavernn_amd', 'csrc', '*.h*')) + [os.path.join(ROOT, 'bench.py')]):
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -76,7 +86,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--utterances', type=int, default=8, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=641, help='mel frames per utterance')
-    ap.add_argument('--algo', default='auto', choices=['auto', 'pipe', 'sparse', 'cluster', 'persist', 'stream'])
+    ap.add_argument('--algo', default='auto', choices=['auto', 'loop', 'sparse', 'stream'])
+    ap.add_argument('--mode', default='MOL', choices=['MOL', 'RAW'], help="RAW = 9-bit mu-law ('bits') softmax sampling")
+    ap.add_argument('--force-dist', action='store_true', help='initialise a torch.distributed nccl (= RCCL) group even at --gpus 1')
+    ap.add_argument('--no-single', action='store_true', help="skip the single-utterance generate() entries (BASELINE config 2's N=481 / N=1001)")
     ap.add_argument('--prune', type=float, default=0.0,
                     help='BASELINE config 5: block-prune the GRU matrices (16x1 blocks) to this sparsity, e.g. 0.95')
     ap.add_argument('--parity-noise', action='store_true')
@@ -94,8 +107,9 @@ def main():
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     group = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29513')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
         group = dist.group.WORLD
 
@@ -104,7 +118,7 @@ def main():
     from wavernn_amd.batch import generate_corpus, plan_utterances
     from wavernn_amd import _lib
 
-    mode, target, overlap, hop = 'MOL', 11000, 550, 275
+    mode, target, overlap, hop = args.mode, 11000, 550, 275
     sd = random_state_dict(0, mode=mode)
     if args.prune > 0:
         from wavernn_amd.prune import block_prune_state_dict
@@ -126,12 +140,12 @@ def main():
     def one_pass():
         outs = generate_corpus(model, mels, target, overlap, True, seeds, group=group, noise_source=noise_source,
                                finish='own', check=False)
-        _lib.check(eng.lib.wrnn_status(eng._ws.data_ptr(), torch.cuda.current_stream().cuda_stream), 'loop kernel')
+        eng.status()
         return outs
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if group is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,10 +159,40 @@ def main():
         loop_ms.append(eng.last_loop_ms())
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if group is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    info = eng.last_run_info()
+
+    def single_utterance(n_frames):
+        """ONE `WaveRNN.generate()` call -- the drop-in API itself -- on BASELINE config 2's stated input (mel seed
+        1234, N frames, target 11000 / overlap 550): wall time of the whole call incl. the WAV write, device noise."""
+        import tempfile
+        mel = torch.from_numpy(random_mel(1234, n_frames)).unsqueeze(0).to(dev)
+        was = model.noise_source
+        model.noise_source = 'device'
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, 'o.wav')
+            model.generate(mel, path, True, target, overlap, True)                   # warm-up
+            times, kms = [], []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                wav = model.generate(mel, path, True, target, overlap, True)
+                times.append(time.perf_counter() - t0)
+                kms.append(model.last_loop_ms)
+        model.noise_source = was
+        model.eval()
+        B = plan_utterances([n_frames * hop], target, overlap).n_segments
+        T = target + 2 * overlap
+        wall, k = float(np.median(times)), float(np.median(kms))
+        bytes_eq = (eng.weight_bytes + B * 836) * T
+        return {'N_frames': n_frames, 'segments': B, 'steps': T, 'samples': int(wav.shape[0]),
+                'samples_per_s': round(wav.shape[0] / wall, 1), 'realtime_factor': round(wav.shape[0] / wall / SAMPLE_RATE, 2),
+                'generate_wall_ms': round(wall * 1e3, 2), 'loop_kernel_ms': round(k, 2), 'us_per_step': round(k * 1e3 / T, 3),
+                'kernel': model.last_loop_kernel, 'split': eng.last_run_info(),
+                'hbm_equivalent_GBps': round(bytes_eq / (k * 1e-3) / 1e9, 1), 'hbm_equivalent_frac': round(bytes_eq / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
     if rank == 0:
         T = plan.T
@@ -165,26 +209,32 @@ def main():
         nnz = int(sum(np.count_nonzero(sd[k]) for k in wkeys))      # 3,825,152 for the dense MoL model
         flops_per_launch = 2.0 * nnz * n_local * T
         tf = flops_per_launch / (kms * 1e-3) / 1e12
-        u_per_wg, ncl, depth = eng.last_loop_split()
+        u_per_wg, ncl, depth = info['units_per_wg'], info['clusters'], info['depth']
+        # HBM-side traffic of the loop kernel per pass, from the rocprofv3 PMC passes of THIS command line on THIS source tree
+        # (scripts/summarize_profile.py writes the file; it is ignored unless kernel, geometry and source hash all match)
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get('kernel') == eng.last_loop_kernel() and tj.get('segments') == n_local and tj.get('T') == T:
-                traffic = tj.get('bytes_per_launch')
+            if (tj.get('kernel') == info['kernel'] and tj.get('segments') == n_local and tj.get('T') == T and tj.get('mode') == mode
+                    and tj.get('source_sha16') == source_sha16()):
+                traffic = tj.get('bytes_per_pass')
         res = {
-            'metric': 'audio samples/sec (real-time factor @22.05 kHz), MoL WaveRNN batched generate',
+            'metric': 'audio samples/sec (real-time factor @22.05 kHz), MoL WaveRNN batched generate' if mode == 'MOL' else
+                      "audio samples/sec (real-time factor @22.05 kHz), 9-bit mu-law ('bits') WaveRNN batched generate",
             'value': round(value, 1), 'unit': 'audio samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'realtime_factor': round(value / SAMPLE_RATE, 2),
             'config': {'workload': (f'BASELINE config 5 (GRU matrices block-pruned to {args.prune:.0%} zeros, 16x1 blocks) = ' if args.prune > 0 else '') +
-                                   f'BASELINE config 2 (MoL WaveRNN, rnn/fc 512, random-init weights, batched fold target={target} '
+                                   f'BASELINE config 2 ({"MoL" if mode == "MOL" else "9-bit mu-law RAW"} WaveRNN, rnn/fc 512, random-init weights, batched fold target={target} '
                                    f'overlap={overlap}) on a batch of {args.utterances} random {args.frames}-frame mels per GPU '
-                                   f'-> {n_local} folded segments x T={T} steps in one launch per GPU, '
+                                   f'-> {n_local} folded segments x T={T} steps per GPU ({info["launches"]} loop-kernel launches per pass: '
+                                   f'{info["rounds"]} round(s) x conditioning slabs of {info["slab_steps"]} steps), '
                                    f'{wave_total // world} output samples per GPU per step',
                        'segments_per_gpu': n_local, 'steps_per_segment': T,
-                       'kernel': eng.last_loop_kernel(), 'units_per_workgroup': u_per_wg, 'clusters': ncl, 'groups_in_flight_per_cluster': depth,
+                       'mode': mode, 'kernel': info['kernel'], 'launches_per_pass': info['launches'], 'rounds': info['rounds'],
+                       'slab_steps': info['slab_steps'], 'units_per_workgroup': u_per_wg, 'clusters': ncl, 'groups_in_flight_per_cluster': depth,
                        'segment_steps_per_s': round(plan.n_segments * T * args.steps / dt, 1),
                        'noise': 'host MT19937 stream (parity mode)' if args.parity_noise else 'device Philox (as the reference on a GPU)',
                        'parallelism': f'{world} x (1 process per GPU, contiguous block of the segment table, RCCL all-gather of audio)'},
@@ -193,29 +243,34 @@ def main():
         # segments per weight pass; the f32 ridge of gfx950 is 157.3 TF / 6.3 TB/s = 25 FLOP/B, i.e. weight-bandwidth-bound
         # below ~50 resident segments and f32-MFMA-bound above.  The other figure is reported beside it.
         hbm = {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-               'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'kernel': eng.last_loop_kernel(),
+               'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'kernel': info['kernel'],
                'kernel_ms': round(kms, 3), 'algorithmic_bytes_per_launch': bytes_per_launch,
                'note': 'weight-streaming-equivalent bandwidth, SURVEY.md 8(d): (W + n*836 B) per batch step x T steps / kernel '
-                       'time (HIP events on the launch stream); the weights are on-chip resident, so this is a per-step latency '
+                       'time (kernel_ms = sum of the loop-kernel launch durations of one pass, HIP events on the launch stream); the weights are on-chip resident, so this is a per-step latency '
                        'figure of merit, not HBM traffic (DESIGN.md)'}
         mfma = {'bound': 'mfma', 'achieved': round(tf, 3), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
-                'frac': round(tf / MFMA_F32_PEAK_TF, 5), 'traffic': traffic, 'kernel': eng.last_loop_kernel(),
-                'kernel_ms': round(kms, 3), 'algorithmic_flops_per_launch': flops_per_launch,
+                'frac': round(tf / MFMA_F32_PEAK_TF, 5), 'traffic': traffic, 'kernel': info['kernel'],
+                'kernel_ms': round(kms, 3), 'launches': info['launches'], 'algorithmic_flops_per_pass': flops_per_launch,
                 'weights_nnz': nnz,
-                'note': 'useful f32 FLOPs of the loop (2 x non-zero loop weights per segment-step x n x T) / kernel time (HIP events '
-                        'on the launch stream) vs the dense f32 MFMA peak; n >= 50 resident segments puts the loop right of the '
+                'note': 'useful f32 FLOPs of the loop (2 x non-zero loop weights per segment-step x n x T) / kernel time (kernel_ms = '
+                        'sum of the loop-kernel launch durations of one pass, HIP events on the launch stream) vs the dense f32 MFMA peak; n >= 50 resident segments puts the loop right of the '
                         'f32 ridge (SURVEY.md 8d)'}
         if n_local >= 50:
             res['roofline'], res['roofline_hbm_equivalent'] = mfma, hbm
         else:
             res['roofline'], res['roofline_mfma'] = hbm, mfma
+        if not args.no_single and world == 1 and args.prune == 0:
+            try:
+                res['config']['single_utterance'] = [single_utterance(481), single_utterance(1001)]
+            except Exception as e:
+                res['config']['single_utterance'] = {'error': repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 res['cpu_baseline'] = cpu_baseline(sd, mode, args.frames, target, overlap, args.cpu_seconds)
             except Exception as e:   # the baseline is a report, never a reason to lose the GPU number
                 res['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if group is not None:
         dist.destroy_process_group()
     # the C-ABI pack must go before the HIP runtime tears down at interpreter exit
     del eng

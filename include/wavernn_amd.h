@@ -199,7 +199,8 @@ int wrnn_debug_read_exchange(const wrnn_pack *p, void *workspace, int32_t n_segm
                              const wrnn_options *opt, int cluster, int slot, int layer, int ring, float *host_out);
 
 /* Timer objects (see wrnn_options.timer).  wrnn_timer_ms synchronises on the recorded events and returns the SUM of the
- * loop-kernel launch durations of the last call that used the timer (<0 if none); wrnn_timer_launches their count. */
+ * loop-kernel launch durations of the last call that used the timer, including the calls that continued it with
+ * t_begin > 0 (<0 if none); wrnn_timer_launches their count. */
 int wrnn_timer_create(int device, wrnn_timer **out);
 void wrnn_timer_destroy(wrnn_timer *t);
 float wrnn_timer_ms(wrnn_timer *t);

@@ -69,8 +69,9 @@ def test_device_selftests(gpu):
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_exchange_layers_match_oracle(gpu, mode):
     """Stage-level check of the loop kernel (test hook `wrnn_debug_read_exchange`): after a 3-step run of 40 segments
-    (3 groups on 3 clusters) the exchanged h1 / h2 of every step still sit in the 3-deep ring, in MFMA-fragment order;
-    un-permuted they must equal the numpy oracle's GRU states -- localises a wrong stage instead of a wrong waveform."""
+    (3 groups on 3 clusters) the exchanged h1 / h2 of the last two steps still sit in the 3-deep ring (the slot of step 0 was
+    re-armed for step 3), in MFMA-fragment order; un-permuted they must equal the numpy oracle's GRU states -- localises
+    a wrong stage instead of a wrong waveform."""
     from oracle import wavernn_oracle as O
     from wavernn_amd.engine import LoopEngine
     cfg = dict(mode=mode, wseed=37, mseed=137, frames=100, batched=True, target=480, overlap=60, seed=97)
@@ -88,7 +89,7 @@ def test_exchange_layers_match_oracle(gpu, mode):
     assert info['kernel'] == 'wrnn_loop_kernel' and info['clusters'] == 4 and info['rounds'] == 1
     NG = (B + 15) // 16
     for t in range(T):
-        for g in range(NG):
+        for g in range(NG if t >= T - 2 else 0):
             b0, b1 = (g * B) // NG, ((g + 1) * B) // NG
             for layer, key in ((0, 'h1'), (1, 'h2')):
                 got = eng.read_exchange(g % 4, g // 4, layer, t % 3)[:b1 - b0]

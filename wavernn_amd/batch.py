@@ -146,7 +146,7 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
     stand-in to exercise the sharding / gather logic under gloo); the default is the model's LoopEngine.
     """
     import torch.distributed as dist
-    from .rng import draw_noise
+    from .rng import draw_noise, draw_steps
     if noise_source == 'cpu' and seeds is None:
         raise ValueError("noise_source='cpu' (parity noise) needs `seeds` (one per utterance); "
                          "pass noise_source='device' to draw from the device generator instead")
@@ -194,17 +194,28 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
             rebase = np.array([local_off[int(u)] - int(plan.offsets[int(u)]) for u in plan.seg_utt[clo:chi]], dtype=np.int64)
             seg_pos = (plan.seg_pos[clo:chi].astype(np.int64) + rebase).astype(np.int32)
             seg_lim = (plan.seg_lim[clo:chi].astype(np.int64) + rebase).astype(np.int32)
+            n_seg, T = chi - clo, plan.T
+            out_view = out_local[clo - lo:chi - lo]
+            eng = model._loop_engine() if loop_fn is None else None
             if noise_source == 'cpu':
                 nz = pack_noise(mode, plan, noise, clo, chi).to(device)
+            elif eng is not None and eng.plan(n_seg, T, algo=model.loop_algo)['kernel'] == 'wrnn_loop_kernel':
+                # device noise in slices of steps (RAW is n_classes floats per segment-step): each slice continues the loop
+                per_step = n_seg * (11 if mode == 'MOL' else model.n_classes) * 4
+                steps = max(1, min(T, getattr(model, 'noise_chunk_bytes', 128 << 20) * 8 // per_step))
+                for t0 in range(0, T, steps):
+                    t1 = min(T, t0 + steps)
+                    nz = draw_steps(mode, n_seg, t1 - t0, model.n_classes, device, 'device')
+                    eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo=model.loop_algo, check=check, out=out_view,
+                                     t_range=None if (t0 == 0 and t1 == T) else (t0, t1))
+                continue
             else:
-                nz = draw_noise(mode, chi - clo, plan.T, model.n_classes, model.rnn_dims, model.aux_dims, device, 'device')
+                nz = draw_noise(mode, n_seg, T, model.n_classes, model.rnn_dims, model.aux_dims, device, 'device')
             if loop_fn is None:
-                eng = model._loop_engine()
-                eng.run_segments(mels_up, aux, seg_pos, seg_lim, plan.T, nz, hop, algo=model.loop_algo, check=check,
-                                 out=out_local[clo - lo:chi - lo])
+                eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo=model.loop_algo, check=check, out=out_view)
             else:
-                out_local[clo - lo:chi - lo] = loop_fn(mels_up, aux, seg_pos, seg_lim, plan.T, nz, hop)
-    if world > 1:
+                out_view[:] = loop_fn(mels_up, aux, seg_pos, seg_lim, T, nz, hop)
+    if group is not None:
         gathered = [torch.empty_like(out_local) for _ in range(world)]
         dist.all_gather(gathered, out_local, group=group)    # the ONE collective of the path: finished audio only
         parts = [gathered[r][:h - l] for r, (l, h) in enumerate(shard_bounds(plan.n_segments, world))]

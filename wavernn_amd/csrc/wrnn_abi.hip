@@ -483,7 +483,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     HIPCHK(hipSetDevice(p->device));
     char *ws = (char *)workspace;
     wrnn_timer *timer = o->timer;
-    if (timer) timer->used = 0;
+    if (timer && pl.t0 == 0) timer->used = 0;            // a continuing call (t_begin > 0) adds its launches to the same total
 
     HIPCHK(hipMemsetAsync(ws + l.status, 0, STATUS_WORDS * sizeof(unsigned), stream));
     // segment table -> device (pageable source: the runtime stages it before returning)

@@ -57,6 +57,7 @@ class LoopEngine:
         self._timer = timer
         self._info = _lib.RunInfo()
         self._last_opts = None
+        self._launches = 0
 
     def __del__(self):
         try:
@@ -157,6 +158,7 @@ class LoopEngine:
                                              mels_up.data_ptr(), aux.data_ptr(), noise.data_ptr(), out.data_ptr(),
                                              self._ws.data_ptr(), self._ws.numel(), ctypes.byref(o), stream)
         _lib.check(rc, 'wrnn_generate_segments')
+        self._launches = (self._launches if t0 > 0 else 0) + int(self._info.launches)
         self._last_opts = (B, T, n_frames, self.options(algo, depth, clusters, slab_steps, cond_valu, None))
         if check:
             _lib.check(self.lib.wrnn_status(self._ws.data_ptr(), stream), 'loop kernel')
@@ -185,10 +187,11 @@ class LoopEngine:
     def last_run_info(self):
         i = self._info
         return dict(kernel=(i.kernel or b'').decode(), units_per_wg=int(i.units_per_wg), clusters=int(i.clusters), depth=int(i.depth),
-                    rounds=int(i.rounds), slab_steps=int(i.slab_steps), launches=int(i.launches))
+                    rounds=int(i.rounds), slab_steps=int(i.slab_steps), launches=int(self._launches))
 
     def last_loop_ms(self):
-        """Sum of the loop-kernel launch durations of the last call (HIP events on the launch stream; synchronises)."""
+        """Sum of the loop-kernel launch durations of the last call, continuations (t_range with t0 > 0) included (HIP events on
+        the launch stream; synchronises)."""
         return float(self.lib.wrnn_timer_ms(self._timer))
 
     def last_loop_kernel(self):

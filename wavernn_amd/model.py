@@ -236,14 +236,13 @@ class WaveRNN(nn.Module):
             per_step = B * (11 if self.mode == 'MOL' else self.n_classes) * 4
             resumable = eng.plan(B, T, algo=self.loop_algo)['kernel'] == 'wrnn_loop_kernel'
             chunk = max(1, min(T, self.noise_chunk_bytes // per_step)) if resumable else T
-            out, ms = None, 0.0
+            out = None
             for t0 in range(0, T, chunk):
                 t1 = min(T, t0 + chunk)
                 noise = draw_steps(self.mode, B, t1 - t0, self.n_classes, device, self.noise_source)
                 out = eng.run(mels_up, aux, B, T, stride, noise, self.hop_length, algo=self.loop_algo, out=out,
                               t_range=None if (t0 == 0 and t1 == T) else (t0, t1))
-                ms += eng.last_loop_ms()
-            self.last_loop_ms = ms
+            self.last_loop_ms = eng.last_loop_ms()
             self.last_loop_kernel = eng.last_loop_kernel()
 
         if self.post_algo == 'native':
