@@ -125,6 +125,8 @@ typedef struct wrnn_options {
     int32_t reserved;
     const float *force_x;    /* test hook, device [n,T]: value fed back as x_t instead of the sample (teacher forcing) */
     float *logits;           /* test hook, device [T,n,C]: fc3 output of every step (:223) */
+    unsigned long long *phase_clocks; /* profiling hook, device [256 workgroups][32] zeroed by the caller: the loop kernel (MOL) adds
+                                its per-(phase, stage segment) shader clocks (layout: csrc/wrnn_loop.hip, "PROF") */
     wrnn_timer *timer;       /* optional: time the loop kernel(s) of this call */
     wrnn_run_info *info;     /* optional out */
 } wrnn_options;
@@ -193,7 +195,7 @@ int wrnn_plan_segments(const wrnn_pack *p, int32_t n_segments, int32_t T, const 
 int wrnn_status(void *workspace, void *stream);
 
 /* Test hook: one exchanged activation layer (0 h1, 1 h2, 2 y1, 3 y2, 4 RAW logits) of (cluster, slot) at ring position `ring`
- * (= step % 3) of the loop kernel's exchange buffer, un-permuted from MFMA-fragment order into host_out[16 segments][512].
+ * (= step % 4) of the loop kernel's exchange buffer, un-permuted from MFMA-fragment order into host_out[16 segments][512].
  * Call after a run with the same (n_segments, T, n_frames, opt).  Synchronises the device. */
 int wrnn_debug_read_exchange(const wrnn_pack *p, void *workspace, int32_t n_segments, int32_t T, int32_t n_frames,
                              const wrnn_options *opt, int cluster, int slot, int layer, int ring, float *host_out);

@@ -69,8 +69,8 @@ def test_device_selftests(gpu):
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_exchange_layers_match_oracle(gpu, mode):
     """Stage-level check of the loop kernel (test hook `wrnn_debug_read_exchange`): after a 3-step run of 40 segments
-    (3 groups on 3 clusters) the exchanged h1 / h2 of the last two steps still sit in the 3-deep ring (the slot of step 0 was
-    re-armed for step 3), in MFMA-fragment order; un-permuted they must equal the numpy oracle's GRU states -- localises
+    (3 groups on 3 clusters) the exchanged h1 / h2 of the last step still sit in the 4-deep ring (the other slots were
+    re-armed for later steps), in MFMA-fragment order; un-permuted they must equal the numpy oracle's GRU states -- localises
     a wrong stage instead of a wrong waveform."""
     from oracle import wavernn_oracle as O
     from wavernn_amd.engine import LoopEngine
@@ -89,10 +89,10 @@ def test_exchange_layers_match_oracle(gpu, mode):
     assert info['kernel'] == 'wrnn_loop_kernel' and info['clusters'] == 4 and info['rounds'] == 1
     NG = (B + 15) // 16
     for t in range(T):
-        for g in range(NG if t >= T - 2 else 0):
+        for g in range(NG if t == T - 1 else 0):                    # only the last step's slot has not been re-armed
             b0, b1 = (g * B) // NG, ((g + 1) * B) // NG
             for layer, key in ((0, 'h1'), (1, 'h2')):
-                got = eng.read_exchange(g % 4, g // 4, layer, t % 3)[:b1 - b0]
+                got = eng.read_exchange(g % 4, g // 4, layer, t % 4)[:b1 - b0]       # ring of 4 slots by step
                 np.testing.assert_allclose(got, rec[key][t][b0:b1], rtol=0, atol=2e-6, err_msg=f'{key} step {t} group {g}')
         np.testing.assert_allclose(logits[t].cpu().numpy(), rec['logits'][t], rtol=0, atol=2e-5, err_msg=f'logits step {t}')
     if mode == 'RAW':

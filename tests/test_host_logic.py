@@ -189,3 +189,56 @@ def test_gen_corpus_input_checks(tmp_path):
         with pytest.raises(ValueError):
             G.load_mels(tmp_path)
         os.remove(tmp_path / name)
+
+
+def test_pruner_follows_the_reference_schedule_and_rule():
+    """`prune.Pruner` / `PruneMask` = the reference notebook's workflow ("Pruning - Scratchpad" :40-186): cubic schedule,
+    re-mask every `prune_every` steps, per-gate magnitude rule with `>=` ties; plus the 16x1 block form config 5 uses."""
+    import torch.nn as nn
+    from wavernn_amd.prune import Pruner, PruneMask, block_mask, wavernn_pruner
+    torch.manual_seed(3)
+    rnn, fc = nn.GRU(32, 48), nn.Linear(48, 48)
+    layers = [rnn, fc]
+    pr = Pruner(layers, start_prune=10, prune_steps=200, target_sparsity=0.9375, prune_every=5)
+    assert pr.total_params == 3 * 48 * 32 + 3 * 48 * 48 + 48 * 48
+    t = torch.zeros(1)
+    zs = []
+    for step in range(260):
+        pr.prune(layers, t)
+        zs.append(pr.z)
+        t += 1
+    expect = [max(0.0, min(0.9375, 0.9375 * (1 - (1 - (s - 10) / 200) ** 3))) for s in range(260)]
+    assert np.allclose(zs, expect) and zs[9] == 0 and zs[-1] == 0.9375
+    # final masks: per gate exactly k = int(n * Z) entries zeroed (no ties in random weights), weights really zero
+    for W, gates in ((rnn.weight_ih_l0, 3), (rnn.weight_hh_l0, 3), (fc.weight, 1)):
+        for Wg in torch.split(W.data, W.size(0) // gates):
+            assert int((Wg == 0).sum()) == int(Wg.numel() * 0.9375)
+    assert pr.num_pruned == sum(int(W.numel() / g * 0.9375) * g for W, g in ((rnn.weight_ih_l0, 3), (rnn.weight_hh_l0, 3), (fc.weight, 1)))
+    # the notebook's rule, restated directly, on one gate matrix
+    W = torch.randn(3 * 16, 24)
+    m = PruneMask(nn.GRU(24, 16), True)
+    M = m.mask_from_matrix(W, 0.5)
+    for g in range(3):
+        Wg = W[16 * g:16 * (g + 1)].abs()
+        thr = torch.sort(Wg.reshape(-1))[0][int(Wg.numel() * 0.5)]
+        assert torch.equal(M[16 * g:16 * (g + 1)], (Wg >= thr).float())
+    # block form == the numpy recipe config 5's fixtures use
+    Wb = torch.randn(3 * 64, 40)
+    mb = PruneMask(nn.GRU(40, 64), True, block=(16, 1))
+    assert np.array_equal(mb.mask_from_matrix(Wb, 0.95).numpy(), block_mask(Wb.numpy(), 0.95, (16, 1)))
+    # restart rebuilds the masks from pruned weights; rnn input pruning can be switched off (notebook's prune_rnn_input)
+    pr2 = Pruner(layers, 10, 200, 0.9375, prune_rnn_input=False, prune_every=5)
+    pr2.restart(layers, torch.tensor([400.]))
+    assert pr2.z == 0.9375 and len(pr2.masks[0].mask) == 1 and pr2.num_pruned > 0
+    # the WaveRNN convenience wrapper + the step hook
+    from wavernn_amd.model import WaveRNN
+    from wavernn_amd.synthetic import SHIPPED
+    model = WaveRNN(**SHIPPED, mode='MOL')
+    pruner, lay = wavernn_pruner(model, start_prune=0, prune_steps=10, target_sparsity=0.95, prune_every=1)
+    hook = pruner.step_hook(lay, model.get_step)
+    for _ in range(12):
+        model.step += 1
+        hook()
+    W = model.rnn1.weight_hh_l0.data.numpy()
+    dens = (np.abs(W).reshape(3, 32, 16, 512).sum(axis=2) != 0).mean()
+    assert abs(dens - 0.05) < 0.002, dens                      # 16x1 blocks, 5 % survive per gate

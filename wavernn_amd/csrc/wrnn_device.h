@@ -24,10 +24,10 @@ constexpr int SPCL = 8;       // block-sparse kernel: 8 clusters (one per XCD)
 constexpr int SPG = 2;        // ... with up to 2 groups in flight each
 constexpr int GRAN_WORDS = SPCL * SPG * NGRAN * SEG * H;     // u64 granules in the workspace (>= MAXCL * MAXG * ...)
 static_assert(SPCL * SPG >= MAXCL * MAXG, "granule workspace");
-// role-split loop kernel (wrnn_loop.hip): tag-free exchange buffer [cluster][slot][layer h1 h2 y1 y2 lg][ring][SEG*H floats]
+// role-split loop kernel (wrnn_loop.hip): tag-free exchange buffer [cluster][slot][layer h1 h2 y1 y2 lg x1 x2][ring][SEG*H floats]
 constexpr int LMAXG = 8;      // slots (groups in flight) per cluster the exchange buffer is sized for
-constexpr int NXLAYER = 5;
-constexpr int XRING = 3;
+constexpr int NXLAYER = 7;      // h1, h2, y1, y2, RAW logits, x1 = xi + h1, x2 = x1 + h2
+constexpr int XRING = 4;
 constexpr size_t XBUF_FLOATS = (size_t)MAXCL * LMAXG * NXLAYER * XRING * SEG * H;
 constexpr int STATUS_WORDS = 16;
 constexpr int NPROF = 16;     // phase counters per workgroup (wrnn_pipe.hip PROF builds)

@@ -12,16 +12,17 @@
 //     so every v_mfma_f32_16x16x4_f32 tile is 16 live rows (gate g of the 16 owned units; 7 tiles per workgroup against
 //     10 two-thirds-full ones before; 224 weight registers, which fit the AGPR half of the register file -- 9 tiles did not
 //     and spilled the B operands).  fc3 lives in LDS in A-fragment order: MOL -- every workgroup holds all 30 rows (2 tiles)
-//     and samples redundantly, no 5th exchange; RAW -- workgroup wg owns logit rows [8 wg, 8 wg + 8) and the 512 logits are
-//     a 5th exchange.
+//     and samples redundantly, no 5th exchange; RAW -- role-A workgroup J owns logit rows [16 J, 16 J + 16) and the 512
+//     logits are a 5th exchange.  Only role A needs x_t (for xi), so only role A runs fc3 and samples.
 //   * TAG-FREE exchange in MFMA-FRAGMENT ORDER.  A layer (h1, h2, y1, y2, RAW logits) of a group is 16 segments x 512 f32 =
 //     32 KB stored as [wave w][k-block r][lane][4]: exactly the B fragments wave w feeds its MFMAs, so a consumer wave
 //     loads its operands with 8 buffer_load_dwordx4 (sc1) straight into registers -- no LDS staging, no sweep barrier, half
 //     the bytes of the 8-byte {tag, value} granules.  Arrival is detected by value: every slot is pre-filled with a
 //     sentinel NaN pattern (0xFFFFFFFF, which no finite activation takes) and a consumer re-reads until none of its 32
-//     words is the sentinel.  Slots form a ring of 3 by step; a producer re-arms its own part of slot (t+1) % 3 at the top
-//     of step t, by which time every consumer is provably done with step t-2, and drains its stores (s_waitcnt vmcnt(0))
-//     before it publishes anything of step t, so the re-arm is visible before any poll of step t+1 can start.
+//     words is the sentinel.  Slots form a ring of 4 by step; a producer wave re-arms its own words of slot (t+3) % 4 at the
+//     end of step t (it holds step t-1, which every consumer is provably done with), and drains its stores (s_waitcnt
+//     vmcnt(0)) at the end of step t+1, before it publishes anything of step t+2 -- so the re-arm is visible before any
+//     poll of step t+3 can start (such a poll follows data that depends on those publications).
 //     A producer's 16 units x 16 segments are one contiguous 1 KB block of the layer: 64 lanes x 16-byte sc1 stores.
 //   * no activation tile in LDS at all: the residual sums x1 = xi + h1, x2 = x1 + h2 (:212,:216) are re-formed in registers
 //     from the conditioning slab and the ring slots (still valid: re-armed two steps later), each wave touching only its own
@@ -31,6 +32,8 @@
 //     the host loops slabs x rounds, the kernel saves / restores its per-group state, the workspace no longer scales with T.
 // Arithmetic and summation order per output are those of wrnn_cluster.hip / wrnn_pipe.hip (K split over 4 waves, two
 // accumulator chains per tile, partials added in wave order), so results are bit-identical to those kernels.
+#include <type_traits>
+
 #include "wrnn_tiles.h"
 
 namespace wrnn {
@@ -41,12 +44,14 @@ constexpr int LNWGC = 2 * LNJ;               // workgroups per cluster (64)
 constexpr int XT = SEG * H;                  // floats of one layer in fragment order (8192)
 constexpr unsigned SENT = 0xFFFFFFFFu;       // "not written yet"
 
-// LDS carve (floats).  Per group: GH[3][256], HOWN[256], XS[16], SP[32 ints]
-constexpr int LGRP = 3 * 256 + 256 + 16 + 32;
-constexpr int O_HOWN = 768, O_XS = 1024, O_SP = 1040;
+// LDS carve (floats).  Per group: GH[3][256], HOWN[256], XS[16], SP[32 ints] (segment table), FR[2][16 ints] (conditioning frame
+// of every segment at step t in FR[t & 1]; the other half is filled for step t+1 during step t)
+//   XO[256]: the owned 16 units x 16 segments of the residual input of this workgroup's GRU (role A: xi, role B: x1), in publish order
+constexpr int LGRP = 3 * 256 + 256 + 16 + 32 + 32 + 256;
+constexpr int O_HOWN = 768, O_XS = 1024, O_SP = 1040, O_FR = 1072, O_XO = 1104;
 constexpr int LPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][slot 0..2][16][16]
 struct LoopLds {
-    int off_part, off_log, off_wi0, off_f3, off_lgt, off_misc, total;
+    int off_part, off_log, off_wi0, off_f3, off_lgt, off_misc, off_prof, total;
 };
 __host__ __device__ inline LoopLds loop_lds(int mode, int G)
 {
@@ -57,7 +62,8 @@ __host__ __device__ inline LoopLds loop_lds(int mode, int G)
     l.off_wi0 = o;  o += H;
     l.off_f3 = o;   o += (mode == 1 ? 2 : 1) * XT;         // fc3 in A-fragment order [tile][wave][r][lane][4]
     l.off_lgt = o;  o += (mode == 0) ? SEG * LDC : 0;      // RAW: the gathered logits as [segment][class] rows
-    l.off_misc = o; o += 16;                               // [0] failure flag
+    l.off_misc = o; o += 16 + 2 * LMAXG;                   // [0] failure flag; [16 + 2 i], [17 + 2 i]: first segment / segment count of slot i
+    l.off_prof = o; o += 2 * 32;                           // [4 phases][8] u64 phase clocks (profiling builds)
     l.total = o;
     return l;
 }
@@ -65,17 +71,23 @@ __host__ __device__ inline LoopLds loop_lds(int mode, int G)
 // fragment-order offset (floats) of (wave w, k-block r, lane): 4 consecutive k of one segment
 __device__ __forceinline__ int frag_off(int w, int r, int lane) { return ((w * 8 + r) * 64 + lane) * 4; }
 
-// Load this wave's 8 B fragments of one exchanged layer (byte offset soff in the exchange buffer) until no word is the
-// sentinel.  Lanes of segments >= nb are not waited for and read as zero.  Wave-uniform result; bounded spin.
-__device__ __forceinline__ bool consume(__amdgpu_buffer_rsrc_t rs, int soff, int w, int lane, int nb, float (&b)[32], unsigned *status)
+// This wave's 8 B fragments of one exchanged layer (byte offset soff in the exchange buffer), as two halves so a stage can put
+// work between them: issue() fires the 8 buffer_load_dwordx4 (sc1); finish() checks that no word is still the sentinel and,
+// only if one is, falls into the polling loop (re-load, bounded spin).  Lanes of segments >= nb are not waited for and
+// read as zero.  Wave-uniform result.
+__device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, int soff, int w, int lane, u32x4 (&x)[8])
+{
+    const int voff = frag_off(w, 0, lane) * 4;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + r * 1024, soff, 16 /* sc1 */);
+}
+__device__ __forceinline__ bool finish(__amdgpu_buffer_rsrc_t rs, int soff, int w, int lane, int nb, u32x4 (&x)[8], float (&b)[32],
+                                       unsigned *status, unsigned &spins)
 {
     const int voff = frag_off(w, 0, lane) * 4;
     const bool live = (lane & 15) < nb;
-    unsigned spins = 0;
-    u32x4 x[8];
+    spins = 0;
     for (;;) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + r * 1024, soff, 16 /* sc1 */);
         bool ok = true;
 #pragma unroll
         for (int r = 0; r < 8; ++r) ok &= (x[r].x != SENT) & (x[r].y != SENT) & (x[r].z != SENT) & (x[r].w != SENT);
@@ -85,6 +97,8 @@ __device__ __forceinline__ bool consume(__amdgpu_buffer_rsrc_t rs, int soff, int
             if (spins > SPIN_LIMIT || ld_agent32(status) != 0u) return false;
         }
         __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + r * 1024, soff, 16 /* sc1 */);
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -106,8 +120,6 @@ __device__ __forceinline__ void publish4(__amdgpu_buffer_rsrc_t rs, int soff /* 
     const int v1 = __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xF, 0xF, true);     // [1,1,1,1]
     const int v2 = __builtin_amdgcn_update_dpp(0, iv, 0xAA, 0xF, 0xF, true);     // [2,2,2,2]
     const int v3 = __builtin_amdgcn_update_dpp(0, iv, 0xFF, 0xF, 0xF, true);     // [3,3,3,3]
-    // every earlier store of this wave (the re-arm of this block's next ring slot) has left before the data goes out
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (on && (tid & 3) == 0) {
         const u32x4 q = {(unsigned)v0, (unsigned)v1, (unsigned)v2, (unsigned)v3};
         __builtin_amdgcn_raw_buffer_store_b128(q, rs, (tid & ~3) * 4, soff, 16 /* sc1 */);
@@ -115,14 +127,14 @@ __device__ __forceinline__ void publish4(__amdgpu_buffer_rsrc_t rs, int soff /* 
 }
 
 // Re-arm (fill with the sentinel) THIS WAVE's quarter (64 floats = 16 lanes x 16 bytes) of the workgroup's block in up to
-// three layers of a ring slot: lanes 0-15 layer la, 16-31 layer lb, 32-47 layer lc (lc < 0: none).  Each wave re-arms exactly
-// the words it later publishes, so its own program order + the vmcnt(0) drain in publish4 order re-arm before data.
+// four layers of a ring slot: lanes 0-15 layer la, 16-31 lb, 32-47 lc, 48-63 ld (< 0: none).  Each wave re-arms exactly the
+// words it later publishes, so its own program order + the vmcnt(0) drain at the end of the next step order re-arm before data.
 __device__ __forceinline__ void rearm(__amdgpu_buffer_rsrc_t rs, int soff_slot0 /* bytes: layer 0 of the slot + block + quarter */,
-                                      int lane, int la, int lb, int lc)
+                                      int lane, int la, int lb, int lc, int ld)
 {
     const int which = lane >> 4;
-    const int layer = which == 0 ? la : (which == 1 ? lb : lc);
-    if (which < 3 && layer >= 0) {
+    const int layer = which == 0 ? la : (which == 1 ? lb : (which == 2 ? lc : ld));
+    if (layer >= 0) {
         const u32x4 q = {SENT, SENT, SENT, SENT};
         __builtin_amdgcn_raw_buffer_store_b128(q, rs, layer * (XRING * XT * 4) + (lane & 15) * 16, soff_slot0, 16 /* sc1 */);
     }
@@ -184,15 +196,6 @@ __device__ __forceinline__ f32x4 mfma1_lds(const float *a_lane /* F3 tile + frag
     return c0 + c1;
 }
 
-// this wave's 8 fragments of a layer that is known to be complete (it was consumed earlier in the step): no check; sc1, so
-// never served from this CU's L1 (which may still hold the slot's lines of three steps ago)
-__device__ __forceinline__ void reload(__amdgpu_buffer_rsrc_t rs, int soff, int w, int lane, u32x4 (&x)[8])
-{
-    const int voff = frag_off(w, 0, lane) * 4;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + r * 1024, soff, 16 /* sc1 */);
-}
-
 // this wave's 8 conditioning fragments cI(t) of one group (plain loads: written by the previous kernel on the stream)
 __device__ __forceinline__ void load_cI(const float *cI_grp, int w, int lane, float4 (&c)[8])
 {
@@ -217,7 +220,10 @@ __device__ __forceinline__ void make_xi(const float4 (&c)[8], const float *WI0, 
 
 // The whole life of one workgroup in one role (compile-time, so the two roles are disjoint code with separate register
 // allocations).  MODE: 0 RAW (C == 512), 1 MOL (C == 30).
-template <int MODE, bool roleA>
+// PROF: thread 0 accumulates shader clocks per (phase, segment of the stage) in LDS and writes them to a.prof at the end:
+//   [phase 0..3][0 issue, 1 barrier wait of the previous stage's back half, 2 its pointwise + publish, 3 load wait / poll,
+//                4 operand build, 5 MFMA + partial tiles, 6 stages, 7 stages whose first check found a sentinel]
+template <int MODE, bool roleA, bool PROF>
 __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl, int wg, int ncl)
 {
     constexpr bool MOL = MODE == 1;
@@ -225,6 +231,17 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     const LoopLds L = loop_lds(MODE, G);
     float *PART = smem + L.off_part, *LOG = smem + L.off_log, *WI0 = smem + L.off_wi0, *F3 = smem + L.off_f3, *LGT = smem + L.off_lgt;
     int *FAIL = reinterpret_cast<int *>(smem + L.off_misc);
+    int *GEO = FAIL + 16;                                // [2 i] first segment of slot i's group in the call's table, [2 i + 1] its count
+    u64 *PROFL = reinterpret_cast<u64 *>(smem + L.off_prof);
+    u64 plast = 0;
+#define PH(k)                                                                  \
+    do {                                                                       \
+        if (PROF && tid == 0) {                                                \
+            const u64 now_ = __builtin_amdgcn_s_memtime();                     \
+            PROFL[k] += now_ - plast;                                          \
+            plast = now_;                                                      \
+        }                                                                      \
+    } while (0)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int J = wg >> 1;                              // owned units [16 J, 16 J + 16)
@@ -236,7 +253,6 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     const int NR = a.Btot, Nall = a.Nall;               // segments of this round / of the whole call (row stride of noise, logits)
     const int NGR = a.NG;                               // groups of this round
     const bool leader = wg == 0;
-    const int f3half = wg & 1;                          // RAW: logit rows [8 wg, 8 wg + 8) = units 8 f3half .. + 8 of block J
 
     // ---- one-time: weight slice -> register-resident MFMA A fragments (7 tiles = 224 registers) ------------------------
     float A_ih[3][AF], A_hh[3][AF], A_fc[AF];
@@ -260,13 +276,13 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     WI0[2 * tid] = a.I_w0[2 * tid];
     WI0[2 * tid + 1] = a.I_w0[2 * tid + 1];
     // fc3 -> LDS in A-fragment order: F3[tile s][wave][r][lane (row fi, k-quad kq)][4] = fc3_w[row(s, fi)][128 wave + 16 r + 4 kq ..]
-    for (int q = tid; q < (MOL ? 2 : 1) * (XT / 4); q += NT) {
+    for (int q = tid; q < (roleA ? (MOL ? 2 : 1) * (XT / 4) : 0); q += NT) {
         const int l6 = q & 63, r = (q >> 6) & 7, wv = (q >> 9) & 3, sidx = q >> 11;
         const int rfi = l6 & 15, rkq = l6 >> 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         int row = -1;
         if (MOL) { if (16 * sidx + rfi < 30) row = 16 * sidx + rfi; }
-        else { if ((rfi >> 3) == f3half) row = LU * J + rfi; }
+        else { row = LU * J + rfi; }                                   // RAW: role-A workgroup J owns logit rows [16 J, 16 J + 16)
         if (row >= 0) v = *reinterpret_cast<const float4 *>(a.fc3_w + (size_t)row * H + KCH * wv + 16 * r + 4 * rkq);
         reinterpret_cast<float4 *>(F3)[q] = v;
     }
@@ -280,6 +296,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
         float *GP = smem + i * LGRP;
         const int g = cl + ncl * i;
         const int b0 = (int)(((long)g * NR) / NGR), nb = (int)(((long)(g + 1) * NR) / NGR) - b0;
+        if (tid == 0) { GEO[2 * i] = a.rb0 + b0; GEO[2 * i + 1] = nb; }
         if (a.resume) {
             const float4 *src = reinterpret_cast<const float4 *>(a.state + state_wg + (size_t)i * LGRP);
             for (int q = tid; q < LGRP / 4; q += NT) reinterpret_cast<float4 *>(GP)[q] = src[q];
@@ -293,6 +310,8 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                 const int sc = a.rb0 + b0 + (tid < nb ? tid : nb - 1);
                 SP[tid] = a.seg_pos[sc];
                 SP[SEG + tid] = a.seg_lim[sc];
+                const int p0 = SP[tid] + T0;
+                reinterpret_cast<int *>(GP + O_FR)[SEG * (T0 & 1) + tid] = (p0 < SP[SEG + tid]) ? (p0 / a.hop) : a.NF;
             }
         }
     }
@@ -308,249 +327,99 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     int t = T0;
 
 #define XLAYER(i, layer, ring) ((((xcl + (i)) * NXLAYER + (layer)) * XRING + (ring)) * XT)
-#define STAGE_BARRIER()                                        \
-    do {                                                       \
-        if (!ok) FAIL[0] = 1;                                  \
-        __syncthreads();                                       \
-        if (FAIL[0] != 0) goto bail;                           \
-    } while (0)
-#define PARTP (PART + pp * (NW * 3 * 256))
-#define GROUP_NB(g) ((int)(((long)((g) + 1) * NR) / NGR) - (int)(((long)(g) * NR) / NGR))
+#define PARTOF(q) (PART + (q) * (NW * 3 * 256))
 
-    for (; t < T1; ++t) {
-        const int ring = t % XRING, ringn = (t + 1) % XRING;
-        const int tc = t - a.cI_t0;                     // row of the conditioning slab
+    // ---- software pipeline, one stage deep.  A STAGE = (phase, group).  Its FRONT half issues the stage's loads, then -- while
+    //      they fly -- runs the BACK half of the previous stage (the workgroup barrier, the 4-wave partial sum, the pointwise
+    //      math, the publish), then checks the loads, runs the MFMA tiles and writes this wave's partial tiles.  One wave per
+    //      SIMD cannot hide a load behind another wave; this hides every stage's loads behind the previous stage's barrier +
+    //      pointwise half instead.  The pending back half is described by (bk, bi, bpp, bt, bc*).
+    enum { BK_NONE = 0, BK_GATES, BK_GH, BK_RELU, BK_SAMPLE };
+    int bk = BK_NONE, bi = 0, bpp = 0, bt = 0, cur_ph = 0;
+    float bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
 
-        // ---- re-arm this wave's words of the NEXT step's ring slot (every consumer is done with step t-2) ---------------
-#pragma unroll 1
-        for (int i = 0; i < nact; ++i)
-            rearm(xrs, (XLAYER(i, 0, ringn) + 256 * J + 64 * w) * 4, lane, roleA ? 0 : 1, roleA ? 2 : 3,
-                  (!MOL && (w >> 1) == f3half) ? 4 : -1);
-        __syncthreads();                                 // x_{t-1} of the last group sampled in the previous step is visible
-
-        // =========================== P1 (role A): rnn1 gates (fatchord_version.py:208-210) =======================
-        if constexpr (roleA) {
-#pragma unroll 1
-            for (int i = 0; i < nact; ++i) {
-                float *GP = smem + i * LGRP;
-                const int g = cl + ncl * i;
-                const int nb = GROUP_NB(g);
-                float b[32];
-                {
-                    float4 c[8];
-                    load_cI(a.cIf + ((size_t)tc * NGR + g) * XT, w, lane, c);
-                    make_xi(c, WI0, GP[O_XS + fi], w, lane, b);
-                }
-                f32x4 o0, o1, o2;
-                mfma3(A_ih[0], A_ih[1], A_ih[2], b, o0, o1, o2);
-                put_partial<3>(PARTP, w, 0, lane, o0);
-                put_partial<3>(PARTP, w, 1, lane, o1);
-                put_partial<3>(PARTP, w, 2, lane, o2);
-                STAGE_BARRIER();
-                {
-                    const float gir = get_partial<3>(PARTP, 0, pu, pj) + bi_r;
-                    const float giz = get_partial<3>(PARTP, 1, pu, pj) + bi_z;
-                    const float gin = get_partial<3>(PARTP, 2, pu, pj) + bi_n;
-                    const float hn = gru_update(gir, giz, gin, GP[tid], GP[256 + tid], GP[512 + tid], GP[O_HOWN + tid]);
-                    GP[O_HOWN + tid] = hn;
-                    publish4(xrs, (XLAYER(i, 0, ring) + 256 * J) * 4, tid, hn, pj < nb);
-                }
-                pp ^= 1;
-            }
-        }
-
-        // =========================== P2: h1 arrives.  A: gh1(t+1) = W_hh1 . h1.  B: rnn2 gates on x1 = xi + h1 (:212-214) =====
-#pragma unroll 1
-        for (int i = 0; i < nact; ++i) {
-            float *GP = smem + i * LGRP;
-            const int g = cl + ncl * i;
-            const int nb = GROUP_NB(g);
-            float b[32];
-            if constexpr (roleA) {
-                ok = ok && consume(xrs, XLAYER(i, 0, ring) * 4, w, lane, nb, b, a.status);
-                if (!ok && fcode == 0u) fcode = 0x400u | 1u;
-                f32x4 o0, o1, o2;
-                mfma3(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
-                put_partial<3>(PARTP, w, 0, lane, o0);
-                put_partial<3>(PARTP, w, 1, lane, o1);
-                put_partial<3>(PARTP, w, 2, lane, o2);
-                STAGE_BARRIER();
-                GP[tid] = get_partial<3>(PARTP, 0, pu, pj) + bh_r;
-                GP[256 + tid] = get_partial<3>(PARTP, 1, pu, pj) + bh_z;
-                GP[512 + tid] = get_partial<3>(PARTP, 2, pu, pj) + bh_n;
-            } else {
-                // aux columns of rnn2 + b_ih2: per-frame table (unconditional loads, issued before the poll)
+    // with_sample: the pending half may be a sampling half (compile-time, so RAW's heavy one is inlined at one site only)
+    auto run_back = [&](auto with_sample) -> bool {
+        if (bk == BK_NONE) return true;
+        float *GP = smem + bi * LGRP;
+        const float *PB = PARTOF(bpp);
+        const int nb = GEO[2 * bi + 1];
+        const int bring = bt % XRING;
+        if (!ok) FAIL[0] = 1;
+        __syncthreads();                                   // every wave's partial tiles of the stage are in LDS
+        if (FAIL[0] != 0) return false;
+        PH(8 * cur_ph + 1);
+        if (bk == BK_GATES) {                              // GRU cell pointwise (ATen gru_cell) -> publish h1 (role A) / h2 (role B)
+            const float gir = get_partial<3>(PB, 0, pu, pj) + bc0;
+            const float giz = get_partial<3>(PB, 1, pu, pj) + bc1;
+            const float gin = get_partial<3>(PB, 2, pu, pj) + bc2;
+            const float hn = gru_update(gir, giz, gin, GP[tid], GP[256 + tid], GP[512 + tid], GP[O_HOWN + tid]);
+            GP[O_HOWN + tid] = hn;
+            publish4(xrs, (XLAYER(bi, roleA ? 0 : 1, bring) + 256 * J) * 4, tid, hn, pj < nb);
+            // ... and the residual sum of the owned units, so its consumers load ONE layer: x1 = xi + h1 (:212) for role B's rnn2
+            // gates, x2 = x1 + h2 (:216) for role A's fc1
+            publish4(xrs, (XLAYER(bi, roleA ? 5 : 6, bring) + 256 * J) * 4, tid, GP[O_XO + tid] + hn, pj < nb);
+        } else if (bk == BK_GH) {                          // gh(t+1) = W_hh . h(t) + b_hh of the owned (unit, segment)
+            GP[tid] = get_partial<3>(PB, 0, pu, pj) + bh_r;
+            GP[256 + tid] = get_partial<3>(PB, 1, pu, pj) + bh_z;
+            GP[512 + tid] = get_partial<3>(PB, 2, pu, pj) + bh_n;
+            if (tid < SEG) {   // conditioning frame of every segment at the NEXT step (Stretch2d: constant over a hop; the fold's zero
+                               // pad -> NF), into the other half of FR: it is first read two stages' barriers from here
                 const int *SP = reinterpret_cast<const int *>(GP + O_SP);
-                const int p = SP[pj] + t;
-                const int f2 = (p < SP[SEG + pj]) ? (p / a.hop) : a.NF;
-                const float c2r = a.c2f[(size_t)f2 * 3 * H + prow];
-                const float c2z = a.c2f[(size_t)f2 * 3 * H + H + prow];
-                const float c2n = a.c2f[(size_t)f2 * 3 * H + 2 * H + prow];
-                float4 c[8];
-                load_cI(a.cIf + ((size_t)tc * NGR + g) * XT, w, lane, c);
-                ok = ok && consume(xrs, XLAYER(i, 0, ring) * 4, w, lane, nb, b, a.status);
-                if (!ok && fcode == 0u) fcode = 0x400u | 2u;
-                {   // x1 = xi + h1 (:212)
-                    float xi[32];
-                    make_xi(c, WI0, GP[O_XS + fi], w, lane, xi);
-#pragma unroll
-                    for (int q = 0; q < 32; ++q) b[q] = xi[q] + b[q];
-                }
-                f32x4 o0, o1, o2;
-                mfma3(A_ih[0], A_ih[1], A_ih[2], b, o0, o1, o2);
-                put_partial<3>(PARTP, w, 0, lane, o0);
-                put_partial<3>(PARTP, w, 1, lane, o1);
-                put_partial<3>(PARTP, w, 2, lane, o2);
-                STAGE_BARRIER();
-                {
-                    const float gir = get_partial<3>(PARTP, 0, pu, pj) + c2r;
-                    const float giz = get_partial<3>(PARTP, 1, pu, pj) + c2z;
-                    const float gin = get_partial<3>(PARTP, 2, pu, pj) + c2n;
-                    const float hn = gru_update(gir, giz, gin, GP[tid], GP[256 + tid], GP[512 + tid], GP[O_HOWN + tid]);
-                    GP[O_HOWN + tid] = hn;
-                    publish4(xrs, (XLAYER(i, 1, ring) + 256 * J) * 4, tid, hn, pj < nb);
-                }
+                const int p1 = SP[tid] + bt + 1;
+                reinterpret_cast<int *>(GP + O_FR)[SEG * ((bt + 1) & 1) + tid] = (p1 < SP[SEG + tid]) ? (p1 / a.hop) : a.NF;
             }
-            pp ^= 1;
-        }
-
-        // =========================== P3: h2 arrives.  A: fc1 + relu on x2 = x1 + h2 (:216-218).  B: gh2(t+1) = W_hh2 . h2 =====
-#pragma unroll 1
-        for (int i = 0; i < nact; ++i) {
-            float *GP = smem + i * LGRP;
-            const int g = cl + ncl * i;
-            const int nb = GROUP_NB(g);
-            float b[32];
-            if constexpr (roleA) {
-                const int *SP = reinterpret_cast<const int *>(GP + O_SP);
-                const int p = SP[pj] + t;
-                const int f3 = (p < SP[SEG + pj]) ? (p / a.hop) : a.NF;
-                const float c3v = a.c3f[(size_t)f3 * H + prow];
-                // x1 is re-formed from the conditioning slab and the h1 slot (both complete; issued ahead of the h2 poll)
-                float4 c[8];
-                u32x4 h1[8];
-                load_cI(a.cIf + ((size_t)tc * NGR + g) * XT, w, lane, c);
-                reload(xrs, XLAYER(i, 0, ring) * 4, w, lane, h1);
-                ok = ok && consume(xrs, XLAYER(i, 1, ring) * 4, w, lane, nb, b, a.status);
-                if (!ok && fcode == 0u) fcode = 0x400u | 3u;
-                {
-                    float xi[32];
-                    make_xi(c, WI0, GP[O_XS + fi], w, lane, xi);
-                    const bool live = fi < nb;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const float h10 = live ? __uint_as_float(h1[r].x) : 0.f, h11 = live ? __uint_as_float(h1[r].y) : 0.f;
-                        const float h12 = live ? __uint_as_float(h1[r].z) : 0.f, h13 = live ? __uint_as_float(h1[r].w) : 0.f;
-                        b[4 * r + 0] = (xi[4 * r + 0] + h10) + b[4 * r + 0];      // (xi + h1) + h2, the reference's order
-                        b[4 * r + 1] = (xi[4 * r + 1] + h11) + b[4 * r + 1];
-                        b[4 * r + 2] = (xi[4 * r + 2] + h12) + b[4 * r + 2];
-                        b[4 * r + 3] = (xi[4 * r + 3] + h13) + b[4 * r + 3];
-                    }
-                }
-                put_partial<3>(PARTP, w, 0, lane, mfma1(A_fc, b));
-                STAGE_BARRIER();
-                publish4(xrs, (XLAYER(i, 2, ring) + 256 * J) * 4, tid, fmaxf(get_partial<3>(PARTP, 0, pu, pj) + c3v, 0.f), pj < nb);
-            } else {
-                ok = ok && consume(xrs, XLAYER(i, 1, ring) * 4, w, lane, nb, b, a.status);
-                if (!ok && fcode == 0u) fcode = 0x400u | 4u;
-                f32x4 o0, o1, o2;
-                mfma3(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
-                put_partial<3>(PARTP, w, 0, lane, o0);
-                put_partial<3>(PARTP, w, 1, lane, o1);
-                put_partial<3>(PARTP, w, 2, lane, o2);
-                STAGE_BARRIER();
-                GP[tid] = get_partial<3>(PARTP, 0, pu, pj) + bh_r;
-                GP[256 + tid] = get_partial<3>(PARTP, 1, pu, pj) + bh_z;
-                GP[512 + tid] = get_partial<3>(PARTP, 2, pu, pj) + bh_n;
-            }
-            pp ^= 1;
-        }
-
-        // =========================== P4 (role B): y1 arrives; fc2 + relu (:220-221) ==============================
-        if constexpr (!roleA) {
-#pragma unroll 1
-            for (int i = 0; i < nact; ++i) {
-                float *GP = smem + i * LGRP;
-                const int g = cl + ncl * i;
-                const int nb = GROUP_NB(g);
-                const int *SP = reinterpret_cast<const int *>(GP + O_SP);
-                const int p = SP[pj] + t;
-                const int f4 = (p < SP[SEG + pj]) ? (p / a.hop) : a.NF;
-                const float c4v = a.c4f[(size_t)f4 * H + prow];
-                float b[32];
-                ok = ok && consume(xrs, XLAYER(i, 2, ring) * 4, w, lane, nb, b, a.status);
-                if (!ok && fcode == 0u) fcode = 0x400u | 5u;
-                put_partial<3>(PARTP, w, 0, lane, mfma1(A_fc, b));
-                STAGE_BARRIER();
-                publish4(xrs, (XLAYER(i, 3, ring) + 256 * J) * 4, tid, fmaxf(get_partial<3>(PARTP, 0, pu, pj) + c4v, 0.f), pj < nb);
-                pp ^= 1;
-            }
-        }
-
-        // =========================== P5 (both roles): y2 arrives; fc3 (:223) + sampling (:225-237) ===================
-#pragma unroll 1
-        for (int i = 0; i < nact; ++i) {
-            float *GP = smem + i * LGRP;
+        } else if (bk == BK_RELU) {                        // fc1 / fc2 + relu -> publish y1 (role A) / y2 (role B)
+            publish4(xrs, (XLAYER(bi, roleA ? 2 : 3, bring) + 256 * J) * 4, tid, fmaxf(get_partial<3>(PB, 0, pu, pj) + bc0, 0.f), pj < nb);
+        } else if constexpr (decltype(with_sample)::value) {   // fc3 logits -> sample x_t (both roles, redundantly)
             float *XS = GP + O_XS;
-            const int g = cl + ncl * i;
-            const int nb = GROUP_NB(g);
-            const int b0 = a.rb0 + (int)(((long)g * NR) / NGR);           // first segment of the group in the call's segment table
-            const size_t tn = (size_t)(t - a.noise_t0);
-            float b[32];
+            const int b0 = GEO[2 * bi];                                   // first segment of the group in the call's segment table
             if constexpr (MOL) {
-                // this step's sampling noise, pre-transformed (wrnn_noise_mol_kernel): thread (segment tid >> 4, mixture tid & 15)
-                const int su = tid >> 4, sm = tid & 15;
-                const float *nrow = a.noise_pre + tn * 11 * Nall;
-                const int suc = su < nb ? su : nb - 1;
-                const float nz0 = nrow[(size_t)(b0 + suc) * 10 + (sm < 10 ? sm : 9)];
-                const float nz1 = nrow[(size_t)10 * Nall + b0 + suc];
-                ok = ok && consume(xrs, XLAYER(i, 3, ring) * 4, w, lane, nb, b, a.status);
-                if (!ok && fcode == 0u) fcode = 0x400u | 6u;
-                put_partial<3>(PARTP, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
-                put_partial<3>(PARTP, w, 1, lane, mfma1_lds(F3 + XT + frag_off(w, 0, lane), b));
-                STAGE_BARRIER();
                 {   // 30 logit rows x 16 segments: thread (row tid >> 4 and 16 + row, segment tid & 15)
                     const int row = tid >> 4, sj = tid & 15;
-                    const float lg = get_partial<3>(PARTP, 0, row, sj) + b3a;
+                    const float lg = get_partial<3>(PB, 0, row, sj) + b3a;
                     LOG[sj * 32 + row] = lg;
-                    if (a.dbg_logits && leader && sj < nb) a.dbg_logits[((size_t)t * Nall + b0 + sj) * C + row] = lg;
+                    if (a.dbg_logits && leader && sj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + sj) * C + row] = lg;
                     if (row < 14) {
-                        const float lg2 = get_partial<3>(PARTP, 1, row, sj) + b3b;
+                        const float lg2 = get_partial<3>(PB, 1, row, sj) + b3b;
                         LOG[sj * 32 + 16 + row] = lg2;
-                        if (a.dbg_logits && leader && sj < nb) a.dbg_logits[((size_t)t * Nall + b0 + sj) * C + 16 + row] = lg2;
+                        if (a.dbg_logits && leader && sj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + sj) * C + 16 + row] = lg2;
                     }
                 }
                 __syncthreads();
-                {   // utils/distribution.py:102-121: 16-lane row = one segment (su), lane sm = mixture
-                    float best = (sm < 10) ? mol_gumbel_pre(LOG[su * 32 + sm], nz0) : -INFINITY;
+                {   // utils/distribution.py:102-121: 16-lane row = one segment (su), lane sm = mixture; bc0 / bc1 = this thread's noise
+                    const int su = tid >> 4, sm = tid & 15;
+                    float best = (sm < 10) ? mol_gumbel_pre(LOG[su * 32 + sm], bc0) : -INFINITY;
                     int bidx = sm;
                     argmax_row16(best, bidx);
                     if (sm == 0 && su < nb) {
-                        float x = mol_sample_pre(LOG[su * 32 + 10 + bidx], LOG[su * 32 + 20 + bidx], nz1);
-                        if (leader) a.out[(size_t)(b0 + su) * a.T + t] = x;
-                        if (a.force_x) x = a.force_x[(size_t)(b0 + su) * a.T + t];
+                        float x = mol_sample_pre(LOG[su * 32 + 10 + bidx], LOG[su * 32 + 20 + bidx], bc1);
+                        if (leader) a.out[(size_t)(b0 + su) * a.T + bt] = x;
+                        if (a.force_x) x = a.force_x[(size_t)(b0 + su) * a.T + bt];
                         XS[su] = x;
                     }
                 }
             } else {
-                ok = ok && consume(xrs, XLAYER(i, 3, ring) * 4, w, lane, nb, b, a.status);
-                if (!ok && fcode == 0u) fcode = 0x400u | 6u;
-                put_partial<3>(PARTP, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
-                STAGE_BARRIER();
-                publish4(xrs, (XLAYER(i, 4, ring) + 256 * J) * 4, tid, get_partial<3>(PARTP, 0, pu, pj) + b3a, (pj < nb) && ((pu >> 3) == f3half));
-                // the 512 logits of every segment -> LGT [segment][class]
-                ok = ok && consume(xrs, XLAYER(i, 4, ring) * 4, w, lane, nb, b, a.status);
-                if (!ok && fcode == 0u) fcode = 0x400u | 7u;
-                {
+                const size_t tn = (size_t)(bt - a.noise_t0);
+                publish4(xrs, (XLAYER(bi, 4, bring) + 256 * J) * 4, tid, get_partial<3>(PB, 0, pu, pj) + b3a, pj < nb);
+                {   // the 512 logits of every segment -> LGT [segment][class]
+                    u32x4 x[8];
+                    float b[32];
+                    issue(xrs, XLAYER(bi, 4, bring) * 4, w, lane, x);
+                    unsigned spins = 0;
+                    ok = ok && finish(xrs, XLAYER(bi, 4, bring) * 4, w, lane, nb, x, b, a.status, spins);
+                    if (!ok && fcode == 0u) fcode = 0x400u | 7u;
                     float *lp = LGT + fi * LDC + kbase_lane;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) *reinterpret_cast<float4 *>(lp + 16 * r) = make_float4(b[4 * r], b[4 * r + 1], b[4 * r + 2], b[4 * r + 3]);
                 }
-                STAGE_BARRIER();
+                if (!ok) FAIL[0] = 1;
+                __syncthreads();
+                if (FAIL[0] != 0) return false;
                 // fatchord_version.py:232-237: softmax -> Categorical (renormalise) -> argmax(p / q); one wave per 4 segments
 #pragma unroll 1
-                for (int s = 0; s < 4; ++s) {
-                    const int sj = 4 * w + s;
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int sj = 4 * w + s4;
                     if (sj < nb) {                                           // wave-uniform
                         float lg[8], qn[8];
                         float mx = -INFINITY;
@@ -558,7 +427,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                         for (int e = 0; e < 8; ++e) {
                             qn[e] = a.noise[(tn * Nall + b0 + sj) * C + lane + 64 * e];
                             lg[e] = LGT[sj * LDC + lane + 64 * e];
-                            if (a.dbg_logits && leader) a.dbg_logits[((size_t)t * Nall + b0 + sj) * C + lane + 64 * e] = lg[e];
+                            if (a.dbg_logits && leader) a.dbg_logits[((size_t)bt * Nall + b0 + sj) * C + lane + 64 * e] = lg[e];
                             mx = fmaxf(mx, lg[e]);
                         }
 #pragma unroll
@@ -588,21 +457,144 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                         }
                         if (lane == 0) {
                             float x = 2.f * (float)bidx / ((float)C - 1.f) - 1.f;
-                            if (leader) a.out[(size_t)(b0 + sj) * a.T + t] = x;
-                            if (a.force_x) x = a.force_x[(size_t)(b0 + sj) * a.T + t];
+                            if (leader) a.out[(size_t)(b0 + sj) * a.T + bt] = x;
+                            if (a.force_x) x = a.force_x[(size_t)(b0 + sj) * a.T + bt];
                             XS[sj] = x;
                         }
                     }
                 }
                 __syncthreads();                         // LGT is read by every wave before the next group overwrites it
             }
-            pp ^= 1;
-            if (t + 1 < T1) {   // pull the next step's conditioning block of this group (32 KB) into this XCD's L2
-                asm volatile("" ::"v"(touch));
-                touch = a.cIf[((size_t)(tc + 1) * NGR + g) * XT + 32 * tid];
+            // x_t is read by EVERY wave in this group's first stage of the next step; with one group in flight that is the very
+            // next front half (with more, other stages' barriers lie in between)
+            if (nact == 1) __syncthreads();
+        }
+        bk = BK_NONE;
+        PH(8 * cur_ph + 2);
+        return true;
+    };
+
+    for (; t < T1; ++t) {
+        const int ring = t % XRING;
+        const int tc = t - a.cI_t0;                     // row of the conditioning slab
+
+        // Phases of a step (ONE loop body, so the back half of the previous stage is inlined once):
+        //   role A: 0 = P1 rnn1 gates on xi (:208-210)      1 = P2 gh1(t+1) = W_hh1 . h1       2 = P3 fc1 + relu on x2 = (xi + h1) + h2 (:216-218)
+        //   role B: 0 = P2 rnn2 gates on x1 = xi + h1 (:212-214)   1 = P3 gh2(t+1) = W_hh2 . h2   2 = P4 fc2 + relu on y1 (:220-221)
+        //   both:   3 = P5 fc3 on y2 (:223); its back half samples x_t (:225-237)
+#pragma unroll 1
+        for (int ph = 0; ph < (roleA ? 4 : 3); ++ph) {
+#pragma unroll 1
+            for (int i = 0; i < nact; ++i) {
+                float *GP = smem + i * LGRP;
+                const int g = cl + ncl * i;
+                const int nb = GEO[2 * i + 1];
+                const float *cIg = a.cIf + ((size_t)tc * NGR + g) * XT;
+                float4 c[8];
+                u32x4 x[8];
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f;           // conditioning / noise values the back half needs
+                cur_ph = ph;
+                if (PROF && tid == 0 && plast == 0) plast = __builtin_amdgcn_s_memtime();
+                int xl = 0;                                    // layer polled in this stage
+                // ---------------- front, part 1: issue this stage's loads ------------------------------------------------
+                if constexpr (roleA) {
+                    if (ph == 0) { v0 = bi_r; v1 = bi_z; v2 = bi_n; load_cI(cIg, w, lane, c); }
+                    else if (ph == 1) { xl = 0; issue(xrs, XLAYER(i, 0, ring) * 4, w, lane, x); }                  // h1
+                    else if (ph == 2) {
+                        const int fr = reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj];               // frame of (segment pj, step t)
+                        v0 = a.c3f[(size_t)fr * H + prow];
+                        xl = 6; issue(xrs, XLAYER(i, 6, ring) * 4, w, lane, x);                                    // x2 = (xi + h1) + h2
+                    } else {
+                        if constexpr (MOL) {
+                            // this step's sampling noise, pre-transformed (wrnn_noise_mol_kernel): thread (segment tid >> 4, mixture tid & 15)
+                            const int b0 = GEO[2 * i];
+                            const int su = tid >> 4, sm = tid & 15;
+                            const float *nrow = a.noise_pre + (size_t)(t - a.noise_t0) * 11 * Nall;
+                            const int suc = su < nb ? su : nb - 1;
+                            v0 = nrow[(size_t)(b0 + suc) * 10 + (sm < 10 ? sm : 9)];
+                            v1 = nrow[(size_t)10 * Nall + b0 + suc];
+                        }
+                        xl = 3; issue(xrs, XLAYER(i, 3, ring) * 4, w, lane, x);                                    // y2
+                    }
+                } else {
+                    const int fr = reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj];
+                    if (ph == 0) {
+                        v0 = a.c2f[(size_t)fr * 3 * H + prow];                       // aux columns of rnn2 + b_ih2: per-frame table
+                        v1 = a.c2f[(size_t)fr * 3 * H + H + prow];
+                        v2 = a.c2f[(size_t)fr * 3 * H + 2 * H + prow];
+                        xl = 5; issue(xrs, XLAYER(i, 5, ring) * 4, w, lane, x);                                    // x1 = xi + h1
+                    } else if (ph == 1) { xl = 1; issue(xrs, XLAYER(i, 1, ring) * 4, w, lane, x); }                // h2
+                    else { v0 = a.c4f[(size_t)fr * H + prow]; xl = 2; issue(xrs, XLAYER(i, 2, ring) * 4, w, lane, x); }   // y1
+                }
+                PH(8 * ph + 0);
+                // ---------------- the previous stage's back half runs while they fly ---------------------------------------
+                if (!run_back(std::integral_constant<bool, MOL>{})) goto bail;
+                // ---------------- front, part 2: operands -> MFMA tiles -> this wave's partial tiles -----------------------
+                float b[32];
+                const bool polled = !(roleA && ph == 0);
+                if (polled) {
+                    unsigned spins = 0;
+                    ok = ok && finish(xrs, XLAYER(i, xl, ring) * 4, w, lane, nb, x, b, a.status, spins);
+                    if (!ok && fcode == 0u) fcode = 0x400u | (roleA ? 0u : 8u) | (unsigned)ph;
+                    if (PROF && tid == 0) { PROFL[8 * ph + 6] += 1; PROFL[8 * ph + 7] += spins != 0u; }
+                }
+                PH(8 * ph + 3);
+                if (ph == (roleA ? 3 : 2) && i == nact - 1) {
+                    // ---- ring hygiene, once per step, at the point where it is free: the last layer this role polls in the step (A: y2,
+                    //      B: y1) has just arrived, and it depends on every store this wave issued before polling for it.
+                    //      (1) Drain: every store of this wave so far -- in particular the re-arm it issued one step ago for the
+                    //      slot of step t+2 -- is acknowledged before anything of step t+1 is published (a consumer polls a word
+                    //      for step t+2 only after consuming data that depends on this wave's step-(t+1) publications).  The
+                    //      publishes themselves then need no drain and never stall on a stage's prefetched loads.
+                    //      (2) Re-arm this wave's own words of slot (t+3) % 4: it holds step t-1, which every consumer is done
+                    //      with (no workgroup publishes y2 of step t before it has finished step t-1).
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const int ringn = (t + 3) % XRING;
+#pragma unroll 1
+                    for (int i2 = 0; i2 < nact; ++i2)
+                        rearm(xrs, (XLAYER(i2, 0, ringn) + 256 * J + 64 * w) * 4, lane, roleA ? 0 : 1, roleA ? 2 : 3, roleA ? 5 : 6,
+                              (!MOL && roleA) ? 4 : -1);
+                }
+                if (roleA && ph == 0) make_xi(c, WI0, GP[O_XS + fi], w, lane, b);       // xi(t) (:208-209)
+                if (ph == 0 && w == (J >> 3)) {
+                    // the owned units' slice of this GRU's input (role A: xi, role B: x1) -> LDS in publish order, for the residual
+                    // sum the gates' back half publishes: unit block J = k-block r = J & 7 of wave J >> 3
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        if (r == (J & 7)) *reinterpret_cast<float4 *>(GP + O_XO + 4 * lane) = make_float4(b[4 * r], b[4 * r + 1], b[4 * r + 2], b[4 * r + 3]);
+                }
+                PH(8 * ph + 4);
+                float *PW = PARTOF(pp);
+                if (ph == 0 || (ph == 1)) {                                          // three gate tiles of W_ih (ph 0) / W_hh (ph 1)
+                    f32x4 o0, o1, o2;
+                    if (ph == 0) mfma3(A_ih[0], A_ih[1], A_ih[2], b, o0, o1, o2);
+                    else mfma3(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
+                    put_partial<3>(PW, w, 0, lane, o0);
+                    put_partial<3>(PW, w, 1, lane, o1);
+                    put_partial<3>(PW, w, 2, lane, o2);
+                    bk = ph == 0 ? BK_GATES : BK_GH;
+                } else if (ph == 2) {
+                    put_partial<3>(PW, w, 0, lane, mfma1(A_fc, b));
+                    bk = BK_RELU;
+                } else {
+                    put_partial<3>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
+                    if constexpr (MOL) put_partial<3>(PW, w, 1, lane, mfma1_lds(F3 + XT + frag_off(w, 0, lane), b));
+                    bk = BK_SAMPLE;
+                    if (t + 1 < T1) {   // pull the next step's conditioning block of this group (32 KB) into this XCD's L2
+                        asm volatile("" ::"v"(touch));
+                        touch = a.cIf[((size_t)(tc + 1) * NGR + g) * XT + 32 * tid];
+                    }
+                }
+                PH(8 * ph + 5);
+                bi = i; bpp = pp; bt = t; bc0 = v0; bc1 = v1; bc2 = v2;
+                pp ^= 1;
+                if constexpr (!MOL) {
+                    if (bk == BK_SAMPLE) { if (!run_back(std::true_type{})) goto bail; }   // RAW: the (heavy) sampling half is not deferred
+                }
             }
         }
     }
+    if (!run_back(std::integral_constant<bool, MOL>{})) goto bail;      // the last stage's back half
     asm volatile("" ::"v"(touch));
     // ---- save the per-group state for the next slab of steps ------------------------------------------------------
     __syncthreads();
@@ -611,17 +603,19 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
         float4 *dst = reinterpret_cast<float4 *>(a.state + state_wg + (size_t)i * LGRP);
         for (int q = tid; q < LGRP / 4; q += NT) dst[q] = GP[q];
     }
+    if (PROF && tid == 0 && a.prof && blockIdx.x < MAXWG) {
+        for (int k = 0; k < 32; ++k) a.prof[(size_t)blockIdx.x * 32 + k] += PROFL[k];
+    }
     return;
 bail:   // a bounded spin expired (or another workgroup raised the abort flag): record the first failure, leave
     if (fcode != 0u) report_failure(a.status, fcode, blockIdx.x, t, tid);
+#undef PH
 #undef XLAYER
-#undef STAGE_BARRIER
-#undef PARTP
-#undef GROUP_NB
+#undef PARTOF
 }
 
 // Grid = clusters x 64 workgroups of 256 threads, cooperative launch.  Workgroup wg of a cluster: role A if wg is even.
-template <int MODE>
+template <int MODE, bool PROF>
 __global__ __launch_bounds__(NT, 1) void wrnn_loop_kernel(const LoopArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -639,8 +633,8 @@ __global__ __launch_bounds__(NT, 1) void wrnn_loop_kernel(const LoopArgs a)
             wg = b % LNWGC;
         }
     }
-    if ((wg & 1) == 0) loop_role<MODE, true>(a, smem, cl, wg, ncl);
-    else loop_role<MODE, false>(a, smem, cl, wg, ncl);
+    if ((wg & 1) == 0) loop_role<MODE, true, PROF>(a, smem, cl, wg, ncl);
+    else loop_role<MODE, false, PROF>(a, smem, cl, wg, ncl);
 }
 
 size_t loop_lds_bytes(int mode, int G) { return (size_t)loop_lds(mode, G).total * sizeof(float); }
@@ -668,7 +662,8 @@ hipError_t launch_loop(const LoopArgs &args, int ncl, int mode, hipStream_t stre
 {
     if (ncl < 1 || args.G < 1 || args.G > loop_max_depth(mode)) return hipErrorInvalidValue;
     const size_t lds = loop_lds_bytes(mode, args.G);
-    const void *fn = mode == 1 ? (const void *)wrnn_loop_kernel<1> : (const void *)wrnn_loop_kernel<0>;
+    const void *fn = mode == 1 ? (args.prof ? (const void *)wrnn_loop_kernel<1, true> : (const void *)wrnn_loop_kernel<1, false>)
+                               : (const void *)wrnn_loop_kernel<0, false>;      // phase clocks: MOL only
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     LoopArgs a = args;

@@ -107,7 +107,8 @@ class LoopEngine:
         return int(self.lib.wrnn_workspace_bytes_segments(self._pack, n_segments, T, n_frames, ctypes.byref(o)))
 
     def run_segments(self, mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='auto', force_x=None, want_logits=False,
-                     check=True, depth=0, clusters=0, slab_steps=0, cond_valu=False, t_range=None, out=None, logits=None):
+                     check=True, depth=0, clusters=0, slab_steps=0, cond_valu=False, t_range=None, out=None, logits=None,
+                     phase_clocks=None):
         """mels_up (L,feat) / aux (n_frames,4*aux_dims) / noise: float32 CUDA tensors; seg_pos / seg_lim: host
         int32 arrays (B,) -- segment b, step t reads position seg_pos[b]+t, zero conditioning from seg_lim[b] on
         (several utterances: concatenated conditioning).  Returns out (B,T) CUDA [and logits (T,B,C)].
@@ -151,6 +152,8 @@ class LoopEngine:
             if logits is None:
                 logits = torch.empty(T, B, self.n_classes, dtype=torch.float32, device=self.device)
             o.logits = logits.data_ptr()
+        if phase_clocks is not None:      # profiling hook: int64 CUDA tensor [256, 32], zeroed by the caller
+            o.phase_clocks = phase_clocks.data_ptr()
         o.timer = self._timer
         o.info = ctypes.pointer(self._info)
         stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -197,6 +197,12 @@ class WaveRNN(nn.Module):
             self._pre_key = key
         return self._pre
 
+    @staticmethod
+    def _require_hip_device(device):
+        if device.type != 'cuda':
+            raise RuntimeError('wavernn_amd.WaveRNN.generate needs the model on a HIP device (model.to("cuda")); '
+                               'there is no CPU path in this package')
+
     def conditioning(self, mels):
         """Pre-loop stage (reference :183-186) without the Stretch2d repeat of aux and without the fold:
         returns mels_up (L, feat), aux frames (N, res_out), wave_len."""
@@ -214,9 +220,7 @@ class WaveRNN(nn.Module):
     def generate(self, mels, save_path: Union[str, Path], batched, target, overlap, mu_law):
         self.eval()
         device = next(self.parameters()).device
-        if device.type != 'cuda':
-            raise RuntimeError('wavernn_amd.WaveRNN.generate needs the model on a HIP device (model.to("cuda")); '
-                               'there is no CPU path in this package')
+        self._require_hip_device(device)
         if self.mode not in ('RAW', 'MOL'):
             raise RuntimeError("Unknown model mode value - ", self.mode)
         mu_law = mu_law if self.mode == 'RAW' else False
