@@ -122,7 +122,8 @@ typedef struct wrnn_options {
     int32_t t_begin, t_end;  /* run steps [t_begin, t_end) of the T; 0,0 = all.  t_begin > 0 CONTINUES the call that ended at
                                 t_begin on the same workspace (loop kernel only); `noise` then covers [t_begin, t_end) only,
                                 `out` / force_x / logits always the whole [.., T] tensors */
-    int32_t reserved;
+    int32_t tuning;          /* loop kernel A/B switches for measurements: bit 0 = no one-stage look-ahead of the exchange loads,
+                                bit 1 = full __syncthreads() fences at the stage barriers (default 0 = the fast forms) */
     const float *force_x;    /* test hook, device [n,T]: value fed back as x_t instead of the sample (teacher forcing) */
     float *logits;           /* test hook, device [T,n,C]: fc3 output of every step (:223) */
     unsigned long long *phase_clocks; /* profiling hook, device [256 workgroups][32] zeroed by the caller: the loop kernel (MOL) adds

@@ -33,6 +33,7 @@ rs = np.random.RandomState(3)
 VARS = {'auto': dict(algo='auto'), 'stream': dict(algo='stream'), 'g1': dict(algo='loop', depth=1), 'g2': dict(algo='loop', depth=2),
         'g3': dict(algo='loop', depth=3), 'g4': dict(algo='loop', depth=4), 'g6': dict(algo='loop', depth=6), 'g8': dict(algo='loop', depth=8),
         'c1g1': dict(algo='loop', clusters=1, depth=1), 'c2g1': dict(algo='loop', clusters=2, depth=1), 'c1g2': dict(algo='loop', clusters=1, depth=2),
+        'nola': dict(algo='loop', tuning=1), 'fence': dict(algo='loop', tuning=2), 'nola-fence': dict(algo='loop', tuning=3),
         's1': dict(algo='sparse', depth=1), 's2': dict(algo='sparse', depth=2)}
 rows = []
 for B in [int(x) for x in args.B.split(',')]:

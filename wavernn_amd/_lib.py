@@ -50,7 +50,7 @@ class RunInfo(ctypes.Structure):
 class Options(ctypes.Structure):
     """wrnn_options (include/wavernn_amd.h): per-call options; nothing is read from the environment."""
     _fields_ = [(n, ctypes.c_int32) for n in ('struct_bytes', 'algo', 'depth', 'clusters', 'cond_valu', 'slab_steps', 't_begin',
-                                              't_end', 'reserved')] + \
+                                              't_end', 'tuning')] + \
                [('force_x', ctypes.c_void_p), ('logits', ctypes.c_void_p), ('phase_clocks', ctypes.c_void_p), ('timer', ctypes.c_void_p),
                 ('info', ctypes.POINTER(RunInfo))]
 

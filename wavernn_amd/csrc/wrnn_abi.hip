@@ -511,6 +511,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     a.noise = noise; a.force_x = o->force_x; a.out = out; a.dbg_logits = o->logits;
     a.status = (unsigned *)(ws + l.status);
     a.prof = (u64 *)o->phase_clocks;
+    a.tuning = o->tuning;
     a.seg_pos = d_pos; a.seg_lim = d_lim;
     a.Btot = B; a.T = T; a.hop = hop; a.NF = n_frames; a.C = p->C;
     a.NG = (B + SEG - 1) / SEG;

@@ -75,6 +75,7 @@ struct LoopArgs {
     float *state;                       // [clusters*64][G][LGRP] per-group state carried between launches of one round
     const float *cIf;                   // [t1 - cI_t0 ...][NG][SEG*H] hoisted conditioning of the round in fragment order (slab)
     int t0, t1, cI_t0, noise_t0;        // noise / noise_pre row 0 is step noise_t0, cIf row 0 is step cI_t0
+    int tuning;                         // A/B switches of the loop kernel (wrnn_options.tuning)
     int rb0, Nall, G, resume;           // resume != 0: restore the per-group state instead of the zero initial state
 };
 

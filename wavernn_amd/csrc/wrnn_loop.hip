@@ -81,6 +81,24 @@ __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, int soff, int w
 #pragma unroll
     for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + r * 1024, soff, 16 /* sc1 */);
 }
+// non-blocking form: true (and b filled) if the fragments already in x carry no sentinel
+__device__ __forceinline__ bool try_finish(int lane, int nb, const u32x4 (&x)[8], float (&b)[32])
+{
+    const bool live = (lane & 15) < nb;
+    unsigned m = 0u;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) m = max(max(m, max(x[r].x, x[r].y)), max(x[r].z, x[r].w));
+    if (!__all(m != SENT || !live)) return false;
+    const unsigned keep = (nb >= SEG || live) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        b[4 * r + 0] = __uint_as_float(x[r].x & keep);
+        b[4 * r + 1] = __uint_as_float(x[r].y & keep);
+        b[4 * r + 2] = __uint_as_float(x[r].z & keep);
+        b[4 * r + 3] = __uint_as_float(x[r].w & keep);
+    }
+    return true;
+}
 __device__ __forceinline__ bool finish(__amdgpu_buffer_rsrc_t rs, int soff, int w, int lane, int nb, u32x4 (&x)[8], float (&b)[32],
                                        unsigned *status, unsigned &spins)
 {
@@ -88,10 +106,12 @@ __device__ __forceinline__ bool finish(__amdgpu_buffer_rsrc_t rs, int soff, int 
     const bool live = (lane & 15) < nb;
     spins = 0;
     for (;;) {
-        bool ok = true;
+        // the sentinel is the largest unsigned value: ONE compare of the running maximum of the 32 words (a chain of v_max3_u32
+        // in the vector unit) instead of 32 compare / scalar-and pairs, which serialise on the VALU -> SALU hand-off
+        unsigned m = 0u;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) ok &= (x[r].x != SENT) & (x[r].y != SENT) & (x[r].z != SENT) & (x[r].w != SENT);
-        if (__all(ok || !live)) break;
+        for (int r = 0; r < 8; ++r) m = max(max(m, max(x[r].x, x[r].y)), max(x[r].z, x[r].w));
+        if (__all(m != SENT || !live)) break;
         ++spins;
         if ((spins & 255u) == 0u) {
             if (spins > SPIN_LIMIT || ld_agent32(status) != 0u) return false;
@@ -100,12 +120,13 @@ __device__ __forceinline__ bool finish(__amdgpu_buffer_rsrc_t rs, int soff, int 
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + r * 1024, soff, 16 /* sc1 */);
     }
+    const unsigned keep = (nb >= SEG || live) ? 0xFFFFFFFFu : 0u;       // ragged last group only: lanes of absent segments read as zero
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        b[4 * r + 0] = live ? __uint_as_float(x[r].x) : 0.f;
-        b[4 * r + 1] = live ? __uint_as_float(x[r].y) : 0.f;
-        b[4 * r + 2] = live ? __uint_as_float(x[r].z) : 0.f;
-        b[4 * r + 3] = live ? __uint_as_float(x[r].w) : 0.f;
+        b[4 * r + 0] = __uint_as_float(x[r].x & keep);
+        b[4 * r + 1] = __uint_as_float(x[r].y & keep);
+        b[4 * r + 2] = __uint_as_float(x[r].z & keep);
+        b[4 * r + 3] = __uint_as_float(x[r].w & keep);
     }
     return true;
 }
@@ -335,6 +356,12 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     //      SIMD cannot hide a load behind another wave; this hides every stage's loads behind the previous stage's barrier +
     //      pointwise half instead.  The pending back half is described by (bk, bi, bpp, bt, bc*).
     enum { BK_NONE = 0, BK_GATES, BK_GH, BK_RELU, BK_SAMPLE };
+    // the exchanged layer a stage polls, by phase (role A phase 0 polls nothing: xi comes from the conditioning slab)
+    auto stage_layer = [](int ph) -> int { return roleA ? (ph == 1 ? 0 : (ph == 2 ? 6 : 3)) : (ph == 0 ? 5 : (ph == 1 ? 1 : 2)); };
+    constexpr int NPH = roleA ? 4 : 3;
+    u32x4 x[8];                                          // fragments of the polled layer; issued ONE STAGE AHEAD (before the previous
+    bool xahead = false;                                 // stage's MFMA tiles) whenever that stage is in the same step
+    const bool lookahead = (a.tuning & 1) == 0, full_fence = (a.tuning & 2) != 0;      // A/B switches (wrnn_options.tuning)
     int bk = BK_NONE, bi = 0, bpp = 0, bt = 0, cur_ph = 0;
     float bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
 
@@ -346,7 +373,11 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
         const int nb = GEO[2 * bi + 1];
         const int bring = bt % XRING;
         if (!ok) FAIL[0] = 1;
-        __syncthreads();                                   // every wave's partial tiles of the stage are in LDS
+        // every wave's partial tiles of the stage are in LDS.  Only LDS is handed over here, so the barrier waits for LDS
+        // traffic alone (lgkmcnt): __syncthreads() would also drain vmcnt -- i.e. wait for the very loads this stage has just
+        // put in flight -- through its workgroup-scope fences.
+        if (full_fence) __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (FAIL[0] != 0) return false;
         PH(8 * cur_ph + 1);
         if (bk == BK_GATES) {                              // GRU cell pointwise (ATen gru_cell) -> publish h1 (role A) / h2 (role B)
@@ -491,20 +522,28 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                 const int nb = GEO[2 * i + 1];
                 const float *cIg = a.cIf + ((size_t)tc * NGR + g) * XT;
                 float4 c[8];
-                u32x4 x[8];
                 float v0 = 0.f, v1 = 0.f, v2 = 0.f;           // conditioning / noise values the back half needs
                 cur_ph = ph;
                 if (PROF && tid == 0 && plast == 0) plast = __builtin_amdgcn_s_memtime();
-                int xl = 0;                                    // layer polled in this stage
-                // ---------------- front, part 1: issue this stage's loads ------------------------------------------------
+                // ---------------- front, part 1 --------------------------------------------------------------------------------
+                // The polled layer: normally its loads were issued ONE STAGE AGO (before the previous stage's MFMA tiles), so they
+                // have landed.  They are consumed FIRST, before anything else touches vector memory: vmcnt retires in order, so a
+                // wait for these loads placed after the back half's publish stores would also wait ~1 us for the stores'
+                // write-through acknowledgements (measured: profiles/r02h_*).  If a word is still the sentinel, the poll comes
+                // after the back half -- it may be waiting for this workgroup's own pending publication.
+                const bool polled = !(roleA && ph == 0);
+                const int xl = stage_layer(ph);
+                float b[32];
+                bool ready = false;
+                if (polled) {
+                    if (xahead) ready = try_finish(lane, nb, x, b);
+                    else issue(xrs, XLAYER(i, xl, ring) * 4, w, lane, x);
+                }
+                // conditioning / noise values of the back half, the conditioning slab (role A, phase 0)
                 if constexpr (roleA) {
                     if (ph == 0) { v0 = bi_r; v1 = bi_z; v2 = bi_n; load_cI(cIg, w, lane, c); }
-                    else if (ph == 1) { xl = 0; issue(xrs, XLAYER(i, 0, ring) * 4, w, lane, x); }                  // h1
-                    else if (ph == 2) {
-                        const int fr = reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj];               // frame of (segment pj, step t)
-                        v0 = a.c3f[(size_t)fr * H + prow];
-                        xl = 6; issue(xrs, XLAYER(i, 6, ring) * 4, w, lane, x);                                    // x2 = (xi + h1) + h2
-                    } else {
+                    else if (ph == 2) v0 = a.c3f[(size_t)reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj] * H + prow];
+                    else if (ph == 3) {
                         if constexpr (MOL) {
                             // this step's sampling noise, pre-transformed (wrnn_noise_mol_kernel): thread (segment tid >> 4, mixture tid & 15)
                             const int b0 = GEO[2 * i];
@@ -514,29 +553,26 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                             v0 = nrow[(size_t)(b0 + suc) * 10 + (sm < 10 ? sm : 9)];
                             v1 = nrow[(size_t)10 * Nall + b0 + suc];
                         }
-                        xl = 3; issue(xrs, XLAYER(i, 3, ring) * 4, w, lane, x);                                    // y2
                     }
                 } else {
-                    const int fr = reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj];
+                    const int fr = reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj];   // conditioning frame of (segment pj, step t)
                     if (ph == 0) {
                         v0 = a.c2f[(size_t)fr * 3 * H + prow];                       // aux columns of rnn2 + b_ih2: per-frame table
                         v1 = a.c2f[(size_t)fr * 3 * H + H + prow];
                         v2 = a.c2f[(size_t)fr * 3 * H + 2 * H + prow];
-                        xl = 5; issue(xrs, XLAYER(i, 5, ring) * 4, w, lane, x);                                    // x1 = xi + h1
-                    } else if (ph == 1) { xl = 1; issue(xrs, XLAYER(i, 1, ring) * 4, w, lane, x); }                // h2
-                    else { v0 = a.c4f[(size_t)fr * H + prow]; xl = 2; issue(xrs, XLAYER(i, 2, ring) * 4, w, lane, x); }   // y1
+                    } else if (ph == 2) v0 = a.c4f[(size_t)fr * H + prow];
                 }
                 PH(8 * ph + 0);
-                // ---------------- the previous stage's back half runs while they fly ---------------------------------------
+                // ---------------- the previous stage's back half -------------------------------------------------------------
                 if (!run_back(std::integral_constant<bool, MOL>{})) goto bail;
                 // ---------------- front, part 2: operands -> MFMA tiles -> this wave's partial tiles -----------------------
-                float b[32];
-                const bool polled = !(roleA && ph == 0);
                 if (polled) {
                     unsigned spins = 0;
-                    ok = ok && finish(xrs, XLAYER(i, xl, ring) * 4, w, lane, nb, x, b, a.status, spins);
-                    if (!ok && fcode == 0u) fcode = 0x400u | (roleA ? 0u : 8u) | (unsigned)ph;
-                    if (PROF && tid == 0) { PROFL[8 * ph + 6] += 1; PROFL[8 * ph + 7] += spins != 0u; }
+                    if (!ready) {
+                        ok = ok && finish(xrs, XLAYER(i, xl, ring) * 4, w, lane, nb, x, b, a.status, spins);
+                        if (!ok && fcode == 0u) fcode = 0x400u | (roleA ? 0u : 8u) | (unsigned)ph;
+                    }
+                    if (PROF && tid == 0) { PROFL[8 * ph + 6] += 1; PROFL[8 * ph + 7] += !ready; }
                 }
                 PH(8 * ph + 3);
                 if (ph == (roleA ? 3 : 2) && i == nact - 1) {
@@ -554,6 +590,14 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                     for (int i2 = 0; i2 < nact; ++i2)
                         rearm(xrs, (XLAYER(i2, 0, ringn) + 256 * J + 64 * w) * 4, lane, roleA ? 0 : 1, roleA ? 2 : 3, roleA ? 5 : 6,
                               (!MOL && roleA) ? 4 : -1);
+                }
+                {   // the NEXT stage's polled layer, one stage ahead: its 8 loads fly during this stage's MFMA tiles and the back half
+                    // that follows (a publication is normally several stages old by the time it is polled; if it is not there yet,
+                    // finish() polls as before).  Not across a step boundary (nothing of the next step is published yet).
+                    int nph = ph, ni = i + 1;
+                    if (ni >= nact) { nph = ph + 1; ni = 0; }
+                    xahead = lookahead && nph < NPH && !(roleA && nph == 0) && (MOL || nph != 3);
+                    if (xahead) issue(xrs, XLAYER(ni, stage_layer(nph), ring) * 4, w, lane, x);
                 }
                 if (roleA && ph == 0) make_xi(c, WI0, GP[O_XS + fi], w, lane, b);       // xi(t) (:208-209)
                 if (ph == 0 && w == (J >> 3)) {

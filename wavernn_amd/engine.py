@@ -87,10 +87,11 @@ class LoopEngine:
         seg_lim = np.full(B, L, dtype=np.int32)
         return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, **kw)
 
-    def options(self, algo='auto', depth=0, clusters=0, slab_steps=0, cond_valu=False, t_range=None):
+    def options(self, algo='auto', depth=0, clusters=0, slab_steps=0, cond_valu=False, t_range=None, tuning=0):
         o = _lib.Options()
         o.algo = _lib.ALGOS[algo]
         o.depth, o.clusters, o.slab_steps, o.cond_valu = int(depth), int(clusters), int(slab_steps), int(bool(cond_valu))
+        o.tuning = int(tuning)
         if t_range is not None:
             o.t_begin, o.t_end = int(t_range[0]), int(t_range[1])
         return o
@@ -108,7 +109,7 @@ class LoopEngine:
 
     def run_segments(self, mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='auto', force_x=None, want_logits=False,
                      check=True, depth=0, clusters=0, slab_steps=0, cond_valu=False, t_range=None, out=None, logits=None,
-                     phase_clocks=None):
+                     phase_clocks=None, tuning=0):
         """mels_up (L,feat) / aux (n_frames,4*aux_dims) / noise: float32 CUDA tensors; seg_pos / seg_lim: host
         int32 arrays (B,) -- segment b, step t reads position seg_pos[b]+t, zero conditioning from seg_lim[b] on
         (several utterances: concatenated conditioning).  Returns out (B,T) CUDA [and logits (T,B,C)].
@@ -133,7 +134,7 @@ class LoopEngine:
         if noise.numel() != need:
             raise ValueError(f'noise has {noise.numel()} elements, expected {need}')
         n_frames = int(aux.shape[0])
-        o = self.options(algo, depth, clusters, slab_steps, cond_valu, t_range)
+        o = self.options(algo, depth, clusters, slab_steps, cond_valu, t_range, tuning)
         nbytes = int(self.lib.wrnn_workspace_bytes_segments(self._pack, B, T, n_frames, ctypes.byref(o)))
         if nbytes == 0:
             raise _lib.WrnnError('bad geometry / options: ' + self.lib.wrnn_last_error().decode())
