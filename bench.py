@@ -4,10 +4,11 @@
 A "step" is ONE full pass of the hot path over one batch of synthetic input.  Workload (BASELINE config 2 -- MoL
 WaveRNN, ljspeech.wavernn.mol hparams, random-init weights, batched generation target=11000 overlap=550 -- as
 one GPU's share of a serving batch / of config 4's corpus): `--utterances` random mels of `--frames` frames per
-GPU (default 8 x 641 frames = 8 x 8 s of audio -> 8 x 16 = 128 folded segments x T=12100 autoregressive steps).
-Timed region (mels already resident in HBM): up-sample network (PyTorch-ROCm) -> hoisted conditioning ->
-the persistent loop kernel (ONE launch for all segments) -> [N>1: RCCL all-gather of the [n,T] audio] -> D2H ->
-cross-fade/unfold on the host.  The WAV write is excluded (the CPU baseline excludes it too).  Sampling noise is
+GPU (default 16 x 641 frames = 16 x 8 s of audio -> 16 x 16 = 256 folded segments x T=12100 autoregressive steps; the
+same line also carries the 8-utterance batch of round 1 and BASELINE config 2's single-utterance calls, N = 481 / 1001).
+Timed region (mels already resident in HBM): up-sample network (HIP pre-loop kernels) -> per conditioning slab {hoisted
+conditioning -> the persistent loop kernel} -> [N>1: RCCL all-gather of the [n,T] audio] -> cross-fade/unfold on the
+device -> D2H of the float64 waveforms.  The WAV write is excluded (the CPU baseline excludes it too).  Sampling noise is
 drawn on the device (Philox), as the reference does when it runs on a GPU; `--parity-noise` uses the host
 MT19937 stream of the parity tests instead (adds ~25 M host RNG draws per pass).
 
@@ -84,7 +85,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--utterances', type=int, default=8, help='utterances per GPU')
+    ap.add_argument('--utterances', type=int, default=16, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=641, help='mel frames per utterance')
     ap.add_argument('--algo', default='auto', choices=['auto', 'loop', 'sparse', 'stream'])
     ap.add_argument('--mode', default='MOL', choices=['MOL', 'RAW'], help="RAW = 9-bit mu-law ('bits') softmax sampling")
@@ -264,6 +265,29 @@ def main():
                 res['config']['single_utterance'] = [single_utterance(481), single_utterance(1001)]
             except Exception as e:
                 res['config']['single_utterance'] = {'error': repr(e)}
+            if args.utterances > 8:
+                try:    # round 1's workload (8 utterances = 128 segments per GPU), for continuity
+                    sub = mels[:8]
+
+                    def small_pass():
+                        generate_corpus(model, sub, target, overlap, True, seeds[:8], noise_source=noise_source, finish='own', check=False)
+                        eng.status()
+                    small_pass()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(2):
+                        small_pass()
+                    torch.cuda.synchronize()
+                    d8 = (time.perf_counter() - t0) / 2
+                    w8 = 8 * (args.frames - 1) * hop
+                    k8 = eng.last_loop_ms()
+                    i8 = eng.last_run_info()
+                    res['config']['batch_of_8_utterances'] = {
+                        'segments': 8 * (plan.n_segments // n_utt), 'samples_per_s': round(w8 / d8, 1), 'realtime_factor': round(w8 / d8 / SAMPLE_RATE, 2),
+                        'ms_per_pass': round(d8 * 1e3, 3), 'loop_kernel_ms': round(k8, 3), 'split': i8,
+                        'mfma_frac': round(2.0 * nnz * 8 * (plan.n_segments // n_utt) * T / (k8 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 5)}
+                except Exception as e:
+                    res['config']['batch_of_8_utterances'] = {'error': repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 res['cpu_baseline'] = cpu_baseline(sd, mode, args.frames, target, overlap, args.cpu_seconds)

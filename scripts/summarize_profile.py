@@ -57,26 +57,33 @@ if os.path.exists(bench):
         if ln.startswith('{'):
             bj = json.loads(ln)
             lines += ['## bench line', '', '```json', json.dumps(bj, indent=1), '```', '']
-# fabric-side traffic of the loop kernel per launch -> profiles/traffic_latest.json (read back by bench.py's roofline.traffic)
+# fabric-side traffic of the loop kernel per PASS (= mean per dispatch x launches per pass) -> profiles/traffic_latest.json, read
+# back by bench.py's roofline.traffic only when kernel, geometry, mode AND the source hash all match the run it is asked about
 if bj is not None:
+    sys.path.insert(0, ROOT)
+    import bench as _bench
     kname = bj['config'].get('kernel', '')
+    launches = int(bj['config'].get('launches_per_pass', 1))
     for k, cs in pmc.items():
         if kname and kname in k and 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs and 'segments_per_gpu' in bj['config']:
-            # FETCH_SIZE / WRITE_SIZE are in KB; the granule polls are 16-B sc1 loads (not the calibrated 2x-under-counted
-            # wide streaming pattern), so the raw counters are reported uncorrected
-            tr = dict(tag=tag, kernel=kname, kernel_instance=k, segments=bj['config']['segments_per_gpu'],
-                      T=bj['config']['steps_per_segment'],
-                      bytes_per_launch=int((cs['FETCH_SIZE'][0] + cs['WRITE_SIZE'][0]) * 1024),
-                      fetch_bytes=int(cs['FETCH_SIZE'][0] * 1024), write_bytes=int(cs['WRITE_SIZE'][0] * 1024),
-                      note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per dispatch; fabric-side '
-                           '(L2 <-> Infinity Fabric) bytes = inter-CU granule exchange + conditioning; uncorrected')
+            # FETCH_SIZE / WRITE_SIZE are in KB.  The exchange loads are 16-B-per-lane sc1 buffer loads of 1 KB per wave-instruction,
+            # i.e. the wide coalesced pattern the guide calibrates as under-counted 2x on gfx950: both the raw and the doubled
+            # fetch figure are kept; bytes_per_pass uses the corrected one
+            fetch, write = cs['FETCH_SIZE'][0] * 1024 * launches, cs['WRITE_SIZE'][0] * 1024 * launches
+            tr = dict(tag=tag, kernel=kname, kernel_instance=k, mode=bj['config'].get('mode', 'MOL'), segments=bj['config']['segments_per_gpu'],
+                      T=bj['config']['steps_per_segment'], launches_per_pass=launches, source_sha16=_bench.source_sha16(),
+                      bytes_per_pass=int(2 * fetch + write), fetch_bytes_raw=int(fetch), fetch_bytes_corrected=int(2 * fetch), write_bytes=int(write),
+                      note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per dispatch x launches per pass; fabric-side '
+                           '(L2 <-> Infinity Fabric / MALL) bytes = the inter-CU activation exchange + conditioning slabs; FETCH_SIZE doubled per '
+                           'MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads)')
             json.dump(tr, open(os.path.join(dst, 'traffic_latest.json'), 'w'), indent=1)
 for k, cs in pmc.items():
     g = lambda c: cs.get(c, (None,))[0]
     lines += [f'## {k}', '', f'launch geometry / registers: {meta[k]}', '']
     if g('FETCH_SIZE') is not None and g('WRITE_SIZE') is not None:
-        lines.append(f'* fabric-side traffic per dispatch: FETCH_SIZE {g("FETCH_SIZE") / 1e6:.3f} GB (KB counter; gfx950 may '
-                     f'under-count wide reads 2x), WRITE_SIZE {g("WRITE_SIZE") / 1e6:.3f} GB')
+        nd = cs['FETCH_SIZE'][1]
+        lines.append(f'* fabric-side traffic per dispatch (mean of {nd}): FETCH_SIZE {g("FETCH_SIZE") * 1024 / 1e9:.3f} GB raw (x2 on gfx950 for wide '
+                     f'coalesced reads = {2 * g("FETCH_SIZE") * 1024 / 1e9:.3f} GB), WRITE_SIZE {g("WRITE_SIZE") * 1024 / 1e9:.3f} GB')
     if g('SQ_LDS_BANK_CONFLICT') is not None and g('SQ_LDS_IDX_ACTIVE'):
         lines.append(f'* LDS bank-conflict rate SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = '
                      f'{g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE"):.4f}')

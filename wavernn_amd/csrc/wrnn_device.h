@@ -26,7 +26,7 @@ constexpr int GRAN_WORDS = SPCL * SPG * NGRAN * SEG * H;     // u64 granules in 
 static_assert(SPCL * SPG >= MAXCL * MAXG, "granule workspace");
 // role-split loop kernel (wrnn_loop.hip): tag-free exchange buffer [cluster][slot][layer h1 h2 y1 y2 lg x1 x2][ring][SEG*H floats]
 constexpr int LMAXG = 8;      // slots (groups in flight) per cluster the exchange buffer is sized for
-constexpr int NXLAYER = 7;      // h1, h2, y1, y2, RAW logits, x1 = xi + h1, x2 = x1 + h2
+constexpr int NXLAYER = 8;      // h1, h2, y1, y2, RAW logits, x1 = xi + h1, x2 = x1 + h2, x_t (16 words: samples drawn by role B)
 constexpr int XRING = 4;
 constexpr size_t XBUF_FLOATS = (size_t)MAXCL * LMAXG * NXLAYER * XRING * SEG * H;
 constexpr int STATUS_WORDS = 16;

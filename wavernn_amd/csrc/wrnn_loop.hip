@@ -13,7 +13,9 @@
 //     10 two-thirds-full ones before; 224 weight registers, which fit the AGPR half of the register file -- 9 tiles did not
 //     and spilled the B operands).  fc3 lives in LDS in A-fragment order: MOL -- every workgroup holds all 30 rows (2 tiles)
 //     and samples redundantly, no 5th exchange; RAW -- role-A workgroup J owns logit rows [16 J, 16 J + 16) and the 512
-//     logits are a 5th exchange.  Only role A needs x_t (for xi), so only role A runs fc3 and samples.
+//     logits are a 5th exchange.  Only role A needs x_t (for xi): with one group in flight (and in RAW) role A alone runs
+//     fc3 + sampling; with >= 2 groups in flight (MOL) the sampling stages alternate between the roles by slot parity, role
+//     B handing its x_t to role A through a 16-word exchange layer, so both roles run 3.5 stages per group-step.
 //   * TAG-FREE exchange in MFMA-FRAGMENT ORDER.  A layer (h1, h2, y1, y2, RAW logits) of a group is 16 segments x 512 f32 =
 //     32 KB stored as [wave w][k-block r][lane][4]: exactly the B fragments wave w feeds its MFMAs, so a consumer wave
 //     loads its operands with 8 buffer_load_dwordx4 (sc1) straight into registers -- no LDS staging, no sweep barrier, half
@@ -273,7 +275,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     const int T0 = a.t0, T1 = a.t1, C = a.C;
     const int NR = a.Btot, Nall = a.Nall;               // segments of this round / of the whole call (row stride of noise, logits)
     const int NGR = a.NG;                               // groups of this round
-    const bool leader = wg == 0;
+    const bool leader = wg == (roleA ? 0 : 1);           // the workgroup of this role that writes out / publishes x_t
 
     // ---- one-time: weight slice -> register-resident MFMA A fragments (7 tiles = 224 registers) ------------------------
     float A_ih[3][AF], A_hh[3][AF], A_fc[AF];
@@ -297,7 +299,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     WI0[2 * tid] = a.I_w0[2 * tid];
     WI0[2 * tid + 1] = a.I_w0[2 * tid + 1];
     // fc3 -> LDS in A-fragment order: F3[tile s][wave][r][lane (row fi, k-quad kq)][4] = fc3_w[row(s, fi)][128 wave + 16 r + 4 kq ..]
-    for (int q = tid; q < (roleA ? (MOL ? 2 : 1) * (XT / 4) : 0); q += NT) {
+    for (int q = tid; q < ((roleA || MOL) ? (MOL ? 2 : 1) * (XT / 4) : 0); q += NT) {
         const int l6 = q & 63, r = (q >> 6) & 7, wv = (q >> 9) & 3, sidx = q >> 11;
         const int rfi = l6 & 15, rkq = l6 >> 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -357,8 +359,28 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     //      pointwise half instead.  The pending back half is described by (bk, bi, bpp, bt, bc*).
     enum { BK_NONE = 0, BK_GATES, BK_GH, BK_RELU, BK_SAMPLE };
     // the exchanged layer a stage polls, by phase (role A phase 0 polls nothing: xi comes from the conditioning slab)
-    auto stage_layer = [](int ph) -> int { return roleA ? (ph == 1 ? 0 : (ph == 2 ? 6 : 3)) : (ph == 0 ? 5 : (ph == 1 ? 1 : 2)); };
-    constexpr int NPH = roleA ? 4 : 3;
+    auto stage_layer = [](int ph) -> int { return roleA ? (ph == 1 ? 0 : (ph == 2 ? 6 : 3)) : (ph == 0 ? 5 : (ph == 1 ? 1 : (ph == 2 ? 2 : 3))); };
+    constexpr int NPH = (roleA || MOL) ? 4 : 3;
+    // Who runs fc3 + sampling (phase 3) for slot i.  Only role A needs x_t (for xi), so one group in flight (and RAW) is sampled by
+    // role A; with >= 2 groups in flight the MOL sampling stages ALTERNATE -- even slots role A, odd slots role B, which hands
+    // x_t to role A through a 16-word exchange layer -- so both roles run 3.5 stages per group-step instead of 4 and 3.
+    const bool alternate = MOL && nact >= 2;
+    auto samples = [&](int i) -> bool { return alternate ? (((i & 1) == 0) == roleA) : roleA; };
+    // last stage of a step this workgroup executes (the ring hygiene point)
+    const int last_ph = (alternate || roleA) ? 3 : 2;
+    const int last_i = !alternate ? nact - 1 : (roleA ? ((nact - 1) & ~1) : (((nact - 1) & 1) ? nact - 1 : nact - 2));
+    unsigned xtw = 0u;                                   // x_{t-1} word of segment fi, polled from role B (alternate sampling)
+    auto poll_xt = [&](int i, int ring, int nb, unsigned &v) -> bool {
+        unsigned spins = 0;
+        while (__any(fi < nb && v == SENT)) {
+            if ((++spins & 255u) == 0u) {
+                if (spins > SPIN_LIMIT || ld_agent32(a.status) != 0u) return false;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            v = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, XLAYER(i, 7, ring) * 4, 16 /* sc1 */);
+        }
+        return true;
+    };
     u32x4 x[8];                                          // fragments of the polled layer; issued ONE STAGE AHEAD (before the previous
     bool xahead = false;                                 // stage's MFMA tiles) whenever that stage is in the same step
     const bool lookahead = (a.tuning & 1) == 0, full_fence = (a.tuning & 2) != 0;      // A/B switches (wrnn_options.tuning)
@@ -428,6 +450,8 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                         if (leader) a.out[(size_t)(b0 + su) * a.T + bt] = x;
                         if (a.force_x) x = a.force_x[(size_t)(b0 + su) * a.T + bt];
                         XS[su] = x;
+                        if (!roleA && leader)                                       // role B sampled this slot: hand x_t to role A
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), xrs, su * 4, XLAYER(bi, 7, bring) * 4, 16 /* sc1 */);
                     }
                 }
             } else {
@@ -496,9 +520,10 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                 }
                 __syncthreads();                         // LGT is read by every wave before the next group overwrites it
             }
-            // x_t is read by EVERY wave in this group's first stage of the next step; with one group in flight that is the very
-            // next front half (with more, other stages' barriers lie in between)
-            if (nact == 1) __syncthreads();
+            // x_t is read by EVERY wave in this slot's first stage of the next step.  When this sampling half is the one that runs
+            // inside that very stage (role A's last sampling stage of a step is slot 0's: one group in flight, or two with
+            // alternating roles) the read follows at once; otherwise another stage's barrier lies in between.
+            if (roleA && last_i == 0) __syncthreads();
         }
         bk = BK_NONE;
         PH(8 * cur_ph + 2);
@@ -514,9 +539,10 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
         //   role B: 0 = P2 rnn2 gates on x1 = xi + h1 (:212-214)   1 = P3 gh2(t+1) = W_hh2 . h2   2 = P4 fc2 + relu on y1 (:220-221)
         //   both:   3 = P5 fc3 on y2 (:223); its back half samples x_t (:225-237)
 #pragma unroll 1
-        for (int ph = 0; ph < (roleA ? 4 : 3); ++ph) {
+        for (int ph = 0; ph < NPH; ++ph) {
 #pragma unroll 1
             for (int i = 0; i < nact; ++i) {
+                if (ph == 3 && !samples(i)) continue;           // the other role samples this slot
                 float *GP = smem + i * LGRP;
                 const int g = cl + ncl * i;
                 const int nb = GEO[2 * i + 1];
@@ -541,19 +567,13 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                 }
                 // conditioning / noise values of the back half, the conditioning slab (role A, phase 0)
                 if constexpr (roleA) {
-                    if (ph == 0) { v0 = bi_r; v1 = bi_z; v2 = bi_n; load_cI(cIg, w, lane, c); }
-                    else if (ph == 2) v0 = a.c3f[(size_t)reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj] * H + prow];
-                    else if (ph == 3) {
-                        if constexpr (MOL) {
-                            // this step's sampling noise, pre-transformed (wrnn_noise_mol_kernel): thread (segment tid >> 4, mixture tid & 15)
-                            const int b0 = GEO[2 * i];
-                            const int su = tid >> 4, sm = tid & 15;
-                            const float *nrow = a.noise_pre + (size_t)(t - a.noise_t0) * 11 * Nall;
-                            const int suc = su < nb ? su : nb - 1;
-                            v0 = nrow[(size_t)(b0 + suc) * 10 + (sm < 10 ? sm : 9)];
-                            v1 = nrow[(size_t)10 * Nall + b0 + suc];
-                        }
+                    if (ph == 0) {
+                        v0 = bi_r; v1 = bi_z; v2 = bi_n;
+                        load_cI(cIg, w, lane, c);
+                        if (alternate && (i & 1) && t > T0)      // x_{t-1} of a slot role B sampled (at the first step of a launch: from the state)
+                            xtw = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, XLAYER(i, 7, (t + 3) % XRING) * 4, 16 /* sc1 */);
                     }
+                    else if (ph == 2) v0 = a.c3f[(size_t)reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj] * H + prow];
                 } else {
                     const int fr = reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj];   // conditioning frame of (segment pj, step t)
                     if (ph == 0) {
@@ -561,6 +581,15 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                         v1 = a.c2f[(size_t)fr * 3 * H + H + prow];
                         v2 = a.c2f[(size_t)fr * 3 * H + 2 * H + prow];
                     } else if (ph == 2) v0 = a.c4f[(size_t)fr * H + prow];
+                }
+                if (MOL && ph == 3) {
+                    // this step's sampling noise, pre-transformed (wrnn_noise_mol_kernel): thread (segment tid >> 4, mixture tid & 15)
+                    const int b0 = GEO[2 * i];
+                    const int su = tid >> 4, sm = tid & 15;
+                    const float *nrow = a.noise_pre + (size_t)(t - a.noise_t0) * 11 * Nall;
+                    const int suc = su < nb ? su : nb - 1;
+                    v0 = nrow[(size_t)(b0 + suc) * 10 + (sm < 10 ? sm : 9)];
+                    v1 = nrow[(size_t)10 * Nall + b0 + suc];
                 }
                 PH(8 * ph + 0);
                 // ---------------- the previous stage's back half -------------------------------------------------------------
@@ -575,7 +604,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                     if (PROF && tid == 0) { PROFL[8 * ph + 6] += 1; PROFL[8 * ph + 7] += !ready; }
                 }
                 PH(8 * ph + 3);
-                if (ph == (roleA ? 3 : 2) && i == nact - 1) {
+                if (ph == last_ph && i == last_i) {
                     // ---- ring hygiene, once per step, at the point where it is free: the last layer this role polls in the step (A: y2,
                     //      B: y1) has just arrived, and it depends on every store this wave issued before polling for it.
                     //      (1) Drain: every store of this wave so far -- in particular the re-arm it issued one step ago for the
@@ -588,18 +617,35 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                     const int ringn = (t + 3) % XRING;
 #pragma unroll 1
                     for (int i2 = 0; i2 < nact; ++i2)
+                    {
                         rearm(xrs, (XLAYER(i2, 0, ringn) + 256 * J + 64 * w) * 4, lane, roleA ? 0 : 1, roleA ? 2 : 3, roleA ? 5 : 6,
                               (!MOL && roleA) ? 4 : -1);
+                        if (!roleA && leader && alternate && (i2 & 1) && lane == 48) {   // the 4 x_t words this wave publishes (segments 4 w ..)
+                            const u32x4 q = {SENT, SENT, SENT, SENT};
+                            __builtin_amdgcn_raw_buffer_store_b128(q, xrs, 16 * w, XLAYER(i2, 7, ringn) * 4, 16 /* sc1 */);
+                        }
+                    }
                 }
                 {   // the NEXT stage's polled layer, one stage ahead: its 8 loads fly during this stage's MFMA tiles and the back half
                     // that follows (a publication is normally several stages old by the time it is polled; if it is not there yet,
                     // finish() polls as before).  Not across a step boundary (nothing of the next step is published yet).
-                    int nph = ph, ni = i + 1;
-                    if (ni >= nact) { nph = ph + 1; ni = 0; }
+                    int nph = ph, ni = i;
+                    do {
+                        if (++ni >= nact) { ++nph; ni = 0; }
+                    } while (nph == 3 && nph < NPH && !samples(ni));
                     xahead = lookahead && nph < NPH && !(roleA && nph == 0) && (MOL || nph != 3);
                     if (xahead) issue(xrs, XLAYER(ni, stage_layer(nph), ring) * 4, w, lane, x);
                 }
-                if (roleA && ph == 0) make_xi(c, WI0, GP[O_XS + fi], w, lane, b);       // xi(t) (:208-209)
+                if (roleA && ph == 0) {
+                    float xs = GP[O_XS + fi];
+                    if (alternate && (i & 1) && t > T0) {
+                        ok = ok && poll_xt(i, (t + 3) % XRING, nb, xtw);
+                        if (!ok && fcode == 0u) fcode = 0x400u | 0x20u;
+                        xs = (fi < nb) ? __uint_as_float(xtw) : 0.f;
+                        GP[O_XS + fi] = xs;                      // (every wave writes the same 16 values) kept for the launch's saved state
+                    }
+                    make_xi(c, WI0, xs, w, lane, b);             // xi(t) (:208-209)
+                }
                 if (ph == 0 && w == (J >> 3)) {
                     // the owned units' slice of this GRU's input (role A: xi, role B: x1) -> LDS in publish order, for the residual
                     // sum the gates' back half publishes: unit block J = k-block r = J & 7 of wave J >> 3
@@ -624,10 +670,10 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                     put_partial<3>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
                     if constexpr (MOL) put_partial<3>(PW, w, 1, lane, mfma1_lds(F3 + XT + frag_off(w, 0, lane), b));
                     bk = BK_SAMPLE;
-                    if (t + 1 < T1) {   // pull the next step's conditioning block of this group (32 KB) into this XCD's L2
-                        asm volatile("" ::"v"(touch));
-                        touch = a.cIf[((size_t)(tc + 1) * NGR + g) * XT + 32 * tid];
-                    }
+                }
+                if (roleA && ph == 2 && t + 1 < T1) {   // pull the next step's conditioning block of this group (32 KB) into this XCD's L2
+                    asm volatile("" ::"v"(touch));
+                    touch = a.cIf[((size_t)(tc + 1) * NGR + g) * XT + 32 * tid];
                 }
                 PH(8 * ph + 5);
                 bi = i; bpp = pp; bt = t; bc0 = v0; bc1 = v1; bc2 = v2;
@@ -639,6 +685,18 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
         }
     }
     if (!run_back(std::integral_constant<bool, MOL>{})) goto bail;      // the last stage's back half
+    if (roleA && alternate && T1 > T0) {                                // x_{T1-1} of the slots role B sampled -> this launch's saved state
+#pragma unroll 1
+        for (int i = 1; i < nact; i += 2) {
+            const int nb = GEO[2 * i + 1];
+            unsigned v = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, XLAYER(i, 7, (T1 - 1) % XRING) * 4, 16 /* sc1 */);
+            ok = ok && poll_xt(i, (T1 - 1) % XRING, nb, v);
+            smem[i * LGRP + O_XS + fi] = (fi < nb) ? __uint_as_float(v) : 0.f;
+        }
+        if (!ok) { fcode = 0x400u | 0x21u; FAIL[0] = 1; }
+        __syncthreads();
+        if (FAIL[0] != 0) goto bail;
+    }
     asm volatile("" ::"v"(touch));
     // ---- save the per-group state for the next slab of steps ------------------------------------------------------
     __syncthreads();
