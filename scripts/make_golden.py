@@ -140,9 +140,30 @@ def rng_kats():
     print('rng kats written')
 
 
+def tacotron_shapes():
+    """Key / shape / dtype table of the reference Tacotron's state dict (hparams.py tts_*): lets the GPU box build a random-init
+    Tacotron state dict of the right architecture without the reference (tests/test_gpu_config3.py)."""
+    import json
+    c = dict(mseed=None, tts_seed=3, frames=1)
+    un = types.ModuleType('unidecode'); un.unidecode = lambda s: s
+    sys.modules.setdefault('unidecode', un)
+    inf = types.ModuleType('inflect'); inf.engine = lambda: types.SimpleNamespace(number_to_words=lambda *a, **k: 'number')
+    sys.modules.setdefault('inflect', inf)
+    from models.tacotron import Tacotron
+    from utils.text.symbols import symbols
+    tts = Tacotron(embed_dims=hp.tts_embed_dims, num_chars=len(symbols), encoder_dims=hp.tts_encoder_dims,
+                   decoder_dims=hp.tts_decoder_dims, n_mels=hp.num_mels, fft_bins=hp.num_mels, postnet_dims=hp.tts_postnet_dims,
+                   encoder_K=hp.tts_encoder_K, lstm_dims=hp.tts_lstm_dims, postnet_K=hp.tts_postnet_K,
+                   num_highways=hp.tts_num_highways, dropout=hp.tts_dropout, stop_threshold=hp.tts_stop_threshold)
+    table = [[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in tts.state_dict().items()]
+    json.dump(table, open(os.path.join(OUT, 'tacotron_shapes.json'), 'w'))
+    print('tacotron shapes written:', len(table), 'tensors')
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     rng_kats()
+    tacotron_shapes()
     only = sys.argv[1:]
     for c in CASES:
         if only and c['name'] not in only:

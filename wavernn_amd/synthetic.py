@@ -81,3 +81,27 @@ def random_state_dict(seed, mode='MOL', rnn_dims=512, fc_dims=512, bits=9, pad=2
 def random_mel(seed, n_frames, n_mels=80):
     """U[0,1) mel of shape (n_mels, n_frames): satisfies the range check of `gen_wavernn.py:52-55`."""
     return np.random.RandomState(seed).uniform(0.0, 1.0, size=(n_mels, n_frames)).astype(np.float32)
+
+
+def random_tacotron_state_dict(seed, shapes):
+    """Seeded random-init Tacotron state dict from a (key, shape, dtype) table (tests/golden/tacotron_shapes.json, written by
+    scripts/make_golden.py from the reference's module): Xavier-uniform matrices like `Tacotron.init_model` (models/tacotron.py:
+    432-434), zero biases, identity batch norms.  Architecture-only stand-in for the absent pretrained checkpoint."""
+    import torch
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for key, shape, dtype in shapes:
+        if dtype != 'float32':
+            val = {'decoder.r': 1, 'step': 0}.get(key, 0)
+            sd[key] = torch.full(shape, val, dtype=getattr(torch, dtype))
+        elif key.endswith('running_var') or (key.endswith('.weight') and 'bnorm' in key):
+            sd[key] = torch.ones(shape)
+        elif key == 'stop_threshold':
+            sd[key] = torch.tensor(-3.4)
+        elif len(shape) >= 2:
+            fan_out, fan_in = shape[0] * int(np.prod(shape[2:])), shape[1] * int(np.prod(shape[2:]))
+            a = np.sqrt(6.0 / (fan_in + fan_out))
+            sd[key] = torch.from_numpy(rs.uniform(-a, a, shape).astype(np.float32))
+        else:
+            sd[key] = torch.zeros(shape)
+    return sd

@@ -1,0 +1,203 @@
+"""Tacotron inference in front of the vocoder -- BASELINE config 3's caller side (`gen_tacotron.py wavernn`, reference
+gen_tacotron.py:139-166; SURVEY.md section 8 row f3's host).
+
+This is NOT the hot path and not a kernel: it is the reference's `Tacotron.generate()` (models/tacotron.py:370-430) restated as
+a FUNCTIONAL forward over a reference state dict (`tts_model.state_dict()` / `latest_weights.pyt`), on whatever device the
+tensors live on -- PyTorch-ROCm on an MI355X.  No module tree, no training code, eval semantics only (dropout and zoneout
+are identities in `generate()`, which calls `self.eval()` first, :371).  On the CPU it reproduces the reference bit for bit
+(tests/test_tacotron_mirror.py, build container); on the GPU the decoder loop -- ~40 small launches per mel frame, one
+sentence = one serial chain -- can be captured ONCE as a HIP graph and replayed per frame (`graph=True`).  The decoder loop
+as a second persistent kernel (f3) is the follow-up; this gives config 3 an end-to-end path and a number to beat.
+
+    tts = TacotronInference(state_dict, device='cuda')
+    mel, linear, attn = tts.generate(ids, steps=800)          # same returns as the reference: (80, N), (fft, N), (N, chars)
+    m = torch.tensor(np.clip((mel + 4) / 8, 0, 1)).unsqueeze(0)   # gen_tacotron.py:143-145
+    voc.generate(m, path, True, 11_000, 550, True)               # gen_tacotron.py:161-163
+"""
+import re
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+#: the character part of the reference's symbol table (utils/text/symbols.py:8-17: pad, '-', punctuation, letters; the ARPAbet
+#: symbols follow and are only reachable through {curly brace} input)
+SYMBOLS = ['_'] + list('-') + list('!\'(),.:;? ') + list('ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz')
+_ID = {s: i for i, s in enumerate(SYMBOLS)}
+
+
+def text_to_ids(text):
+    """`text_to_sequence(text, ['basic_cleaners'])` (utils/text/__init__.py:16-43, cleaners.py:69-73) for plain text: lowercase,
+    collapse whitespace, drop unknown symbols and the pad.  The reference's default `english_cleaners` additionally
+    transliterates and spells out numbers / abbreviations (needs unidecode + inflect); for text without those both agree."""
+    text = re.sub(r'\s+', ' ', text.lower())
+    return [_ID[c] for c in text if c in _ID and c not in '_~']
+
+
+class TacotronInference:
+    def __init__(self, state_dict, device=None):
+        dev = torch.device(device) if device is not None else None
+        self.p = {k: (v.detach().to(dev) if dev is not None else v.detach()) for k, v in state_dict.items() if torch.is_tensor(v)}
+        p = self.p
+        self.device = p['encoder.embedding.weight'].device
+        self.n_mels = p['decoder.prenet.fc1.weight'].shape[1]
+        self.decoder_dims = p['decoder.attn_rnn.weight_hh'].shape[1]
+        self.lstm_dims = p['decoder.res_rnn1.weight_hh'].shape[1]
+        self.max_r = p['decoder.mel_proj.weight'].shape[0] // self.n_mels
+        self.r = int(p['decoder.r'].item()) if 'decoder.r' in p else int(p.get('r', torch.tensor(1)).item())
+        self.stop_threshold = float(p['stop_threshold'].item()) if 'stop_threshold' in p else -3.4
+        self._enc_k = self._count('encoder.cbhg.conv1d_bank.%d.conv.weight')
+        self._post_k = self._count('postnet.conv1d_bank.%d.conv.weight')
+
+    def _count(self, pattern):
+        n = 0
+        while pattern % n in self.p:
+            n += 1
+        return n
+
+    # -- building blocks (eval mode) ----------------------------------------------------------------------------------
+    def _bnconv(self, x, prefix, relu=True):
+        """BatchNormConv (models/tacotron.py:43-54): conv (same padding) -> [relu] -> batch norm (running statistics)."""
+        w = self.p[prefix + '.conv.weight']
+        x = F.conv1d(x, w, None, 1, w.shape[2] // 2)
+        if relu:
+            x = F.relu(x)
+        q = prefix + '.bnorm.'
+        return F.batch_norm(x, self.p[q + 'running_mean'], self.p[q + 'running_var'], self.p[q + 'weight'], self.p[q + 'bias'], False, 0.0, 1e-5)
+
+    def _prenet(self, x, prefix):
+        """PreNet (:141-155) in eval mode: two linear + relu layers, dropout off."""
+        x = F.relu(F.linear(x, self.p[prefix + '.fc1.weight'], self.p[prefix + '.fc1.bias']))
+        return F.relu(F.linear(x, self.p[prefix + '.fc2.weight'], self.p[prefix + '.fc2.bias']))
+
+    def _cbhg(self, x, prefix, K):
+        """CBHG (:57-139): conv bank 1..K -> max pool -> two projections -> residual -> highways -> bidirectional GRU."""
+        p = self.p
+        n = x.size(-1)
+        res = x
+        bank = torch.cat([self._bnconv(x, f'{prefix}.conv1d_bank.{k}')[:, :, :n] for k in range(K)], dim=1)
+        x = F.max_pool1d(bank, 2, 1, 1)[:, :, :n]
+        x = self._bnconv(x, prefix + '.conv_project1')
+        x = self._bnconv(x, prefix + '.conv_project2', relu=False)
+        x = (x + res).transpose(1, 2)
+        if prefix + '.pre_highway.weight' in p:
+            x = F.linear(x, p[prefix + '.pre_highway.weight'])
+        h = 0
+        while f'{prefix}.highways.{h}.W1.weight' in p:
+            q = f'{prefix}.highways.{h}.'
+            x1 = F.linear(x, p[q + 'W1.weight'], p[q + 'W1.bias'])
+            g = torch.sigmoid(F.linear(x, p[q + 'W2.weight'], p[q + 'W2.bias']))
+            x = g * F.relu(x1) + (1. - g) * x
+            h += 1
+        q = prefix + '.rnn.'
+        flat = [p[q + n_] for n_ in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0', 'weight_ih_l0_reverse',
+                                     'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')]
+        hx = torch.zeros(2, x.size(0), flat[1].shape[1], device=x.device, dtype=x.dtype)
+        out, _ = torch._VF.gru(x, hx, flat, True, 1, 0.0, False, True, True)
+        return out
+
+    def encode(self, ids):
+        """Encoder (:24-39) + `encoder_proj` (:403-404): ids (n,) -> encoder_seq (1, n, 2C), its projection (1, n, D)."""
+        x = torch.as_tensor(ids, dtype=torch.long, device=self.device).unsqueeze(0)
+        x = F.embedding(x, self.p['encoder.embedding.weight'])
+        x = self._prenet(x, 'encoder.pre_net').transpose(1, 2)
+        seq = self._cbhg(x, 'encoder.cbhg', self._enc_k)
+        return seq, F.linear(seq, self.p['encoder_proj.weight'])
+
+    def _decoder_step(self, seq, seq_proj, prenet_in, st):
+        """Decoder.forward (:218-279) in eval mode with the LSA attention (:181-207); `st` holds the recurrent tensors and is
+        updated IN PLACE (static addresses: the step can be captured as a HIP graph)."""
+        p = self.p
+        q = 'decoder.'
+        pre = self._prenet(prenet_in, q + 'prenet')
+        attn_h = torch.gru_cell(torch.cat([st['context'], pre], dim=-1), st['attn_h'], p[q + 'attn_rnn.weight_ih'], p[q + 'attn_rnn.weight_hh'],
+                                p[q + 'attn_rnn.bias_ih'], p[q + 'attn_rnn.bias_hh'])
+        # location-sensitive attention with sigmoid-normalised ("smooth") scores
+        pq = F.linear(attn_h, p[q + 'attn_net.W.weight'], p[q + 'attn_net.W.bias']).unsqueeze(1)
+        loc = torch.cat([st['cumulative'].unsqueeze(1), st['attention'].unsqueeze(1)], dim=1)
+        kw = p[q + 'attn_net.conv.weight']
+        ploc = F.linear(F.conv1d(loc, kw, None, 1, (kw.shape[2] - 1) // 2).transpose(1, 2), p[q + 'attn_net.L.weight'], p[q + 'attn_net.L.bias'])
+        u = F.linear(torch.tanh(pq + seq_proj + ploc), p[q + 'attn_net.v.weight']).squeeze(-1)
+        scores = torch.sigmoid(u) / torch.sigmoid(u).sum(dim=1, keepdim=True)
+        st['attention'].copy_(scores)
+        st['cumulative'].add_(scores)
+        context = (scores.unsqueeze(-1).transpose(1, 2) @ seq).squeeze(1)
+        x = F.linear(torch.cat([context, attn_h], dim=1), p[q + 'rnn_input.weight'], p[q + 'rnn_input.bias'])
+        h1, c1 = torch.lstm_cell(x, (st['h1'], st['c1']), p[q + 'res_rnn1.weight_ih'], p[q + 'res_rnn1.weight_hh'], p[q + 'res_rnn1.bias_ih'],
+                                 p[q + 'res_rnn1.bias_hh'])
+        x = x + h1
+        h2, c2 = torch.lstm_cell(x, (st['h2'], st['c2']), p[q + 'res_rnn2.weight_ih'], p[q + 'res_rnn2.weight_hh'], p[q + 'res_rnn2.bias_ih'],
+                                 p[q + 'res_rnn2.bias_hh'])
+        x = x + h2
+        mels = F.linear(x, p[q + 'mel_proj.weight']).view(x.size(0), self.n_mels, self.max_r)[:, :, :self.r]
+        for k, v in (('attn_h', attn_h), ('context', context), ('h1', h1), ('c1', c1), ('h2', h2), ('c2', c2)):
+            st[k].copy_(v)
+        return mels, scores
+
+    @torch.no_grad()
+    def generate(self, ids, steps=2000, graph=False, stop_check_every=1):
+        """`Tacotron.generate(x, steps)` (:370-430).  Returns numpy (mel (n_mels, N), linear (fft, N), attention (N, n_chars)).
+
+        graph=True (CUDA/HIP device): one decoder step is captured as a HIP graph and replayed; the stop test of :411 (`all
+        frames < stop_threshold and t > 10`) is then evaluated from per-step flags every `stop_check_every` frames and the
+        output truncated at the first step that met it -- the same result as the eager loop, without a host round trip
+        per frame."""
+        dev = self.device
+        seq, seq_proj = self.encode(ids)
+        n = seq.size(1)
+        z = lambda *s: torch.zeros(*s, device=dev)
+        st = dict(attn_h=z(1, self.decoder_dims), h1=z(1, self.lstm_dims), h2=z(1, self.lstm_dims), c1=z(1, self.lstm_dims),
+                  c2=z(1, self.lstm_dims), context=z(1, self.decoder_dims), cumulative=z(1, n), attention=z(1, n))
+        prenet_in = z(1, self.n_mels)                                              # the <GO> frame
+        frames, scores_all = [], []
+        if graph and dev.type == 'cuda':
+            out_m, out_s = z(1, self.n_mels, self.r), z(1, n)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                                          # warm-up outside capture, then restore the state
+                saved = {k: v.clone() for k, v in st.items()}
+                self._decoder_step(seq, seq_proj, prenet_in, st)
+                for k, v in saved.items():
+                    st[k].copy_(v)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                m_, s_ = self._decoder_step(seq, seq_proj, prenet_in, st)
+                out_m.copy_(m_)
+                out_s.copy_(s_)
+                prenet_in.copy_(m_[:, :, -1])
+            for k, v in saved.items():                                             # capture does not execute: state is still pristine,
+                st[k].copy_(v)                                                     # but be explicit
+            prenet_in.zero_()
+            flags, last = [], 0
+            for t in range(0, steps, self.r):
+                g.replay()
+                frames.append(out_m.clone())
+                scores_all.append(out_s.clone())
+                flags.append((out_m < self.stop_threshold).all())
+                if (len(flags) - last) >= stop_check_every or t + self.r >= steps:
+                    f = torch.stack(flags).cpu().numpy()
+                    hit = [i for i in range(len(f)) if f[i] and i * self.r > 10]
+                    if hit:
+                        frames, scores_all = frames[:hit[0] + 1], scores_all[:hit[0] + 1]
+                        break
+                    last = len(flags)
+        else:
+            for t in range(0, steps, self.r):
+                m_, s_ = self._decoder_step(seq, seq_proj, prenet_in, st)
+                frames.append(m_)
+                scores_all.append(s_.clone())
+                prenet_in = m_[:, :, -1]
+                if (m_ < self.stop_threshold).all() and t > 10:
+                    break
+        mel = torch.cat(frames, dim=2)
+        post = self._cbhg(mel, 'postnet', self._post_k)
+        linear = F.linear(post, self.p['post_proj.weight']).transpose(1, 2)[0]
+        attn = torch.cat([s.unsqueeze(-1).transpose(1, 2) for s in scores_all], 1)[0]
+        return mel[0].cpu().numpy(), linear.cpu().numpy(), attn.cpu().numpy()
+
+
+def tacotron_to_wavernn_mel(mel):
+    """gen_tacotron.py:143-145: rescale the Tacotron mel from [-4, 4] to [0, 1] and clip."""
+    m = (np.asarray(mel) + 4) / 8
+    return np.clip(m, 0, 1, out=m)
