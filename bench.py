@@ -71,11 +71,12 @@ def cpu_baseline(sd, mode, frames, target, overlap, budget_s):
 
 
 def source_sha16():
-    """Hash of the kernel + host sources a measurement belongs to (keys profiles/traffic_latest.json to the code it measured)."""
+    """Hash of the kernel sources a measurement belongs to (keys profiles/traffic_latest.json to the code it measured; the
+    workload is matched separately: kernel, mode, segments, T)."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, 'wavernn_amd', 'csrc', '*.h*')) + [os.path.join(ROOT, 'bench.py')]):
+    for f in sorted(glob.glob(os.path.join(ROOT, 'wavernn_amd', 'csrc', '*.h*'))):
         h.update(open(f, 'rb').read())
     return h.hexdigest()[:16]
 
@@ -293,6 +294,12 @@ def main():
                 res['cpu_baseline'] = cpu_baseline(sd, mode, args.frames, target, overlap, args.cpu_seconds)
             except Exception as e:   # the baseline is a report, never a reason to lose the GPU number
                 res['cpu_baseline'] = {'error': repr(e)}
+        sys.stdout.flush()
+        try:    # RCCL / HIP libraries printf into the C stdio buffer, which is flushed at exit, i.e. AFTER this line: empty it first so
+            import ctypes                      # the JSON line is the last line of stdout
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(res), flush=True)
     if group is not None:
         dist.destroy_process_group()
