@@ -563,6 +563,34 @@ def test_full_size_properties(gpu, mode):
         assert np.abs(a - s).max() <= MOL_TOL
 
 
+def test_inplace_weight_edit_rebuilds_the_device_pack(gpu, tmp_path):
+    """Weights edited in place through `.data` (what the reference's pruning notebook does: `W *= M` on `parameters()[i].data`)
+    change neither data_ptr nor `_version` of the parameter; the device weight pack is keyed on a content fingerprint, so
+    the next generate() sees them (round-1 advisor finding: it used to keep the stale pack)."""
+    from wavernn_amd.model import WaveRNN
+    from wavernn_amd.prune import wavernn_pruner
+    from wavernn_amd.synthetic import random_state_dict, random_mel, SHIPPED
+    model = WaveRNN(**SHIPPED, mode='MOL')
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in random_state_dict(54, mode='MOL').items()}, strict=True)
+    model = model.to(gpu)
+    mel = torch.tensor(random_mel(630, 30)).unsqueeze(0)
+    torch.manual_seed(5)
+    a = model.generate(mel, tmp_path / 'a.wav', True, 1100, 55, True)
+    eng = model._loop_engine()
+    assert model._loop_engine() is eng and eng.sparse_blocks < 0                    # unchanged weights: the pack is reused (dense)
+    pruner, layers = wavernn_pruner(model, start_prune=0, prune_steps=1, target_sparsity=0.95, prune_every=1)
+    for step in (1, 2):
+        pruner.prune(layers, step)                                                   # in-place .data edits, 16x1 blocks, 95 %
+    torch.manual_seed(5)
+    b = model.generate(mel, tmp_path / 'b.wav', True, 1100, 55, True)
+    assert model._loop_engine() is not eng and model._loop_engine().sparse_blocks > 0
+    assert model.last_loop_kernel == 'wrnn_sparse_kernel' and not np.array_equal(a, b)
+    from oracle import wavernn_oracle as O
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    ref = O.generate(sd, 'MOL', random_mel(630, 30), True, 1100, 55, True, 5)
+    assert np.abs(b - ref).max() <= MOL_TOL
+
+
 def test_product_fails_loudly_without_extension(gpu, monkeypatch):
     from wavernn_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)

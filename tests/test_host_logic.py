@@ -242,3 +242,25 @@ def test_pruner_follows_the_reference_schedule_and_rule():
     W = model.rnn1.weight_hh_l0.data.numpy()
     dens = (np.abs(W).reshape(3, 32, 16, 512).sum(axis=2) != 0).mean()
     assert abs(dens - 0.05) < 0.002, dens                      # 16x1 blocks, 5 % survive per gate
+
+
+def test_corpus_chunks_and_seed_check():
+    """`generate_corpus` works through a rank's block in chunks of whole utterances (bounded resident conditioning / noise) and
+    refuses parity noise without seeds with a clear error (round-1 advisor findings)."""
+    from wavernn_amd.batch import plan_utterances, chunk_utterances, generate_corpus
+    plan = plan_utterances([n * 275 for n in (23, 40, 31, 26, 55, 21)], 550, 55)
+    total = plan.n_segments
+    chunks = chunk_utterances(plan, 0, total, 20)
+    assert [u for c in chunks for u in c[0]] == list(range(6))                       # every utterance once, in order
+    assert chunks[0][1] == 0 and chunks[-1][2] == total
+    assert all(a[2] == b[1] for a, b in zip(chunks, chunks[1:]))                     # contiguous segment ranges
+    assert all(c[2] - c[1] <= 20 or len(c[0]) == 1 for c in chunks)                  # bounded (one long utterance may exceed)
+    lo, hi = total // 3, 2 * total // 3                                               # a middle rank's block: clipped at both ends
+    mid = chunk_utterances(plan, lo, hi, 8)
+    assert mid[0][1] == lo and mid[-1][2] == hi and all(a[2] == b[1] for a, b in zip(mid, mid[1:]))
+    assert chunk_utterances(plan, 0, total, 10 ** 6) == [(list(range(6)), 0, total)]
+    from wavernn_amd.model import WaveRNN
+    from wavernn_amd.synthetic import SHIPPED
+    m = WaveRNN(**SHIPPED, mode='MOL')
+    with pytest.raises(ValueError, match='seeds'):
+        generate_corpus(m, [torch.rand(1, 80, 30)], 550, 55, True)

@@ -12,6 +12,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SO_PATH = os.path.join(CSRC, 'libwavernn_amd.so')
 
 WRNN_OK = 0
+ERR_RESIDENCY = -6          # WRNN_ERR_RESIDENCY: the persistent grid cannot be co-resident on this device
 MODE_RAW, MODE_MOL = 0, 1
 ABI_VERSION = 3
 ALGO_AUTO, ALGO_STREAM, ALGO_LOOP, ALGO_SPARSE = 0, 1, 2, 5

@@ -383,9 +383,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     };
     u32x4 x[8];                                          // fragments of the polled layer; issued ONE STAGE AHEAD (before the previous
     bool xahead = false;                                 // stage's MFMA tiles) whenever that stage is in the same step
-    // look-ahead only pays with >= 2 groups in flight: with one, the next stage's layer is never there a stage early (its producers
-    // are waiting for this stage's own publication), so the early loads would all be wasted
-    const bool lookahead = (a.tuning & 1) == 0 && nact >= 2, full_fence = (a.tuning & 2) != 0;      // A/B switches (wrnn_options.tuning)
+    const bool lookahead = (a.tuning & 1) == 0, full_fence = (a.tuning & 2) != 0;      // A/B switches (wrnn_options.tuning)
     int bk = BK_NONE, bi = 0, bpp = 0, bt = 0, cur_ph = 0;
     float bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
 

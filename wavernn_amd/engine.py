@@ -161,6 +161,13 @@ class LoopEngine:
         rc = self.lib.wrnn_generate_segments(self._pack, B, T, seg_pos.ctypes.data, seg_lim.ctypes.data, L, hop, n_frames,
                                              mels_up.data_ptr(), aux.data_ptr(), noise.data_ptr(), out.data_ptr(),
                                              self._ws.data_ptr(), self._ws.numel(), ctypes.byref(o), stream)
+        if rc == _lib.ERR_RESIDENCY and algo == 'auto' and t0 == 0 and t1 == T:
+            # the persistent grid is not co-resident right now (CU masking, a smaller partition, another cooperative kernel):
+            # `auto` degrades to the stream kernel (any device, no inter-workgroup traffic) instead of failing
+            import warnings
+            warnings.warn('wavernn_amd: cooperative launch refused (' + self.lib.wrnn_last_error().decode() + '); using the stream kernel')
+            return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='stream', force_x=force_x,
+                                     want_logits=want_logits, check=check, cond_valu=cond_valu, out=out, logits=logits)
         _lib.check(rc, 'wrnn_generate_segments')
         self._launches = (self._launches if t0 > 0 else 0) + int(self._info.launches)
         self._last_opts = (B, T, n_frames, self.options(algo, depth, clusters, slab_steps, cond_valu, None))
