@@ -264,3 +264,26 @@ def test_corpus_chunks_and_seed_check():
     m = WaveRNN(**SHIPPED, mode='MOL')
     with pytest.raises(ValueError, match='seeds'):
         generate_corpus(m, [torch.rand(1, 80, 30)], 550, 55, True)
+
+
+def test_wav_front_end_properties(tmp_path):
+    """dsp.py's `.wav` -> mel front-end (librosa restated; PARITY UNPINNED: librosa is not available) -- defining properties only:
+    frame count of a centered STFT, range, a pure tone lands in the mel band that contains it, unit-area filters, WAV round trip."""
+    from wavernn_amd import dsp
+    sr, hop = 22050, 275
+    t = np.arange(sr) / sr
+    for f0 in (200.0, 1000.0, 4000.0):
+        m = dsp.melspectrogram((0.5 * np.sin(2 * np.pi * f0 * t)).astype(np.float32))
+        assert m.shape == (80, 1 + sr // hop) and m.dtype == np.float32 and 0.0 <= m.min() and m.max() <= 1.0
+        edges = dsp._mel_to_hz(np.linspace(dsp._hz_to_mel(40), dsp._hz_to_mel(sr / 2), 82))
+        band = int(m[:, 40].argmax())
+        assert edges[band] <= f0 <= edges[band + 2], (f0, band, edges[band:band + 3])
+    B = dsp.mel_basis()
+    assert B.shape == (80, 1025) and (B >= 0).all()
+    np.testing.assert_allclose((B * (sr / 2 / 1024)).sum(axis=1), 1.0, atol=0.08)          # unit area (discretised)
+    assert np.allclose(dsp._mel_to_hz(dsp._hz_to_mel([40.0, 999.0, 1000.0, 8000.0])), [40.0, 999.0, 1000.0, 8000.0])
+    x = (0.25 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    dsp.save_wav(x, tmp_path / 'a.wav', sr)
+    assert np.array_equal(dsp.load_wav(tmp_path / 'a.wav', sr), x)
+    with pytest.raises(ValueError):
+        dsp.load_wav(tmp_path / 'a.wav', 16000)

@@ -51,6 +51,7 @@ constexpr unsigned SENT = 0xFFFFFFFFu;       // "not written yet"
 //   XO[256]: the owned 16 units x 16 segments of the residual input of this workgroup's GRU (role A: xi, role B: x1), in publish order
 constexpr int LGRP = 3 * 256 + 256 + 16 + 32 + 32 + 256;
 constexpr int O_HOWN = 768, O_XS = 1024, O_SP = 1040, O_FR = 1072, O_XO = 1104;
+constexpr int LOGS = 33;                     // row stride of the logits scratch (32 would put a column's 16 writers on one bank)
 constexpr int LPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][slot 0..2][16][16]
 struct LoopLds {
     int off_part, off_log, off_wi0, off_f3, off_lgt, off_misc, off_prof, total;
@@ -60,7 +61,7 @@ __host__ __device__ inline LoopLds loop_lds(int mode, int G)
     LoopLds l;
     int o = G * LGRP;
     l.off_part = o; o += LPART;
-    l.off_log = o;  o += SEG * 32;
+    l.off_log = o;  o += SEG * LOGS;                       // [segment][LOGS] logits of the group being sampled (528 floats: keeps 16-B alignment)
     l.off_wi0 = o;  o += H;
     l.off_f3 = o;   o += (mode == 1 ? 2 : 1) * XT;         // fc3 in A-fragment order [tile][wave][r][lane][4]
     l.off_lgt = o;  o += (mode == 0) ? SEG * LDC : 0;      // RAW: the gathered logits as [segment][class] rows
@@ -431,22 +432,22 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                 {   // 30 logit rows x 16 segments: thread (row tid >> 4 and 16 + row, segment tid & 15)
                     const int row = tid >> 4, sj = tid & 15;
                     const float lg = get_partial<3>(PB, 0, row, sj) + b3a;
-                    LOG[sj * 32 + row] = lg;
+                    LOG[sj * LOGS + row] = lg;
                     if (a.dbg_logits && leader && sj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + sj) * C + row] = lg;
                     if (row < 14) {
                         const float lg2 = get_partial<3>(PB, 1, row, sj) + b3b;
-                        LOG[sj * 32 + 16 + row] = lg2;
+                        LOG[sj * LOGS + 16 + row] = lg2;
                         if (a.dbg_logits && leader && sj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + sj) * C + 16 + row] = lg2;
                     }
                 }
                 __syncthreads();
                 {   // utils/distribution.py:102-121: 16-lane row = one segment (su), lane sm = mixture; bc0 / bc1 = this thread's noise
                     const int su = tid >> 4, sm = tid & 15;
-                    float best = (sm < 10) ? mol_gumbel_pre(LOG[su * 32 + sm], bc0) : -INFINITY;
+                    float best = (sm < 10) ? mol_gumbel_pre(LOG[su * LOGS + sm], bc0) : -INFINITY;
                     int bidx = sm;
                     argmax_row16(best, bidx);
                     if (sm == 0 && su < nb) {
-                        float x = mol_sample_pre(LOG[su * 32 + 10 + bidx], LOG[su * 32 + 20 + bidx], bc1);
+                        float x = mol_sample_pre(LOG[su * LOGS + 10 + bidx], LOG[su * LOGS + 20 + bidx], bc1);
                         if (leader) a.out[(size_t)(b0 + su) * a.T + bt] = x;
                         if (a.force_x) x = a.force_x[(size_t)(b0 + su) * a.T + bt];
                         XS[su] = x;
@@ -456,6 +457,15 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                 }
             } else {
                 const size_t tn = (size_t)(bt - a.noise_t0);
+                // this wave samples segments 4 w .. 4 w + 3 (clamped to the group: a ragged group re-does its last segment, results
+                // discarded): their Exp(1) variates are requested FIRST, so the 2 KB per segment arrive behind the logit exchange
+                float qn[4][8];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int sjc = (4 * w + s4 < nb) ? 4 * w + s4 : nb - 1;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qn[s4][e] = a.noise[(tn * Nall + b0 + sjc) * C + lane + 64 * e];
+                }
                 publish4(xrs, (XLAYER(bi, 4, bring) + 256 * J) * 4, tid, get_partial<3>(PB, 0, pu, pj) + b3a, pj < nb);
                 {   // the 512 logits of every segment -> LGT [segment][class]
                     u32x4 x[8];
@@ -471,50 +481,81 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                 if (!ok) FAIL[0] = 1;
                 __syncthreads();
                 if (FAIL[0] != 0) return false;
-                // fatchord_version.py:232-237: softmax -> Categorical (renormalise) -> argmax(p / q); one wave per 4 segments
-#pragma unroll 1
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const int sj = 4 * w + s4;
-                    if (sj < nb) {                                           // wave-uniform
-                        float lg[8], qn[8];
-                        float mx = -INFINITY;
+                // fatchord_version.py:232-237: softmax -> Categorical (renormalise) -> argmax(p / q).  One wave per 4 segments, the
+                // four handled in lock step (straight-line code: four independent butterfly chains in flight instead of one); per
+                // segment the operation order is unchanged (bit-exact class indices)
+                {
+                    float lg[4][8], mx[4], sum[4], sum2[4], best[4];
+                    int bidx[4];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int sjc = (4 * w + s4 < nb) ? 4 * w + s4 : nb - 1;
+                        mx[s4] = -INFINITY;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            qn[e] = a.noise[(tn * Nall + b0 + sj) * C + lane + 64 * e];
-                            lg[e] = LGT[sj * LDC + lane + 64 * e];
-                            if (a.dbg_logits && leader) a.dbg_logits[((size_t)bt * Nall + b0 + sj) * C + lane + 64 * e] = lg[e];
-                            mx = fmaxf(mx, lg[e]);
+                            lg[s4][e] = LGT[sjc * LDC + lane + 64 * e];
+                            mx[s4] = fmaxf(mx[s4], lg[s4][e]);
                         }
+                    }
+                    if (a.dbg_logits && leader) {
 #pragma unroll
-                        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-                        float sum = 0.f;
+                        for (int s4 = 0; s4 < 4; ++s4)
+                            if (4 * w + s4 < nb)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { lg[e] = expf(lg[e] - mx); sum += lg[e]; }
+                                for (int e = 0; e < 8; ++e) a.dbg_logits[((size_t)bt * Nall + b0 + 4 * w + s4) * C + lane + 64 * e] = lg[s4][e];
+                    }
 #pragma unroll
-                        for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
-                        float sum2 = 0.f;
+                    for (int m = 32; m >= 1; m >>= 1)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { lg[e] = lg[e] / sum; sum2 += lg[e]; }
+                        for (int s4 = 0; s4 < 4; ++s4) mx[s4] = fmaxf(mx[s4], __shfl_xor(mx[s4], m, 64));
 #pragma unroll
-                        for (int m = 32; m >= 1; m >>= 1) sum2 += __shfl_xor(sum2, m, 64);
-                        float best = -INFINITY;
-                        int bidx = 0;
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        sum[s4] = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { lg[s4][e] = expf(lg[s4][e] - mx[s4]); sum[s4] += lg[s4][e]; }
+                    }
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) sum[s4] += __shfl_xor(sum[s4], m, 64);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        sum2[s4] = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { lg[s4][e] = lg[s4][e] / sum[s4]; sum2[s4] += lg[s4][e]; }
+                    }
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) sum2[s4] += __shfl_xor(sum2[s4], m, 64);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        best[s4] = -INFINITY;
+                        bidx[s4] = 0;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float rr = (lg[e] / sum2) / qn[e];
-                            if (rr > best) { best = rr; bidx = lane + 64 * e; }
+                            const float rr = (lg[s4][e] / sum2[s4]) / qn[s4][e];
+                            if (rr > best[s4]) { best[s4] = rr; bidx[s4] = lane + 64 * e; }
                         }
+                    }
 #pragma unroll
-                        for (int m = 32; m >= 1; m >>= 1) {
-                            const float ob = __shfl_xor(best, m, 64);
-                            const int oi = __shfl_xor(bidx, m, 64);
-                            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+                    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            const float ob = __shfl_xor(best[s4], m, 64);
+                            const int oi = __shfl_xor(bidx[s4], m, 64);
+                            if (ob > best[s4] || (ob == best[s4] && oi < bidx[s4])) { best[s4] = ob; bidx[s4] = oi; }
                         }
-                        if (lane == 0) {
-                            float x = 2.f * (float)bidx / ((float)C - 1.f) - 1.f;
-                            if (leader) a.out[(size_t)(b0 + sj) * a.T + bt] = x;
-                            if (a.force_x) x = a.force_x[(size_t)(b0 + sj) * a.T + bt];
-                            XS[sj] = x;
+                    if (lane == 0) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            const int sj = 4 * w + s4;
+                            if (sj < nb) {
+                                float x = 2.f * (float)bidx[s4] / ((float)C - 1.f) - 1.f;
+                                if (leader) a.out[(size_t)(b0 + sj) * a.T + bt] = x;
+                                if (a.force_x) x = a.force_x[(size_t)(b0 + sj) * a.T + bt];
+                                XS[sj] = x;
+                            }
                         }
                     }
                 }

@@ -1,5 +1,6 @@
 """`python -m wavernn_amd.gen_wavernn --file mel.npy --weights latest_weights.pyt` -- the `--file x.npy` path of the
-reference's vocoder CLI (gen_wavernn.py:38-65, :68-142) on the MI355X-native generate path.
+reference's vocoder CLI (gen_wavernn.py:38-65, :68-142) on the MI355X-native generate path (`--file x.wav` goes through the
+librosa-free mel front-end of dsp.py).
 
 Same flags as the reference where they exist (--batched/-b, --unbatched/-u, --target/-t, --overlap/-o, --file/-f,
 --weights/-w); the hparams.py machinery is replaced by flags with the shipped defaults (hparams.py:20-60).  Mel
@@ -17,14 +18,21 @@ from .synthetic import SHIPPED
 def gen_from_file(model, load_path: Path, save_path: Path, batched, target, overlap, mu_law=True):
     """gen_wavernn.py:38-65 for a `.npy` mel."""
     suffix = load_path.suffix
-    if suffix != '.npy':
-        raise ValueError(f"Expected an extension of .npy, but got {suffix}! (.wav needs the reference's librosa front-end)")
-    mel = np.load(load_path)
-    if mel.ndim != 2 or mel.shape[0] != 80:
-        raise ValueError(f'Expected a numpy array shaped (n_mels, n_hops), but got {mel.shape}!')
-    _max, _min = mel.max(), mel.min()
-    if _max >= 1.01 or _min <= -0.01:
-        raise ValueError(f'Expected spectrogram range in [0,1] but was instead [{_min}, {_max}]')
+    if suffix == '.wav':
+        # gen_wavernn.py:44-47: the librosa front-end, restated without librosa (dsp.py; parity unpinned -- see its header)
+        from . import dsp
+        wav = dsp.load_wav(load_path, model.sample_rate)
+        dsp.save_wav(wav, save_path / f'__{load_path.stem}__{model.get_step() // 1000}k_steps_target.wav', model.sample_rate)
+        mel = dsp.melspectrogram(wav)
+    elif suffix == '.npy':
+        mel = np.load(load_path)
+        if mel.ndim != 2 or mel.shape[0] != 80:
+            raise ValueError(f'Expected a numpy array shaped (n_mels, n_hops), but got {mel.shape}!')
+        _max, _min = mel.max(), mel.min()
+        if _max >= 1.01 or _min <= -0.01:
+            raise ValueError(f'Expected spectrogram range in [0,1] but was instead [{_min}, {_max}]')
+    else:
+        raise ValueError(f'Expected an extension of .wav or .npy, but got {suffix}!')
     mel = torch.tensor(mel).unsqueeze(0)
     batch_str = f'gen_batched_target{target}_overlap{overlap}' if batched else 'gen_NOT_BATCHED'
     save_str = save_path / f'__{load_path.stem}__{batch_str}.wav'
@@ -38,7 +46,7 @@ def main(argv=None):
     ap.add_argument('--unbatched', '-u', dest='batched', action='store_false')
     ap.add_argument('--target', '-t', type=int, default=11000)
     ap.add_argument('--overlap', '-o', type=int, default=550)
-    ap.add_argument('--file', '-f', type=str, required=True, help='.npy mel spectrogram (80, N) in [0,1]')
+    ap.add_argument('--file', '-f', type=str, required=True, help='.npy mel spectrogram (80, N) in [0,1], or a .wav at the model sample rate')
     ap.add_argument('--weights', '-w', type=str, help='state-dict .pyt of the reference WaveRNN (random init if omitted)')
     ap.add_argument('--mode', default='MOL', choices=['MOL', 'RAW'])
     ap.add_argument('--output', default='.', help='output directory')
