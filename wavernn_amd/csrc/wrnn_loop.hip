@@ -388,8 +388,10 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     int bk = BK_NONE, bi = 0, bpp = 0, bt = 0, cur_ph = 0;
     float bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
 
-    // with_sample: the pending half may be a sampling half (compile-time, so RAW's heavy one is inlined at one site only)
-    auto run_back = [&](auto with_sample) -> bool {
+    // KINDS: bit mask (1 << BK_*) of the halves that can be pending at the call site (compile-time: every site inlines only those,
+    // and RAW's heavy sampling half exists at one site only)
+    auto run_back = [&](auto KINDS) -> bool {
+        constexpr unsigned KM = decltype(KINDS)::value;
         if (bk == BK_NONE) return true;
         float *GP = smem + bi * LGRP;
         const float *PB = PARTOF(bpp);
@@ -403,7 +405,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
         else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (FAIL[0] != 0) return false;
         PH(8 * cur_ph + 1);
-        if (bk == BK_GATES) {                              // GRU cell pointwise (ATen gru_cell) -> publish h1 (role A) / h2 (role B)
+        if ((KM & (1u << BK_GATES)) && bk == BK_GATES) {   // GRU cell pointwise (ATen gru_cell) -> publish h1 (role A) / h2 (role B)
             const float gir = get_partial<3>(PB, 0, pu, pj) + bc0;
             const float giz = get_partial<3>(PB, 1, pu, pj) + bc1;
             const float gin = get_partial<3>(PB, 2, pu, pj) + bc2;
@@ -413,7 +415,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
             // ... and the residual sum of the owned units, so its consumers load ONE layer: x1 = xi + h1 (:212) for role B's rnn2
             // gates, x2 = x1 + h2 (:216) for role A's fc1
             publish4(xrs, (XLAYER(bi, roleA ? 5 : 6, bring) + 256 * J) * 4, tid, GP[O_XO + tid] + hn, pj < nb);
-        } else if (bk == BK_GH) {                          // gh(t+1) = W_hh . h(t) + b_hh of the owned (unit, segment)
+        } else if ((KM & (1u << BK_GH)) && bk == BK_GH) {  // gh(t+1) = W_hh . h(t) + b_hh of the owned (unit, segment)
             GP[tid] = get_partial<3>(PB, 0, pu, pj) + bh_r;
             GP[256 + tid] = get_partial<3>(PB, 1, pu, pj) + bh_z;
             GP[512 + tid] = get_partial<3>(PB, 2, pu, pj) + bh_n;
@@ -423,9 +425,10 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                 const int p1 = SP[tid] + bt + 1;
                 reinterpret_cast<int *>(GP + O_FR)[SEG * ((bt + 1) & 1) + tid] = (p1 < SP[SEG + tid]) ? (p1 / a.hop) : a.NF;
             }
-        } else if (bk == BK_RELU) {                        // fc1 / fc2 + relu -> publish y1 (role A) / y2 (role B)
+        } else if ((KM & (1u << BK_RELU)) && bk == BK_RELU) {   // fc1 / fc2 + relu -> publish y1 (role A) / y2 (role B)
             publish4(xrs, (XLAYER(bi, roleA ? 2 : 3, bring) + 256 * J) * 4, tid, fmaxf(get_partial<3>(PB, 0, pu, pj) + bc0, 0.f), pj < nb);
-        } else if constexpr (decltype(with_sample)::value) {   // fc3 logits -> sample x_t (both roles, redundantly)
+        } else if constexpr ((KM & (1u << BK_SAMPLE)) != 0u) {  // fc3 logits -> sample x_t
+            if (bk == BK_SAMPLE) {
             float *XS = GP + O_XS;
             const int b0 = GEO[2 * bi];                                   // first segment of the group in the call's segment table
             if constexpr (MOL) {
@@ -565,167 +568,189 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
             // inside that very stage (role A's last sampling stage of a step is slot 0's: one group in flight, or two with
             // alternating roles) the read follows at once; otherwise another stage's barrier lies in between.
             if (roleA && last_i == 0) __syncthreads();
+            }
         }
         bk = BK_NONE;
         PH(8 * cur_ph + 2);
         return true;
     };
 
-    for (; t < T1; ++t) {
-        const int ring = t % XRING;
-        const int tc = t - a.cI_t0;                     // row of the conditioning slab
-
-        // Phases of a step (ONE loop body, so the back half of the previous stage is inlined once):
-        //   role A: 0 = P1 rnn1 gates on xi (:208-210)      1 = P2 gh1(t+1) = W_hh1 . h1       2 = P3 fc1 + relu on x2 = (xi + h1) + h2 (:216-218)
-        //   role B: 0 = P2 rnn2 gates on x1 = xi + h1 (:212-214)   1 = P3 gh2(t+1) = W_hh2 . h2   2 = P4 fc2 + relu on y1 (:220-221)
-        //   both:   3 = P5 fc3 on y2 (:223); its back half samples x_t (:225-237)
+    // A STAGE of phase PH, compile-time: its loads, operands and tiles are straight-line code, and the pending back half can
+    // only be the phase's own kind (previous group) or the previous phase's (its last group).  Phases of a step:
+    //   role A: 0 = P1 rnn1 gates on xi (:208-210)      1 = P2 gh1(t+1) = W_hh1 . h1       2 = P3 fc1 + relu on x2 = (xi + h1) + h2 (:216-218)
+    //   role B: 0 = P2 rnn2 gates on x1 = xi + h1 (:212-214)   1 = P3 gh2(t+1) = W_hh2 . h2   2 = P4 fc2 + relu on y1 (:220-221)
+    //   both:   3 = P5 fc3 on y2 (:223); its back half samples x_t (:225-237)
+    constexpr unsigned KM_SAMPLE = MOL ? (1u << BK_SAMPLE) : 0u;           // RAW runs its sampling half at once: never pending
+    int ring = 0, tc = 0;
+    auto stage = [&](auto PHC, int i) -> bool {
+        constexpr int ph = decltype(PHC)::value;
+        constexpr unsigned KM = ph == 0 ? ((1u << BK_GATES) | KM_SAMPLE | (roleA ? 0u : (1u << BK_RELU)))
+                              : ph == 1 ? ((1u << BK_GH) | (1u << BK_GATES))
+                              : ph == 2 ? ((1u << BK_RELU) | (1u << BK_GH))
+                                        : (KM_SAMPLE | (1u << BK_RELU));
+        float *GP = smem + i * LGRP;
+        const int g = cl + ncl * i;
+        const int nb = GEO[2 * i + 1];
+        const float *cIg = a.cIf + ((size_t)tc * NGR + g) * XT;
+        float4 c[8];
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;           // conditioning / noise values the back half needs
+        cur_ph = ph;
+        if (PROF && tid == 0 && plast == 0) plast = __builtin_amdgcn_s_memtime();
+        // ---------------- front, part 1 --------------------------------------------------------------------------------
+        // The polled layer: normally its loads were issued ONE STAGE AGO (before the previous stage's MFMA tiles), so they
+        // have landed.  They are consumed FIRST, before anything else touches vector memory: vmcnt retires in order, so a
+        // wait for these loads placed after the back half's publish stores would also wait ~1 us for the stores'
+        // write-through acknowledgements (measured: profiles/r02h_*).  If a word is still the sentinel, the poll comes
+        // after the back half -- it may be waiting for this workgroup's own pending publication.
+        constexpr bool polled = !(roleA && ph == 0);
+        const int xl = stage_layer(ph);
+        float b[32];
+        bool ready = false;
+        if (polled) {
+            if (xahead) ready = try_finish(lane, nb, x, b);
+            else issue(xrs, XLAYER(i, xl, ring) * 4, w, lane, x);
+        }
+        // conditioning / noise values of the back half, the conditioning slab (role A, phase 0)
+        if constexpr (roleA) {
+            if (ph == 0) {
+                v0 = bi_r; v1 = bi_z; v2 = bi_n;
+                load_cI(cIg, w, lane, c);
+                if (alternate && (i & 1) && t > T0)      // x_{t-1} of a slot role B sampled (at the first step of a launch: from the state)
+                    xtw = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, XLAYER(i, 7, (t + 3) % XRING) * 4, 16 /* sc1 */);
+            }
+            else if (ph == 2) v0 = a.c3f[(size_t)reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj] * H + prow];
+        } else {
+            const int fr = reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj];   // conditioning frame of (segment pj, step t)
+            if (ph == 0) {
+                v0 = a.c2f[(size_t)fr * 3 * H + prow];                       // aux columns of rnn2 + b_ih2: per-frame table
+                v1 = a.c2f[(size_t)fr * 3 * H + H + prow];
+                v2 = a.c2f[(size_t)fr * 3 * H + 2 * H + prow];
+            } else if (ph == 2) v0 = a.c4f[(size_t)fr * H + prow];
+        }
+        if (MOL && ph == 3) {
+            // this step's sampling noise, pre-transformed (wrnn_noise_mol_kernel): thread (segment tid >> 4, mixture tid & 15)
+            const int b0 = GEO[2 * i];
+            const int su = tid >> 4, sm = tid & 15;
+            const float *nrow = a.noise_pre + (size_t)(t - a.noise_t0) * 11 * Nall;
+            const int suc = su < nb ? su : nb - 1;
+            v0 = nrow[(size_t)(b0 + suc) * 10 + (sm < 10 ? sm : 9)];
+            v1 = nrow[(size_t)10 * Nall + b0 + suc];
+        }
+        PH(8 * ph + 0);
+        // ---------------- the previous stage's back half -------------------------------------------------------------
+        if (!run_back(std::integral_constant<unsigned, KM>{})) return false;
+        // ---------------- front, part 2: operands -> MFMA tiles -> this wave's partial tiles -----------------------
+        if (polled) {
+            unsigned spins = 0;
+            if (!ready) {
+                ok = ok && finish(xrs, XLAYER(i, xl, ring) * 4, w, lane, nb, x, b, a.status, spins);
+                if (!ok && fcode == 0u) fcode = 0x400u | (roleA ? 0u : 8u) | (unsigned)ph;
+            }
+            if (PROF && tid == 0) { PROFL[8 * ph + 6] += 1; PROFL[8 * ph + 7] += !ready; }
+        }
+        PH(8 * ph + 3);
+        if (ph == last_ph && i == last_i) {
+            // ---- ring hygiene, once per step, at the point where it is free: the last layer this role polls in the step (A: y2,
+            //      B: y1) has just arrived, and it depends on every store this wave issued before polling for it.
+            //      (1) Drain: every store of this wave so far -- in particular the re-arm it issued one step ago for the
+            //      slot of step t+2 -- is acknowledged before anything of step t+1 is published (a consumer polls a word
+            //      for step t+2 only after consuming data that depends on this wave's step-(t+1) publications).  The
+            //      publishes themselves then need no drain and never stall on a stage's prefetched loads.
+            //      (2) Re-arm this wave's own words of slot (t+3) % 4: it holds step t-1, which every consumer is done
+            //      with (no workgroup publishes y2 of step t before it has finished step t-1).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ringn = (t + 3) % XRING;
 #pragma unroll 1
-        for (int ph = 0; ph < NPH; ++ph) {
-#pragma unroll 1
-            for (int i = 0; i < nact; ++i) {
-                if (ph == 3 && !samples(i)) continue;           // the other role samples this slot
-                float *GP = smem + i * LGRP;
-                const int g = cl + ncl * i;
-                const int nb = GEO[2 * i + 1];
-                const float *cIg = a.cIf + ((size_t)tc * NGR + g) * XT;
-                float4 c[8];
-                float v0 = 0.f, v1 = 0.f, v2 = 0.f;           // conditioning / noise values the back half needs
-                cur_ph = ph;
-                if (PROF && tid == 0 && plast == 0) plast = __builtin_amdgcn_s_memtime();
-                // ---------------- front, part 1 --------------------------------------------------------------------------------
-                // The polled layer: normally its loads were issued ONE STAGE AGO (before the previous stage's MFMA tiles), so they
-                // have landed.  They are consumed FIRST, before anything else touches vector memory: vmcnt retires in order, so a
-                // wait for these loads placed after the back half's publish stores would also wait ~1 us for the stores'
-                // write-through acknowledgements (measured: profiles/r02h_*).  If a word is still the sentinel, the poll comes
-                // after the back half -- it may be waiting for this workgroup's own pending publication.
-                const bool polled = !(roleA && ph == 0);
-                const int xl = stage_layer(ph);
-                float b[32];
-                bool ready = false;
-                if (polled) {
-                    if (xahead) ready = try_finish(lane, nb, x, b);
-                    else issue(xrs, XLAYER(i, xl, ring) * 4, w, lane, x);
-                }
-                // conditioning / noise values of the back half, the conditioning slab (role A, phase 0)
-                if constexpr (roleA) {
-                    if (ph == 0) {
-                        v0 = bi_r; v1 = bi_z; v2 = bi_n;
-                        load_cI(cIg, w, lane, c);
-                        if (alternate && (i & 1) && t > T0)      // x_{t-1} of a slot role B sampled (at the first step of a launch: from the state)
-                            xtw = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, XLAYER(i, 7, (t + 3) % XRING) * 4, 16 /* sc1 */);
-                    }
-                    else if (ph == 2) v0 = a.c3f[(size_t)reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj] * H + prow];
-                } else {
-                    const int fr = reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj];   // conditioning frame of (segment pj, step t)
-                    if (ph == 0) {
-                        v0 = a.c2f[(size_t)fr * 3 * H + prow];                       // aux columns of rnn2 + b_ih2: per-frame table
-                        v1 = a.c2f[(size_t)fr * 3 * H + H + prow];
-                        v2 = a.c2f[(size_t)fr * 3 * H + 2 * H + prow];
-                    } else if (ph == 2) v0 = a.c4f[(size_t)fr * H + prow];
-                }
-                if (MOL && ph == 3) {
-                    // this step's sampling noise, pre-transformed (wrnn_noise_mol_kernel): thread (segment tid >> 4, mixture tid & 15)
-                    const int b0 = GEO[2 * i];
-                    const int su = tid >> 4, sm = tid & 15;
-                    const float *nrow = a.noise_pre + (size_t)(t - a.noise_t0) * 11 * Nall;
-                    const int suc = su < nb ? su : nb - 1;
-                    v0 = nrow[(size_t)(b0 + suc) * 10 + (sm < 10 ? sm : 9)];
-                    v1 = nrow[(size_t)10 * Nall + b0 + suc];
-                }
-                PH(8 * ph + 0);
-                // ---------------- the previous stage's back half -------------------------------------------------------------
-                if (!run_back(std::integral_constant<bool, MOL>{})) goto bail;
-                // ---------------- front, part 2: operands -> MFMA tiles -> this wave's partial tiles -----------------------
-                if (polled) {
-                    unsigned spins = 0;
-                    if (!ready) {
-                        ok = ok && finish(xrs, XLAYER(i, xl, ring) * 4, w, lane, nb, x, b, a.status, spins);
-                        if (!ok && fcode == 0u) fcode = 0x400u | (roleA ? 0u : 8u) | (unsigned)ph;
-                    }
-                    if (PROF && tid == 0) { PROFL[8 * ph + 6] += 1; PROFL[8 * ph + 7] += !ready; }
-                }
-                PH(8 * ph + 3);
-                if (ph == last_ph && i == last_i) {
-                    // ---- ring hygiene, once per step, at the point where it is free: the last layer this role polls in the step (A: y2,
-                    //      B: y1) has just arrived, and it depends on every store this wave issued before polling for it.
-                    //      (1) Drain: every store of this wave so far -- in particular the re-arm it issued one step ago for the
-                    //      slot of step t+2 -- is acknowledged before anything of step t+1 is published (a consumer polls a word
-                    //      for step t+2 only after consuming data that depends on this wave's step-(t+1) publications).  The
-                    //      publishes themselves then need no drain and never stall on a stage's prefetched loads.
-                    //      (2) Re-arm this wave's own words of slot (t+3) % 4: it holds step t-1, which every consumer is done
-                    //      with (no workgroup publishes y2 of step t before it has finished step t-1).
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const int ringn = (t + 3) % XRING;
-#pragma unroll 1
-                    for (int i2 = 0; i2 < nact; ++i2)
-                    {
-                        rearm(xrs, (XLAYER(i2, 0, ringn) + 256 * J + 64 * w) * 4, lane, roleA ? 0 : 1, roleA ? 2 : 3, roleA ? 5 : 6,
-                              (!MOL && roleA) ? 4 : -1);
-                        if (!roleA && leader && alternate && (i2 & 1) && lane == 48) {   // the 4 x_t words this wave publishes (segments 4 w ..)
-                            const u32x4 q = {SENT, SENT, SENT, SENT};
-                            __builtin_amdgcn_raw_buffer_store_b128(q, xrs, 16 * w, XLAYER(i2, 7, ringn) * 4, 16 /* sc1 */);
-                        }
-                    }
-                }
-                {   // the NEXT stage's polled layer, one stage ahead: its 8 loads fly during this stage's MFMA tiles and the back half
-                    // that follows (a publication is normally several stages old by the time it is polled; if it is not there yet,
-                    // finish() polls as before).  Not across a step boundary (nothing of the next step is published yet).
-                    int nph = ph, ni = i;
-                    do {
-                        if (++ni >= nact) { ++nph; ni = 0; }
-                    } while (nph == 3 && nph < NPH && !samples(ni));
-                    xahead = lookahead && nph < NPH && !(roleA && nph == 0) && (MOL || nph != 3);
-                    if (xahead) issue(xrs, XLAYER(ni, stage_layer(nph), ring) * 4, w, lane, x);
-                }
-                if (roleA && ph == 0) {
-                    float xs = GP[O_XS + fi];
-                    if (alternate && (i & 1) && t > T0) {
-                        ok = ok && poll_xt(i, (t + 3) % XRING, nb, xtw);
-                        if (!ok && fcode == 0u) fcode = 0x400u | 0x20u;
-                        xs = (fi < nb) ? __uint_as_float(xtw) : 0.f;
-                        GP[O_XS + fi] = xs;                      // (every wave writes the same 16 values) kept for the launch's saved state
-                    }
-                    make_xi(c, WI0, xs, w, lane, b);             // xi(t) (:208-209)
-                }
-                if (ph == 0 && w == (J >> 3)) {
-                    // the owned units' slice of this GRU's input (role A: xi, role B: x1) -> LDS in publish order, for the residual
-                    // sum the gates' back half publishes: unit block J = k-block r = J & 7 of wave J >> 3
-#pragma unroll
-                    for (int r = 0; r < 8; ++r)
-                        if (r == (J & 7)) *reinterpret_cast<float4 *>(GP + O_XO + 4 * lane) = make_float4(b[4 * r], b[4 * r + 1], b[4 * r + 2], b[4 * r + 3]);
-                }
-                PH(8 * ph + 4);
-                float *PW = PARTOF(pp);
-                if (ph == 0 || (ph == 1)) {                                          // three gate tiles of W_ih (ph 0) / W_hh (ph 1)
-                    f32x4 o0, o1, o2;
-                    if (ph == 0) mfma3(A_ih[0], A_ih[1], A_ih[2], b, o0, o1, o2);
-                    else mfma3(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
-                    put_partial<3>(PW, w, 0, lane, o0);
-                    put_partial<3>(PW, w, 1, lane, o1);
-                    put_partial<3>(PW, w, 2, lane, o2);
-                    bk = ph == 0 ? BK_GATES : BK_GH;
-                } else if (ph == 2) {
-                    put_partial<3>(PW, w, 0, lane, mfma1(A_fc, b));
-                    bk = BK_RELU;
-                } else {
-                    put_partial<3>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
-                    if constexpr (MOL) put_partial<3>(PW, w, 1, lane, mfma1_lds(F3 + XT + frag_off(w, 0, lane), b));
-                    bk = BK_SAMPLE;
-                }
-                if (roleA && ph == 2 && t + 1 < T1) {   // pull the next step's conditioning block of this group (32 KB) into this XCD's L2
-                    asm volatile("" ::"v"(touch));
-                    touch = a.cIf[((size_t)(tc + 1) * NGR + g) * XT + 32 * tid];
-                }
-                PH(8 * ph + 5);
-                bi = i; bpp = pp; bt = t; bc0 = v0; bc1 = v1; bc2 = v2;
-                pp ^= 1;
-                if constexpr (!MOL) {
-                    if (bk == BK_SAMPLE) { if (!run_back(std::true_type{})) goto bail; }   // RAW: the (heavy) sampling half is not deferred
+            for (int i2 = 0; i2 < nact; ++i2)
+            {
+                rearm(xrs, (XLAYER(i2, 0, ringn) + 256 * J + 64 * w) * 4, lane, roleA ? 0 : 1, roleA ? 2 : 3, roleA ? 5 : 6,
+                      (!MOL && roleA) ? 4 : -1);
+                if (!roleA && leader && alternate && (i2 & 1) && lane == 48) {   // the 4 x_t words this wave publishes (segments 4 w ..)
+                    const u32x4 q = {SENT, SENT, SENT, SENT};
+                    __builtin_amdgcn_raw_buffer_store_b128(q, xrs, 16 * w, XLAYER(i2, 7, ringn) * 4, 16 /* sc1 */);
                 }
             }
         }
+        {   // the NEXT stage's polled layer, one stage ahead: its 8 loads fly during this stage's MFMA tiles and the back half
+            // that follows (a publication is normally several stages old by the time it is polled; if it is not there yet,
+            // finish() polls as before).  Not across a step boundary (nothing of the next step is published yet).
+            int nph = ph, ni = i;
+            do {
+                if (++ni >= nact) { ++nph; ni = 0; }
+            } while (nph == 3 && nph < NPH && !samples(ni));
+            xahead = lookahead && nph < NPH && !(roleA && nph == 0) && (MOL || nph != 3);
+            if (xahead) issue(xrs, XLAYER(ni, stage_layer(nph), ring) * 4, w, lane, x);
+        }
+        if (roleA && ph == 0) {
+            float xs = GP[O_XS + fi];
+            if (alternate && (i & 1) && t > T0) {
+                ok = ok && poll_xt(i, (t + 3) % XRING, nb, xtw);
+                if (!ok && fcode == 0u) fcode = 0x400u | 0x20u;
+                xs = (fi < nb) ? __uint_as_float(xtw) : 0.f;
+                GP[O_XS + fi] = xs;                      // (every wave writes the same 16 values) kept for the launch's saved state
+            }
+            make_xi(c, WI0, xs, w, lane, b);             // xi(t) (:208-209)
+        }
+        if (ph == 0 && w == (J >> 3)) {
+            // the owned units' slice of this GRU's input (role A: xi, role B: x1) -> LDS in publish order, for the residual
+            // sum the gates' back half publishes: unit block J = k-block r = J & 7 of wave J >> 3
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r == (J & 7)) *reinterpret_cast<float4 *>(GP + O_XO + 4 * lane) = make_float4(b[4 * r], b[4 * r + 1], b[4 * r + 2], b[4 * r + 3]);
+        }
+        PH(8 * ph + 4);
+        float *PW = PARTOF(pp);
+        if (ph == 0 || (ph == 1)) {                                          // three gate tiles of W_ih (ph 0) / W_hh (ph 1)
+            f32x4 o0, o1, o2;
+            if (ph == 0) mfma3(A_ih[0], A_ih[1], A_ih[2], b, o0, o1, o2);
+            else mfma3(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
+            put_partial<3>(PW, w, 0, lane, o0);
+            put_partial<3>(PW, w, 1, lane, o1);
+            put_partial<3>(PW, w, 2, lane, o2);
+            bk = ph == 0 ? BK_GATES : BK_GH;
+        } else if (ph == 2) {
+            put_partial<3>(PW, w, 0, lane, mfma1(A_fc, b));
+            bk = BK_RELU;
+        } else {
+            put_partial<3>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
+            if constexpr (MOL) put_partial<3>(PW, w, 1, lane, mfma1_lds(F3 + XT + frag_off(w, 0, lane), b));
+            bk = BK_SAMPLE;
+        }
+        if (roleA && ph == 2 && t + 1 < T1) {   // pull the next step's conditioning block of this group (32 KB) into this XCD's L2
+            asm volatile("" ::"v"(touch));
+            touch = a.cIf[((size_t)(tc + 1) * NGR + g) * XT + 32 * tid];
+        }
+        PH(8 * ph + 5);
+        bi = i; bpp = pp; bt = t; bc0 = v0; bc1 = v1; bc2 = v2;
+        pp ^= 1;
+        if constexpr (!MOL && ph == 3) {                                     // RAW: the (heavy) sampling half is not deferred
+            if (!run_back(std::integral_constant<unsigned, (1u << BK_SAMPLE)>{})) return false;
+        }
+        return true;
+    };
+
+    for (; t < T1; ++t) {
+        ring = t % XRING;
+        tc = t - a.cI_t0;                               // row of the conditioning slab
+#pragma unroll 1
+        for (int i = 0; i < nact; ++i)
+            if (!stage(std::integral_constant<int, 0>{}, i)) goto bail;
+#pragma unroll 1
+        for (int i = 0; i < nact; ++i)
+            if (!stage(std::integral_constant<int, 1>{}, i)) goto bail;
+#pragma unroll 1
+        for (int i = 0; i < nact; ++i)
+            if (!stage(std::integral_constant<int, 2>{}, i)) goto bail;
+        if constexpr (NPH == 4) {
+#pragma unroll 1
+            for (int i = 0; i < nact; ++i)
+                if (samples(i)) {                       // (else the other role samples this slot)
+                    if (!stage(std::integral_constant<int, 3>{}, i)) goto bail;
+                }
+        }
     }
-    if (!run_back(std::integral_constant<bool, MOL>{})) goto bail;      // the last stage's back half
+    // the last stage's back half
+    if (!run_back(std::integral_constant<unsigned, (roleA ? KM_SAMPLE : (KM_SAMPLE | (1u << BK_RELU)))>{})) goto bail;
     if (roleA && alternate && T1 > T0) {                                // x_{T1-1} of the slots role B sampled -> this launch's saved state
 #pragma unroll 1
         for (int i = 1; i < nact; i += 2) {
