@@ -71,13 +71,17 @@ __host__ __device__ inline LoopLds loop_lds(int mode, int G)
     return l;
 }
 
+// workgroup barrier that hands over LDS only: waits for this wave's LDS traffic (lgkmcnt), not -- as __syncthreads() does through
+// its fences -- for every global load and store it has in flight (vmcnt)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // fragment-order offset (floats) of (wave w, k-block r, lane): 4 consecutive k of one segment
 __device__ __forceinline__ int frag_off(int w, int r, int lane) { return ((w * 8 + r) * 64 + lane) * 4; }
 
 // This wave's 8 B fragments of one exchanged layer (byte offset soff in the exchange buffer), as two halves so a stage can put
 // work between them: issue() fires the 8 buffer_load_dwordx4 (sc1); finish() checks that no word is still the sentinel and,
-// only if one is, falls into the polling loop (re-load, bounded spin).  Lanes of segments >= nb are not waited for and
-// read as zero.  Wave-uniform result.
+// only if one is, falls into the polling loop (re-load, bounded spin).  Lanes of segments >= nb are not waited for (their
+// columns are garbage, used by nothing).  Wave-uniform result.
 __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, int soff, int w, int lane, u32x4 (&x)[8])
 {
     const int voff = frag_off(w, 0, lane) * 4;
@@ -92,13 +96,14 @@ __device__ __forceinline__ bool try_finish(int lane, int nb, const u32x4 (&x)[8]
 #pragma unroll
     for (int r = 0; r < 8; ++r) m = max(max(m, max(x[r].x, x[r].y)), max(x[r].z, x[r].w));
     if (!__all(m != SENT || !live)) return false;
-    const unsigned keep = (nb >= SEG || live) ? 0xFFFFFFFFu : 0u;
+    // columns of absent segments (ragged last group) keep whatever the buffer holds -- the sentinel, a NaN: an MFMA column, the
+    // partial sums and the pointwise math are all per segment, nothing of an absent segment is ever published or written out
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        b[4 * r + 0] = __uint_as_float(x[r].x & keep);
-        b[4 * r + 1] = __uint_as_float(x[r].y & keep);
-        b[4 * r + 2] = __uint_as_float(x[r].z & keep);
-        b[4 * r + 3] = __uint_as_float(x[r].w & keep);
+        b[4 * r + 0] = __uint_as_float(x[r].x);
+        b[4 * r + 1] = __uint_as_float(x[r].y);
+        b[4 * r + 2] = __uint_as_float(x[r].z);
+        b[4 * r + 3] = __uint_as_float(x[r].w);
     }
     return true;
 }
@@ -123,13 +128,12 @@ __device__ __forceinline__ bool finish(__amdgpu_buffer_rsrc_t rs, int soff, int 
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + r * 1024, soff, 16 /* sc1 */);
     }
-    const unsigned keep = (nb >= SEG || live) ? 0xFFFFFFFFu : 0u;       // ragged last group only: lanes of absent segments read as zero
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        b[4 * r + 0] = __uint_as_float(x[r].x & keep);
-        b[4 * r + 1] = __uint_as_float(x[r].y & keep);
-        b[4 * r + 2] = __uint_as_float(x[r].z & keep);
-        b[4 * r + 3] = __uint_as_float(x[r].w & keep);
+        b[4 * r + 0] = __uint_as_float(x[r].x);
+        b[4 * r + 1] = __uint_as_float(x[r].y);
+        b[4 * r + 2] = __uint_as_float(x[r].z);
+        b[4 * r + 3] = __uint_as_float(x[r].w);
     }
     return true;
 }
@@ -402,7 +406,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
         // traffic alone (lgkmcnt): __syncthreads() would also drain vmcnt -- i.e. wait for the very loads this stage has just
         // put in flight -- through its workgroup-scope fences.
         if (full_fence) __syncthreads();
-        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else lds_barrier();
         if (FAIL[0] != 0) return false;
         PH(8 * cur_ph + 1);
         if ((KM & (1u << BK_GATES)) && bk == BK_GATES) {   // GRU cell pointwise (ATen gru_cell) -> publish h1 (role A) / h2 (role B)
@@ -416,9 +420,12 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
             // gates, x2 = x1 + h2 (:216) for role A's fc1
             publish4(xrs, (XLAYER(bi, roleA ? 5 : 6, bring) + 256 * J) * 4, tid, GP[O_XO + tid] + hn, pj < nb);
         } else if ((KM & (1u << BK_GH)) && bk == BK_GH) {  // gh(t+1) = W_hh . h(t) + b_hh of the owned (unit, segment)
-            GP[tid] = get_partial<3>(PB, 0, pu, pj) + bh_r;
-            GP[256 + tid] = get_partial<3>(PB, 1, pu, pj) + bh_z;
-            GP[512 + tid] = get_partial<3>(PB, 2, pu, pj) + bh_n;
+            // (all twelve partials are read before the first store: the compiler cannot tell GP from PB and would otherwise
+            // serialise read -> wait -> store per gate)
+            const float g0 = get_partial<3>(PB, 0, pu, pj), g1 = get_partial<3>(PB, 1, pu, pj), g2 = get_partial<3>(PB, 2, pu, pj);
+            GP[tid] = g0 + bh_r;
+            GP[256 + tid] = g1 + bh_z;
+            GP[512 + tid] = g2 + bh_n;
             if (tid < SEG) {   // conditioning frame of every segment at the NEXT step (Stretch2d: constant over a hop; the fold's zero
                                // pad -> NF), into the other half of FR: it is first read two stages' barriers from here
                 const int *SP = reinterpret_cast<const int *>(GP + O_SP);
@@ -435,15 +442,15 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                 {   // 30 logit rows x 16 segments: thread (row tid >> 4 and 16 + row, segment tid & 15)
                     const int row = tid >> 4, sj = tid & 15;
                     const float lg = get_partial<3>(PB, 0, row, sj) + b3a;
+                    const float lg2 = get_partial<3>(PB, 1, row, sj) + b3b;      // (rows 30, 31 of the second tile: zero weights, unused)
                     LOG[sj * LOGS + row] = lg;
                     if (a.dbg_logits && leader && sj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + sj) * C + row] = lg;
                     if (row < 14) {
-                        const float lg2 = get_partial<3>(PB, 1, row, sj) + b3b;
                         LOG[sj * LOGS + 16 + row] = lg2;
                         if (a.dbg_logits && leader && sj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + sj) * C + 16 + row] = lg2;
                     }
                 }
-                __syncthreads();
+                lds_barrier();
                 {   // utils/distribution.py:102-121: 16-lane row = one segment (su), lane sm = mixture; bc0 / bc1 = this thread's noise
                     const int su = tid >> 4, sm = tid & 15;
                     float best = (sm < 10) ? mol_gumbel_pre(LOG[su * LOGS + sm], bc0) : -INFINITY;
@@ -482,7 +489,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                     for (int r = 0; r < 8; ++r) *reinterpret_cast<float4 *>(lp + 16 * r) = make_float4(b[4 * r], b[4 * r + 1], b[4 * r + 2], b[4 * r + 3]);
                 }
                 if (!ok) FAIL[0] = 1;
-                __syncthreads();
+                lds_barrier();
                 if (FAIL[0] != 0) return false;
                 // fatchord_version.py:232-237: softmax -> Categorical (renormalise) -> argmax(p / q).  One wave per 4 segments, the
                 // four handled in lock step (straight-line code: four independent butterfly chains in flight instead of one); per
@@ -562,12 +569,12 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                         }
                     }
                 }
-                __syncthreads();                         // LGT is read by every wave before the next group overwrites it
+                lds_barrier();                         // LGT is read by every wave before the next group overwrites it
             }
             // x_t is read by EVERY wave in this slot's first stage of the next step.  When this sampling half is the one that runs
             // inside that very stage (role A's last sampling stage of a step is slot 0's: one group in flight, or two with
             // alternating roles) the read follows at once; otherwise another stage's barrier lies in between.
-            if (roleA && last_i == 0) __syncthreads();
+            if (roleA && last_i == 0) lds_barrier();
             }
         }
         bk = BK_NONE;
