@@ -26,8 +26,13 @@ _KEYS = dict(I_w='I.weight', I_b='I.bias', w_ih1='rnn1.weight_ih_l0', w_hh1='rnn
 
 
 def loop(sd, mode, mels, aux, noise, want_logits=False, nthreads=0):
-    """C twin of `wavernn_oracle.loop`.  Returns out (B,T) [and logits (T,B,C)]."""
+    """C twin of `wavernn_oracle.loop`.  Returns out (B,T) [and logits (T,B,C)].  nthreads = 0: min(64, host threads) -- the
+    loop synchronises its threads ~10 times per step, so on a 256-thread host all threads are several times SLOWER than 64
+    (bench.py's cpu_baseline leg measures 8 / 16 / 32 / 64); the result does not depend on the thread count (rows of a layer
+    are split over threads, each row is summed by one thread in a fixed order)."""
     lib = ctypes.CDLL(build())
+    if nthreads <= 0:
+        nthreads = min(64, os.cpu_count() or 1)
     keep = {k: np.ascontiguousarray(sd[v], dtype=np.float32) for k, v in _KEYS.items()}
     w = _W()
     w.rnn_dims = keep['w_hh1'].shape[1]
