@@ -26,13 +26,13 @@ _KEYS = dict(I_w='I.weight', I_b='I.bias', w_ih1='rnn1.weight_ih_l0', w_hh1='rnn
 
 
 def loop(sd, mode, mels, aux, noise, want_logits=False, nthreads=0):
-    """C twin of `wavernn_oracle.loop`.  Returns out (B,T) [and logits (T,B,C)].  nthreads = 0: min(64, host threads) -- the
+    """C twin of `wavernn_oracle.loop`.  Returns out (B,T) [and logits (T,B,C)].  nthreads = 0: the OpenMP default, capped at 64 threads -- the
     loop synchronises its threads ~10 times per step, so on a 256-thread host all threads are several times SLOWER than 64
     (bench.py's cpu_baseline leg measures 8 / 16 / 32 / 64); the result does not depend on the thread count (rows of a layer
     are split over threads, each row is summed by one thread in a fixed order)."""
     lib = ctypes.CDLL(build())
-    if nthreads <= 0:
-        nthreads = min(64, os.cpu_count() or 1)
+    if nthreads <= 0 and len(os.sched_getaffinity(0)) > 64:
+        nthreads = 64            # (small hosts keep the OpenMP default, incl. whatever torch.set_num_threads / OMP_NUM_THREADS set)
     keep = {k: np.ascontiguousarray(sd[v], dtype=np.float32) for k, v in _KEYS.items()}
     w = _W()
     w.rnn_dims = keep['w_hh1'].shape[1]
