@@ -21,7 +21,30 @@ def gpu():
     return torch.device('cuda', 0)
 
 
+_MEMO = {}
+
+
 def _inputs(cfg):
+    """Seeded inputs of a case (memoised per configuration: the parametrised variants share them)."""
+    key = ('in',) + tuple(sorted(cfg.items()))
+    if key not in _MEMO:
+        _MEMO[key] = _inputs_uncached(cfg)
+    return _MEMO[key]
+
+
+def _oracle_free_run(cfg):
+    """The C oracle's free-running [B,T] output for a case (seconds of CPU per call, identical for every kernel variant of the
+    case: computed once per test session)."""
+    from oracle import c_oracle as C, wavernn_oracle as O
+    key = ('ref',) + tuple(sorted(cfg.items()))
+    if key not in _MEMO:
+        sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
+        mels_f, aux_f, _ = O.conditioning(sd, mel, cfg['batched'], cfg['target'], cfg['overlap'])
+        _MEMO[key] = C.loop(sd, cfg['mode'], mels_f, aux_f, noise)
+    return _MEMO[key]
+
+
+def _inputs_uncached(cfg):
     from oracle import wavernn_oracle as O
     from wavernn_amd.synthetic import random_state_dict, random_mel
     sd = random_state_dict(cfg['wseed'], mode=cfg['mode'])
@@ -148,8 +171,7 @@ def test_loop_matches_reference_golden(gpu, name, variant):
     assert eng.last_loop_kernel() == KERNEL_NAME[opts['algo']]
     if opts.get('depth'):
         assert eng.last_loop_split()[2] == opts['depth']
-    mels_f, aux_f, _ = __import__('oracle.wavernn_oracle', fromlist=['x']).conditioning(sd, mel, cfg['batched'], cfg['target'], cfg['overlap'])
-    ref = C.loop(sd, cfg['mode'], mels_f, aux_f, noise)
+    ref = _oracle_free_run(cfg)
     if cfg['mode'] == 'RAW':
         bad = np.argwhere(out != g['raw'])
         assert bad.size == 0, f'first divergence at (b,t)={bad[0]} of {out.shape}'
@@ -290,8 +312,7 @@ def test_many_segments_all_clusters(gpu, mode, variant):
     opts = VARIANTS[variant]
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     assert (B, T) == (46, 660)
-    mels_f, aux_f, _ = O.conditioning(sd, mel, True, cfg['target'], cfg['overlap'])
-    ref = C.loop(sd, mode, mels_f, aux_f, noise)
+    ref = _oracle_free_run(cfg)
     eng = LoopEngine(sd, mode, device=gpu)
     out = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
                   torch.from_numpy(flat).to(gpu), 275, **opts).cpu().numpy()
@@ -312,8 +333,7 @@ def test_more_segments_than_slots(gpu, variant):
     opts = VARIANTS[variant]
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     assert (B, T) == (114, 264)
-    mels_f, aux_f, _ = O.conditioning(sd, mel, True, cfg['target'], cfg['overlap'])
-    ref = C.loop(sd, 'MOL', mels_f, aux_f, noise)
+    ref = _oracle_free_run(cfg)
     eng = LoopEngine(sd, 'MOL', device=gpu)
     out = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
                   torch.from_numpy(flat).to(gpu), 275, **opts).cpu().numpy()
