@@ -13,8 +13,10 @@ drawn on the device (Philox), as the reference does when it runs on a GPU; `--pa
 MT19937 stream of the parity tests instead (adds ~25 M host RNG draws per pass).
 
     python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          # WORLD_SIZE unset: spawns its own N ranks (one per GPU, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # ... or is launched as one rank of N (RANK / WORLD_SIZE in the env)
+    python bench.py --gpus N --corpus config4              # BASELINE config 4: the fixed 64-utterance corpus (942 segments), STRONG scaling
 
 value = useful audio samples per second over all ranks = N * K * sum(wave_len) / max-over-ranks(time).
 """
@@ -81,6 +83,37 @@ def source_sha16():
     return h.hexdigest()[:16]
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
+    127.0.0.1), relay rank 0's stdout so that its JSON line is the LAST line this process prints, propagate failures."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f'bench.py: ranks failed (rank, exit code): {bad}')
+
+
+def load_factory(spec):
+    """'package.module:function' -> the function (the --dry-host loop stand-in is named by the caller, i.e. by a test)."""
+    import importlib
+    mod, _, fn = spec.partition(':')
+    return getattr(importlib.import_module(mod), fn)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -97,30 +130,53 @@ def main():
     ap.add_argument('--parity-noise', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--corpus', default='batch', choices=['batch', 'config4'],
+                    help="batch: --utterances x --frames per GPU (weak scaling).  config4: BASELINE config 4's fixed corpus -- 64 "
+                         "utterances of RandomState(2024).randint(300, 901) frames = 942 folded segments, sharded over the ranks "
+                         "(strong scaling)")
+    ap.add_argument('--corpus-limit', type=int, default=64, help=argparse.SUPPRESS)     # tests: only the first K utterances of config 4
+    ap.add_argument('--target', type=int, default=11000, help=argparse.SUPPRESS)
+    ap.add_argument('--overlap', type=int, default=550, help=argparse.SUPPRESS)
+    ap.add_argument('--dry-host', default=None, metavar='MODULE:FACTORY',
+                    help='LAUNCH-PATH TEST, not a measurement: run the host side (rank spawn, gloo group, sharding, all-gather, '
+                         'unfold, the JSON line) on CPU with the loop replaced by FACTORY(state_dict, mode) -> loop_fn; the line '
+                         'is marked "dry_host": true and carries no roofline')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert world == args.gpus, f'WORLD_SIZE={world} but --gpus {args.gpus}'
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a HIP device: the product path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    if world != args.gpus and rank == 0:      # the launcher's world size is what runs; --gpus is only what was asked for
+        print(f'bench.py: WORLD_SIZE={world} overrides --gpus {args.gpus}', file=sys.stderr)
+    dry = args.dry_host is not None
     import torch.distributed as dist
     group = None
+    if dry:
+        dev = torch.device('cpu')
+        torch.set_num_threads(2)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs a HIP device: the product path has no CPU fallback')
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
     if world > 1 or args.force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29513')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if dry:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
         group = dist.group.WORLD
+    world_seen = dist.get_world_size(group) if group is not None else 1      # what the process group actually spans
 
     from wavernn_amd.model import WaveRNN
     from wavernn_amd.synthetic import random_state_dict, random_mel, SHIPPED
     from wavernn_amd.batch import generate_corpus, plan_utterances
     from wavernn_amd import _lib
 
-    mode, target, overlap, hop = args.mode, 11000, 550, 275
+    mode, target, overlap, hop = args.mode, args.target, args.overlap, 275
     sd = random_state_dict(0, mode=mode)
     if args.prune > 0:
         from wavernn_amd.prune import block_prune_state_dict
@@ -130,26 +186,38 @@ def main():
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
     model.loop_algo = args.algo
-    # the whole job's batch: `utterances` per rank (weak scaling: fixed work per GPU); rank r's share is the r-th block
-    n_utt = args.utterances * world
-    mels = [torch.from_numpy(random_mel(1234 + u, args.frames)).unsqueeze(0).to(dev) for u in range(n_utt)]
-    seeds = [77 + u for u in range(n_utt)]
-    plan = plan_utterances([args.frames * hop] * n_utt, target, overlap)
-    wave_total = n_utt * (args.frames - 1) * hop
-    eng = model._loop_engine()
+    if args.corpus == 'config4':
+        # BASELINE config 4: the corpus is FIXED, the ranks share it -> strong scaling
+        frames = [int(n) for n in np.random.RandomState(2024).randint(300, 901, 64)][:args.corpus_limit]
+        mel_seeds, seeds = [1000 + u for u in range(len(frames))], [4000 + u for u in range(len(frames))]
+    else:
+        # the whole job's batch: `utterances` per rank (weak scaling: fixed work per GPU); rank r's share is the r-th block
+        frames = [args.frames] * (args.utterances * world)
+        mel_seeds, seeds = [1234 + u for u in range(len(frames))], [77 + u for u in range(len(frames))]
+    n_utt = len(frames)
+    mels = [torch.from_numpy(random_mel(ms, n)).unsqueeze(0).to(dev) for ms, n in zip(mel_seeds, frames)]
+    plan = plan_utterances([n * hop for n in frames], target, overlap)
+    wave_total = sum((n - 1) * hop for n in frames)
     noise_source = 'cpu' if args.parity_noise else 'device'
+    if dry:
+        eng, loop_fn = None, load_factory(args.dry_host)(sd, mode)
+    else:
+        eng, loop_fn = model._loop_engine(), None
 
     def one_pass():
         outs = generate_corpus(model, mels, target, overlap, True, seeds, group=group, noise_source=noise_source,
-                               finish='own', check=False)
-        eng.status()
+                               finish='own', check=False, loop_fn=loop_fn)
+        if eng is not None:
+            eng.status()
         return outs
 
     def fence():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if group is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         one_pass()
@@ -158,13 +226,33 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_pass()
-        loop_ms.append(eng.last_loop_ms())
+        if eng is not None:
+            loop_ms.append(eng.last_loop_ms())
     fence()
     dt = time.perf_counter() - t0
     if group is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    from wavernn_amd.batch import shard_bounds
+    lo0, hi0 = shard_bounds(plan.n_segments, world)[0]
+    par = (f'{world_seen} rank(s) in the process group ({"gloo, DRY RUN on the host" if dry else "nccl = RCCL" if group is not None else "no group"}): '
+           f'1 process per GPU, contiguous block of the segment table, ONE all-gather of the finished audio')
+    if dry:
+        if rank == 0:
+            print(json.dumps({
+                'metric': 'audio samples/sec (real-time factor @22.05 kHz), MoL WaveRNN batched generate', 'value': None,
+                'unit': 'audio samples/s', 'n_gpus': world_seen, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+                'scaling': 'strong' if args.corpus == 'config4' else 'weak', 'vs_baseline': None, 'dtype': 'f32',
+                'data': 'synthetic', 'dry_host': True,
+                'config': {'workload': f'DRY RUN of the launch path on the host, NOT a measurement: {n_utt} utterances -> '
+                                       f'{plan.n_segments} segments x T={plan.T}, loop stand-in {args.dry_host}',
+                           'segments_rank0': hi0 - lo0, 'host_samples_per_s': round(args.steps * wave_total / dt, 1),
+                           'parallelism': par}}), flush=True)
+        if group is not None:
+            dist.destroy_process_group()
+        return
     info = eng.last_run_info()
 
     def single_utterance(n_frames):
@@ -198,7 +286,7 @@ def main():
 
     if rank == 0:
         T = plan.T
-        n_local = plan.n_segments // world                   # segments this GPU's launch advances
+        n_local = hi0 - lo0                                  # segments this GPU's launches advance (rank 0's block)
         value = args.steps * wave_total / dt
         W = eng.weight_bytes
         kms = float(np.mean(loop_ms))
@@ -224,13 +312,14 @@ def main():
         res = {
             'metric': 'audio samples/sec (real-time factor @22.05 kHz), MoL WaveRNN batched generate' if mode == 'MOL' else
                       "audio samples/sec (real-time factor @22.05 kHz), 9-bit mu-law ('bits') WaveRNN batched generate",
-            'value': round(value, 1), 'unit': 'audio samples/s', 'n_gpus': world, 'steps': args.steps,
+            'value': round(value, 1), 'unit': 'audio samples/s', 'n_gpus': world_seen, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'strong' if args.corpus == 'config4' else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'realtime_factor': round(value / SAMPLE_RATE, 2),
             'config': {'workload': (f'BASELINE config 5 (GRU matrices block-pruned to {args.prune:.0%} zeros, 16x1 blocks) = ' if args.prune > 0 else '') +
                                    f'BASELINE config 2 ({"MoL" if mode == "MOL" else "9-bit mu-law RAW"} WaveRNN, rnn/fc 512, random-init weights, batched fold target={target} '
-                                   f'overlap={overlap}) on a batch of {args.utterances} random {args.frames}-frame mels per GPU '
+                                   f'overlap={overlap}) on ' + (f"BASELINE config 4's fixed corpus of {n_utt} random mels of 300-900 frames ({plan.n_segments} segments) shared by {world} GPU(s) "
+                                                                 if args.corpus == 'config4' else f'a batch of {args.utterances} random {args.frames}-frame mels per GPU ') +
                                    f'-> {n_local} folded segments x T={T} steps per GPU ({info["launches"]} loop-kernel launches per pass: '
                                    f'{info["rounds"]} round(s) x conditioning slabs of {info["slab_steps"]} steps), '
                                    f'{wave_total // world} output samples per GPU per step',
@@ -239,7 +328,7 @@ def main():
                        'slab_steps': info['slab_steps'], 'units_per_workgroup': u_per_wg, 'clusters': ncl, 'groups_in_flight_per_cluster': depth,
                        'segment_steps_per_s': round(plan.n_segments * T * args.steps / dt, 1),
                        'noise': 'host MT19937 stream (parity mode)' if args.parity_noise else 'device Philox (as the reference on a GPU)',
-                       'parallelism': f'{world} x (1 process per GPU, contiguous block of the segment table, RCCL all-gather of audio)'},
+                       'parallelism': par},
         }
         # Which roofline bounds the loop: arithmetic intensity = 2n FLOP per 4 weight bytes = n/2 FLOP/B for n
         # segments per weight pass; the f32 ridge of gfx950 is 157.3 TF / 6.3 TB/s = 25 FLOP/B, i.e. weight-bandwidth-bound
@@ -261,7 +350,7 @@ def main():
             res['roofline'], res['roofline_hbm_equivalent'] = mfma, hbm
         else:
             res['roofline'], res['roofline_mfma'] = hbm, mfma
-        if not args.no_single and world == 1 and args.prune == 0:
+        if not args.no_single and world == 1 and args.prune == 0 and args.corpus == 'batch':
             try:
                 res['config']['single_utterance'] = [single_utterance(481), single_utterance(1001)]
             except Exception as e:

@@ -46,3 +46,12 @@ def oracle_loop_fn(sd, mode):
             nzo = np.ascontiguousarray(nz.reshape(T, n, -1))
         return torch.from_numpy(C.loop(sd, mode, mels_f, aux_f, nzo))
     return fn
+
+
+def zero_loop_fn(sd, mode):
+    """Loop stand-in that generates silence -- TEST ONLY: for launch-path tests whose workload is too large for the oracle."""
+    import torch
+
+    def fn(mels_up, aux, seg_pos, seg_lim, T, noise, hop):
+        return torch.zeros(len(seg_pos), T)
+    return fn

@@ -287,3 +287,30 @@ def test_wav_front_end_properties(tmp_path):
     assert np.array_equal(dsp.load_wav(tmp_path / 'a.wav', sr), x)
     with pytest.raises(ValueError):
         dsp.load_wav(tmp_path / 'a.wav', 16000)
+
+
+def test_bench_self_launches_two_ranks_dry_host(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (how the driver invokes `--gpus 1`): bench.py spawns its own two
+    ranks, they rendezvous on 127.0.0.1, shard the segment table, all-gather and unfold; rank 0's JSON line is the last line
+    of stdout and reports the world size the process group really had.  `--dry-host` swaps the HIP loop for the test's CPU
+    stand-in (gloo instead of RCCL): what is exercised is the launch path, no number is claimed (`value` is null)."""
+    import json, subprocess, sys
+    from helpers import ROOT
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, 'tests'), ROOT, os.environ.get('PYTHONPATH', '')]))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--utterances', '2',
+           '--frames', '30', '--target', '550', '--overlap', '55', '--dry-host', 'helpers:oracle_loop_fn']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['dry_host'] is True and line['value'] is None and line['n_gpus'] == 2 and line['scaling'] == 'weak'
+    assert line['config']['parallelism'].startswith('2 rank(s)')
+    # 4 utterances of 30 frames, target 550 / overlap 55 -> 14 segments each, rank 0 owns the first half
+    assert line['config']['segments_rank0'] * 2 == 4 * 14
+    # the fixed corpus of BASELINE config 4 is strong scaling; one rank of a launcher-provided world (WORLD_SIZE in the env) runs as is
+    env1 = dict(env, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1')
+    r = subprocess.run(cmd[:2] + ['--gpus', '1', '--steps', '1', '--warmup', '0', '--corpus', 'config4', '--corpus-limit', '3', '--dry-host', 'helpers:zero_loop_fn'], env=env1, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['scaling'] == 'strong' and line['n_gpus'] == 1 and '3 utterances' in line['config']['workload']
