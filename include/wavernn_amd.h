@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define WRNN_ABI_VERSION 3
+#define WRNN_ABI_VERSION 4
 
 enum {
     WRNN_OK = 0,
@@ -130,6 +130,14 @@ typedef struct wrnn_options {
                                 its per-(phase, stage segment) shader clocks (layout: csrc/wrnn_loop.hip, "PROF") */
     wrnn_timer *timer;       /* optional: time the loop kernel(s) of this call */
     wrnn_run_info *info;     /* optional out */
+    /* optional progress read-out (ABI v4) -- the reference's `gen_display` (fatchord_version.py:241, :267-271: a rate line every
+     * 100 steps of its Python loop).  Here the loop is one persistent kernel per conditioning slab, so the read-out exists per
+     * slab: after the launches of every slab a host function is enqueued on `stream` (hipLaunchHostFunc) that calls
+     * progress(steps_done, T, n_segments, progress_user) from a HIP runtime thread once the device has really got there.  No
+     * synchronisation, nothing inside the kernel.  The callback must not call into HIP.  Loop kernel only (the other kernels are
+     * one launch: they report once, at the end). */
+    void (*progress)(int32_t steps_done, int32_t T, int32_t n_segments, void *user);
+    void *progress_user;
 } wrnn_options;
 
 const char *wrnn_last_error(void);

@@ -46,7 +46,7 @@ def test_tacotron_graph_loop_and_vocoder_handoff(tmp_path):
     voc.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in random_state_dict(0, mode='MOL').items()}, strict=True)
     voc = voc.to(dev)
     voc.noise_source = 'device'
-    m = torch.tensor(tacotron_to_wavernn_mel(mel_g)).unsqueeze(0)
+    m = torch.tensor(tacotron_to_wavernn_mel(lin_g)).unsqueeze(0)        # `_, m, attention = tts_model.generate(x)` (:142): the postnet output
     voc.generate(m, tmp_path / 'w.wav', True, 11_000, 550, True)       # warm-up (weight packs)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

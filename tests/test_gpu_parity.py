@@ -81,7 +81,7 @@ KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'loop': 'wrnn_loop_kernel', 'spar
 def test_device_selftests(gpu):
     from wavernn_amd import _lib
     L = _lib.lib()
-    assert L.wrnn_abi_version() == 3
+    assert L.wrnn_abi_version() == 4
     assert L.wrnn_device_cus(0) > 0
     _lib.check(L.wrnn_selftest(0, 1), 'mfma selftest')
     print(L.wrnn_last_error().decode())
@@ -585,8 +585,9 @@ def test_full_size_properties(gpu, mode):
 
 def test_inplace_weight_edit_rebuilds_the_device_pack(gpu, tmp_path):
     """Weights edited in place through `.data` (what the reference's pruning notebook does: `W *= M` on `parameters()[i].data`)
-    change neither data_ptr nor `_version` of the parameter; the device weight pack is keyed on a content fingerprint, so
-    the next generate() sees them (round-1 advisor finding: it used to keep the stale pack)."""
+    change neither data_ptr nor `_version` of the parameter: `prune.Pruner` therefore invalidates the model's device weight
+    packs itself (`on_change` -> `WaveRNN.invalidate_engines`), and the next generate() sees the pruned weights (round-1
+    advisor finding: the stale pack was kept; round 2 hashed all weights with a device sync on every call instead)."""
     from wavernn_amd.model import WaveRNN
     from wavernn_amd.prune import wavernn_pruner
     from wavernn_amd.synthetic import random_state_dict, random_mel, SHIPPED

@@ -23,7 +23,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.wrnn_abi_version() == 3
+    assert L.wrnn_abi_version() == 4
     # no GPU here: compute entry points must fail loudly, never fall back to the host
     if not torch.cuda.is_available():
         assert L.wrnn_device_cus(0) < 0
@@ -314,3 +314,53 @@ def test_bench_self_launches_two_ranks_dry_host(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line['scaling'] == 'strong' and line['n_gpus'] == 1 and '3 utterances' in line['config']['workload']
+
+
+def test_sliced_generate_degrades_to_stream_when_the_grid_is_refused(tmp_path, monkeypatch):
+    """Round-2 advisor: `auto` -> stream on WRNN_ERR_RESIDENCY only fired for unsliced runs.  A step-sliced generate() (batched
+    RAW always is) whose first slice is refused must redo the WHOLE call on the stream kernel from the same point of the
+    noise stream, and leave the global generator where an unsliced run leaves it.  (Engine mocked: no GPU here.)"""
+    import warnings
+    import wavernn_amd.model as M
+    from wavernn_amd import _lib
+    from wavernn_amd.synthetic import random_state_dict, random_mel, SHIPPED
+    calls = []
+
+    class Eng:
+        def plan(self, n, T, **kw):
+            return dict(kernel='wrnn_loop_kernel')
+
+        def run(self, mels_up, aux, B, T, stride, noise, hop, algo='auto', out=None, t_range=None, progress=None, **kw):
+            calls.append((algo, t_range, float(noise.sum())))
+            if algo == 'auto':
+                raise _lib.ResidencyError('refused')
+            assert t_range is None and noise.shape[0] == T
+            return torch.zeros(B, T)
+
+        def last_loop_ms(self):
+            return 0.0
+
+        def last_loop_kernel(self):
+            return 'wrnn_stream_kernel'
+    monkeypatch.setattr(M.WaveRNN, '_require_hip_device', staticmethod(lambda device: None))
+    monkeypatch.setattr(M.WaveRNN, '_loop_engine', lambda self: Eng())
+    monkeypatch.setattr(M, 'save_wav', lambda x, path, sr: None)
+    model = M.WaveRNN(**SHIPPED, mode='MOL')
+    model.pre_algo, model.post_algo = 'torch', 'numpy'
+    model.noise_chunk_bytes = 11 * 3 * 4 * 100          # ~100 steps of noise at a time -> several slices
+    mel = torch.from_numpy(random_mel(5, 30)).unsqueeze(0)
+    torch.manual_seed(11)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        model.generate(mel, tmp_path / 'x.wav', True, 2200, 55, True)
+    assert any('stream kernel' in str(x.message) for x in w)
+    assert [c[0] for c in calls] == ['auto', 'stream'] and calls[0][1][0] == 0
+    after = torch.empty(3).uniform_(0, 1)
+    # reference order of draws: ctor burn, then T x 11 B uniforms -- as one unsliced run
+    from wavernn_amd.rng import burn_ctor_draws, draw_steps
+    torch.manual_seed(11)
+    burn_ctor_draws(512, 32, 'cpu')
+    B, T = 4, 2310
+    whole = draw_steps('MOL', B, T, 30, 'cpu', 'cpu')
+    assert abs(calls[1][2] - float(whole.sum())) < 1e-3
+    assert torch.equal(after, torch.empty(3).uniform_(0, 1))

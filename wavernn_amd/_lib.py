@@ -14,7 +14,7 @@ SO_PATH = os.path.join(CSRC, 'libwavernn_amd.so')
 WRNN_OK = 0
 ERR_RESIDENCY = -6          # WRNN_ERR_RESIDENCY: the persistent grid cannot be co-resident on this device
 MODE_RAW, MODE_MOL = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 ALGO_AUTO, ALGO_STREAM, ALGO_LOOP, ALGO_SPARSE = 0, 1, 2, 5
 ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'loop': ALGO_LOOP, 'sparse': ALGO_SPARSE}
 
@@ -53,15 +53,24 @@ class Options(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('struct_bytes', 'algo', 'depth', 'clusters', 'cond_valu', 'slab_steps', 't_begin',
                                               't_end', 'tuning')] + \
                [('force_x', ctypes.c_void_p), ('logits', ctypes.c_void_p), ('phase_clocks', ctypes.c_void_p), ('timer', ctypes.c_void_p),
-                ('info', ctypes.POINTER(RunInfo))]
+                ('info', ctypes.POINTER(RunInfo)), ('progress', ctypes.c_void_p), ('progress_user', ctypes.c_void_p)]
 
     def __init__(self, **kw):
         super().__init__(**kw)
         self.struct_bytes = ctypes.sizeof(Options)
 
 
+#: wrnn_options.progress: void (*)(int32 steps_done, int32 T, int32 n_segments, void *user)
+PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p)
+
+
 class WrnnError(RuntimeError):
     pass
+
+
+class ResidencyError(WrnnError):
+    """WRNN_ERR_RESIDENCY on the FIRST slice of a step-sliced `auto` run: the persistent grid is not co-resident right now.  The
+    callers that slice (WaveRNN.generate, generate_corpus) catch it and redo the call unsliced on the stream kernel."""
 
 
 def build(verbose=False):

@@ -200,15 +200,25 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
             if noise_source == 'cpu':
                 nz = pack_noise(mode, plan, noise, clo, chi).to(device)
             elif eng is not None and eng.plan(n_seg, T, algo=model.loop_algo)['kernel'] == 'wrnn_loop_kernel':
-                # device noise in slices of steps (RAW is n_classes floats per segment-step): each slice continues the loop
+                # device noise in slices of steps (RAW is n_classes floats per segment-step): each slice continues the loop; at most
+                # `model.noise_chunk_bytes` of noise are resident (the same bound WaveRNN.generate() keeps)
+                from ._lib import ResidencyError
                 per_step = n_seg * (11 if mode == 'MOL' else model.n_classes) * 4
-                steps = max(1, min(T, getattr(model, 'noise_chunk_bytes', 128 << 20) * 8 // per_step))
-                for t0 in range(0, T, steps):
-                    t1 = min(T, t0 + steps)
-                    nz = draw_steps(mode, n_seg, t1 - t0, model.n_classes, device, 'device')
-                    eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo=model.loop_algo, check=check, out=out_view,
-                                     t_range=None if (t0 == 0 and t1 == T) else (t0, t1))
-                continue
+                steps = max(1, min(T, getattr(model, 'noise_chunk_bytes', 128 << 20) // per_step))
+                steps = -(-T // (-(-T // steps)))            # equal slices (no short tail slice with its own launches)
+                try:
+                    for t0 in range(0, T, steps):
+                        t1 = min(T, t0 + steps)
+                        nz = draw_steps(mode, n_seg, t1 - t0, model.n_classes, device, 'device')
+                        eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo=model.loop_algo, check=check, out=out_view,
+                                         t_range=None if (t0 == 0 and t1 == T) else (t0, t1))
+                    continue
+                except ResidencyError as e:     # the persistent grid was refused on the first slice: the whole chunk on the stream kernel
+                    import warnings
+                    warnings.warn(f'wavernn_amd: {e}; using the stream kernel')
+                    nz = draw_noise(mode, n_seg, T, model.n_classes, model.rnn_dims, model.aux_dims, device, 'device')
+                    eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo='stream', check=check, out=out_view)
+                    continue
             else:
                 nz = draw_noise(mode, n_seg, T, model.n_classes, model.rnn_dims, model.aux_dims, device, 'device')
             if loop_fn is None:

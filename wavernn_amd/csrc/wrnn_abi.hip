@@ -272,6 +272,31 @@ int timer_mark(wrnn_timer *t, hipStream_t stream)
     return WRNN_OK;
 }
 
+// progress read-out (wrnn_options.progress): a host function enqueued behind the launches of a slab
+struct ProgressCtx {
+    void (*fn)(int32_t, int32_t, int32_t, void *);
+    void *user;
+    int32_t done, T, n;
+};
+void progress_trampoline(void *p)
+{
+    ProgressCtx *c = static_cast<ProgressCtx *>(p);
+    c->fn(c->done, c->T, c->n, c->user);
+    delete c;
+}
+int enqueue_progress(const wrnn_options *o, int done, int T, int n, hipStream_t stream)
+{
+    if (!o->progress) return WRNN_OK;
+    ProgressCtx *c = new ProgressCtx{o->progress, o->progress_user, done, T, n};
+    hipError_t e = hipLaunchHostFunc(stream, progress_trampoline, c);
+    if (e != hipSuccess) {
+        delete c;
+        set_err("hipLaunchHostFunc failed: %s", hipGetErrorString(e));
+        return WRNN_ERR_HIP;
+    }
+    return WRNN_OK;
+}
+
 enum Kind { K_STREAM, K_LOOP, K_SPARSE };
 
 // what a call will run: kernel, split, rounds, slab length
@@ -485,7 +510,9 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     wrnn_timer *timer = o->timer;
     if (timer && pl.t0 == 0) timer->used = 0;            // a continuing call (t_begin > 0) adds its launches to the same total
 
-    HIPCHK(hipMemsetAsync(ws + l.status, 0, STATUS_WORDS * sizeof(unsigned), stream));
+    // (a continuation keeps the status words: a give-up in an earlier slice must stay visible to wrnn_status(), and the
+    // kernels leave at once when the abort flag is already up)
+    if (pl.t0 == 0) HIPCHK(hipMemsetAsync(ws + l.status, 0, STATUS_WORDS * sizeof(unsigned), stream));
     // segment table -> device (pageable source: the runtime stages it before returning)
     HIPCHK(hipMemcpyAsync(ws + l.segs, seg_pos, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(ws + l.segs + (size_t)B * sizeof(int), seg_lim, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -558,6 +585,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                 if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
                 info.launches += 1;
             }
+            if ((rc = enqueue_progress(o, s1, T, B, stream)) != WRNN_OK) return rc;
         }
     } else {
         // ---- stream / block-sparse kernels: whole-T conditioning in [t][segment][H] order, one launch --------------------
@@ -589,6 +617,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
         }
         if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
         info.launches = 1;
+        if ((rc = enqueue_progress(o, T, T, B, stream)) != WRNN_OK) return rc;
     }
     if (o->info) *o->info = info;
     return WRNN_OK;

@@ -109,7 +109,7 @@ class LoopEngine:
 
     def run_segments(self, mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='auto', force_x=None, want_logits=False,
                      check=True, depth=0, clusters=0, slab_steps=0, cond_valu=False, t_range=None, out=None, logits=None,
-                     phase_clocks=None, tuning=0):
+                     phase_clocks=None, tuning=0, progress=None):
         """mels_up (L,feat) / aux (n_frames,4*aux_dims) / noise: float32 CUDA tensors; seg_pos / seg_lim: host
         int32 arrays (B,) -- segment b, step t reads position seg_pos[b]+t, zero conditioning from seg_lim[b] on
         (several utterances: concatenated conditioning).  Returns out (B,T) CUDA [and logits (T,B,C)].
@@ -117,7 +117,9 @@ class LoopEngine:
 
         depth / clusters / slab_steps / cond_valu: `wrnn_options` (0 = the library picks).  t_range=(t0, t1) runs only those
         steps; t0 > 0 continues the previous call on this engine's workspace (pass the same `out`; `noise` then holds the
-        rows of [t0, t1) only) -- how long RAW runs draw their noise in chunks instead of T*B*C floats at once."""
+        rows of [t0, t1) only) -- how long RAW runs draw their noise in chunks instead of T*B*C floats at once.
+        progress: optional `f(steps_done, T, n_segments)` called from a HIP runtime thread when the device has finished each
+        conditioning slab (wrnn_options.progress; must not touch the device)."""
         for name, t_ in (('mels_up', mels_up), ('aux', aux), ('noise', noise)):
             if not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()):
                 raise ValueError(f'{name} must be a contiguous float32 CUDA tensor')
@@ -155,6 +157,9 @@ class LoopEngine:
             o.logits = logits.data_ptr()
         if phase_clocks is not None:      # profiling hook: int64 CUDA tensor [256, 32], zeroed by the caller
             o.phase_clocks = phase_clocks.data_ptr()
+        if progress is not None:          # keep the ctypes thunk alive until the stream has drained (released on the next call)
+            self._progress_keep = _lib.PROGRESS_FN(lambda done, T_, n_, user: progress(int(done), int(T_), int(n_)))
+            o.progress = ctypes.cast(self._progress_keep, ctypes.c_void_p)
         o.timer = self._timer
         o.info = ctypes.pointer(self._info)
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -167,7 +172,11 @@ class LoopEngine:
             import warnings
             warnings.warn('wavernn_amd: cooperative launch refused (' + self.lib.wrnn_last_error().decode() + '); using the stream kernel')
             return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='stream', force_x=force_x,
-                                     want_logits=want_logits, check=check, cond_valu=cond_valu, out=out, logits=logits)
+                                     want_logits=want_logits, check=check, cond_valu=cond_valu, out=out, logits=logits, progress=progress)
+        if rc == _lib.ERR_RESIDENCY and algo == 'auto' and t0 == 0:
+            # ... the same refusal on the first slice of a step-sliced run (only the loop kernel continues a call): the caller,
+            # who owns the slicing and the noise stream, redoes the whole call on the stream kernel
+            raise _lib.ResidencyError('cooperative launch refused (' + self.lib.wrnn_last_error().decode() + ')')
         _lib.check(rc, 'wrnn_generate_segments')
         self._launches = (self._launches if t0 > 0 else 0) + int(self._info.launches)
         self._last_opts = (B, T, n_frames, self.options(algo, depth, clusters, slab_steps, cond_valu, None))

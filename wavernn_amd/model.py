@@ -7,6 +7,8 @@ contract and side effects (eval at entry, train at exit, RNG consumption, WAV wr
 the loop (reference :192-245) is ONE call into libwavernn_amd.so, conditioning is never folded in memory, and
 the model must live on a HIP device -- there is no CPU path here (use the reference for that).
 """
+import sys
+import time
 from pathlib import Path
 from typing import Union
 
@@ -15,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from . import fold as _fold
 from .dsp import save_wav
 from .engine import LoopEngine, LOOP_KEYS
@@ -136,6 +139,9 @@ class WaveRNN(nn.Module):
         self.post_algo = 'native'
         #: upper bound on the sampling noise resident at once (bytes); longer runs draw it slice by slice
         self.noise_chunk_bytes = 128 << 20
+        #: optional `f(steps_done, T, n_segments, seconds)` called after every noise slice of generate() (row a17: the
+        #: reference's gen_display read-out, :241/:267-271); None = silent, no extra synchronisation
+        self.progress_callback = None
         self._engine = None
         self._engine_key = None
         self._pre = None
@@ -166,21 +172,22 @@ class WaveRNN(nn.Module):
         return self.fc3(x)
 
     # ------------------------------------------------------------------------------------------------
-    @staticmethod
-    def _fingerprint(tensors):
-        """Cheap content fingerprint of device tensors: catches in-place edits made through `.data` (what the reference's
-        pruning notebook does: `p.data.mul_(mask)`), which bump neither data_ptr nor `_version` of the parameter."""
-        flat = torch.cat([t.detach().reshape(-1).view(torch.int32) for t in tensors]).to(torch.int64)
-        return tuple(torch.stack([flat.sum(), (flat * flat).sum(), (flat[1:] * flat[:-1]).sum()]).tolist())
-
     def invalidate_engines(self):
-        """Drop the cached device weight packs (they are also rebuilt automatically when the weights' content changes)."""
+        """Drop the cached device weight packs.  They are rebuilt automatically when a weight tensor is replaced or edited
+        through autograd-visible in-place ops (`load()`, `load_state_dict()`, an optimiser step: each bumps the tensor's
+        `_version`), and by `prune.Pruner` (which calls this).  Edits made behind autograd's back -- `p.data.mul_(mask)`, what
+        the reference's pruning notebook does by hand -- bump nothing PyTorch exposes: call this after them.  (Rounds 1-2 keyed
+        the packs on a content hash instead: a reduction over all 15 MB of weights plus a device synchronisation on EVERY
+        generate() call, which the C ABI's "no hidden synchronisation" rule forbids.)"""
         self._engine = self._pre = self._engine_key = self._pre_key = None
+
+    @staticmethod
+    def _weights_key(sd):
+        return tuple((k, v.data_ptr(), str(v.device), tuple(v.shape), str(v.dtype), int(v._version)) for k, v in sorted(sd.items()))
 
     def _loop_engine(self):
         sd = {k: v for k, v in self.state_dict().items() if k in LOOP_KEYS.values()}
-        key = tuple((k, v.data_ptr(), str(v.device), tuple(v.shape)) for k, v in sorted(sd.items()))
-        key = key + self._fingerprint([v for _, v in sorted(sd.items())])
+        key = self._weights_key(sd)
         if self._engine is None or key != self._engine_key:
             dev = next(self.parameters()).device
             self._engine = LoopEngine(sd, self.mode, device=dev)
@@ -190,8 +197,7 @@ class WaveRNN(nn.Module):
     def _pre_engine(self):
         from .pre import PreEngine
         sd = {k: v for k, v in self.state_dict().items() if k.startswith('upsample.')}
-        fl = [v for _, v in sorted(sd.items()) if v.dtype == torch.float32]
-        key = tuple((k, v.data_ptr(), str(v.device), tuple(v.shape)) for k, v in sorted(sd.items())) + self._fingerprint(fl)
+        key = self._weights_key(sd)
         if self._pre is None or key != self._pre_key:
             self._pre = PreEngine(sd, device=next(self.parameters()).device)
             self._pre_key = key
@@ -240,12 +246,19 @@ class WaveRNN(nn.Module):
             per_step = B * (11 if self.mode == 'MOL' else self.n_classes) * 4
             resumable = eng.plan(B, T, algo=self.loop_algo)['kernel'] == 'wrnn_loop_kernel'
             chunk = max(1, min(T, self.noise_chunk_bytes // per_step)) if resumable else T
-            out = None
-            for t0 in range(0, T, chunk):
-                t1 = min(T, t0 + chunk)
-                noise = draw_steps(self.mode, B, t1 - t0, self.n_classes, device, self.noise_source)
-                out = eng.run(mels_up, aux, B, T, stride, noise, self.hop_length, algo=self.loop_algo, out=out,
-                              t_range=None if (t0 == 0 and t1 == T) else (t0, t1))
+            chunk = -(-T // (-(-T // chunk)))                # equal slices (no short tail slice with its own launches)
+            rng_state = torch.get_rng_state() if (self.noise_source == 'cpu' and chunk < T) else None
+            algo = self.loop_algo
+            try:
+                out = self._run_sliced(eng, mels_up, aux, B, T, stride, chunk, algo, device)
+            except _lib.ResidencyError as e:
+                # `auto` picked the persistent kernel but its cooperative launch was refused (CU masking, a smaller partition,
+                # another cooperative kernel): redo the call UNSLICED on the stream kernel, from the same point of the noise stream
+                import warnings
+                warnings.warn(f'wavernn_amd: {e}; using the stream kernel')
+                if rng_state is not None:
+                    torch.set_rng_state(rng_state)
+                out = self._run_sliced(eng, mels_up, aux, B, T, stride, T, 'stream', device)
             self.last_loop_ms = eng.last_loop_ms()
             self.last_loop_kernel = eng.last_loop_kernel()
 
@@ -265,6 +278,37 @@ class WaveRNN(nn.Module):
         save_wav(output, save_path, self.sample_rate)
         self.train()
         return output
+
+    def _run_sliced(self, eng, mels_up, aux, B, T, stride, chunk, algo, device):
+        """The loop in slices of `chunk` steps: each slice draws its own rows of sampling noise and continues the loop where the
+        previous one stopped (wrnn_options.t_begin / t_end), so at most `noise_chunk_bytes` of noise are resident.
+        `progress_callback(steps_done, T, B, seconds)`, if set, is driven by wrnn_options.progress: a host function enqueued
+        behind every conditioning slab of the loop kernel -- the reference's `gen_display` read-out (:241, :267-271) at slab
+        granularity, without a synchronisation and with nothing inside the kernel."""
+        out = None
+        prog = None
+        if self.progress_callback is not None:
+            t_start, cb = time.perf_counter(), self.progress_callback
+            prog = lambda done, T_, n_: cb(done, T_, n_, time.perf_counter() - t_start)
+        for t0 in range(0, T, chunk):
+            t1 = min(T, t0 + chunk)
+            noise = draw_steps(self.mode, B, t1 - t0, self.n_classes, device, self.noise_source)
+            out = eng.run(mels_up, aux, B, T, stride, noise, self.hop_length, algo=algo, out=out,
+                          t_range=None if (t0 == 0 and t1 == T) else (t0, t1), progress=prog)
+        return out
+
+    def gen_display(self, i, seq_len, b_size, gen_rate):
+        """The reference's progress line (:267-271; utils/display.py:9-18 `progbar` + `stream`), for use as
+
+            model.progress_callback = lambda done, T, B, dt: model.gen_display(done, T, B, done / dt * B / 1000)
+
+        The reference calls it every 100 steps from inside its Python loop (:241); here the loop is one persistent kernel per
+        conditioning slab, so the read-out exists per slab (a few hundred steps; `wrnn_options.slab_steps`)."""
+        bar_len = 16
+        done = (i * bar_len) // max(1, seq_len)
+        pbar = ''.join(chr(0x2588) if k < done else chr(0x2591) for k in range(bar_len))
+        msg = f'| {pbar} {i * b_size}/{seq_len * b_size} | Batch Size: {b_size} | Gen Rate: {gen_rate:.1f}kHz | '
+        sys.stdout.write(f'\r{msg}')
 
     # -- API parity helpers (reference :281-435) -------------------------------------------------------
     def pad_tensor(self, x, pad, side='both'):

@@ -131,6 +131,9 @@ class Pruner:
         self.masks = [PruneMask(layer, prune_rnn_input, block) for layer in layers]
         self.num_pruned = 0
         self.total_params = sum(m.total_params for m in self.masks)
+        #: called after every step that edited weights (the masks are applied through `.data`, which bumps nothing PyTorch
+        #: exposes): `wavernn_pruner` points it at `WaveRNN.invalidate_engines`, so the next generate() repacks the weights
+        self.on_change = None
 
     @staticmethod
     def _step(t):
@@ -156,6 +159,8 @@ class Pruner:
             if self.apply_or_not(t):
                 m.apply_mask(layer)
         self.count_num_pruned()
+        if self.apply_or_not(t) and self.on_change is not None:
+            self.on_change()
 
     def restart(self, layers, t):
         """After a training restart: rebuild the masks from the (already pruned) weights at the schedule's sparsity."""
@@ -177,9 +182,12 @@ def wavernn_pruner(model, start_prune, prune_steps, target_sparsity=0.95, prune_
     """`Pruner` over a WaveRNN's recurrent layers (both weight matrices of rnn1 and rnn2; with `prune_fc` also fc1 / fc2, the
     notebook's `splits['Linear']` case) in the 16x1 block structure the block-sparse loop kernel packs.  Returns
     (pruner, layers): call `pruner.prune(layers, step)` after every optimiser step, then `model.generate()` -- the device weight
-    pack is rebuilt automatically when the weights change, and `auto` picks `wrnn_sparse_kernel` once every block row is
+    pack is rebuilt after every pruning step (`Pruner.on_change` -> `WaveRNN.invalidate_engines`), and `auto` picks `wrnn_sparse_kernel` once every block row is
     sparse enough (`LoopEngine.sparse_blocks`)."""
     layers = [model.rnn1, model.rnn2] + ([model.fc1, model.fc2] if prune_fc else [])
     if prune_fc and block is not None and (model.fc1.weight.size(1) % block[1] or model.fc1.weight.size(0) % block[0]):
         raise ValueError('fc weights do not tile by the block')
-    return Pruner(layers, start_prune, prune_steps, target_sparsity, True, prune_every, block), layers
+    pruner = Pruner(layers, start_prune, prune_steps, target_sparsity, True, prune_every, block)
+    if hasattr(model, 'invalidate_engines'):
+        pruner.on_change = model.invalidate_engines
+    return pruner, layers

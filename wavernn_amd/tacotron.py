@@ -10,8 +10,9 @@ sentence = one serial chain -- can be captured ONCE as a HIP graph and replayed 
 as a second persistent kernel (f3) is the follow-up; this gives config 3 an end-to-end path and a number to beat.
 
     tts = TacotronInference(state_dict, device='cuda')
-    mel, linear, attn = tts.generate(ids, steps=800)          # same returns as the reference: (80, N), (fft, N), (N, chars)
-    m = torch.tensor(np.clip((mel + 4) / 8, 0, 1)).unsqueeze(0)   # gen_tacotron.py:143-145
+    _, m, attn = tts.generate(ids, steps=800)                 # same returns as the reference: (80, N), (fft, N), (N, chars); the
+                                                              # vocoder takes the SECOND one (postnet output; gen_tacotron.py:142)
+    m = torch.tensor(np.clip((m + 4) / 8, 0, 1)).unsqueeze(0)     # gen_tacotron.py:143-145
     voc.generate(m, path, True, 11_000, 550, True)               # gen_tacotron.py:161-163
 """
 import re
