@@ -50,6 +50,9 @@ enum {
     WRNN_ALGO_LOOP = 2,     /* role-split pipelined persistent kernel (RAW and MOL): up to 4 clusters of 64 CUs, each with a full
                                fp32 copy of the loop weights in registers, up to 8 groups of <= 16 segments in flight per cluster,
                                tag-free activation exchange in MFMA-fragment order (csrc/wrnn_loop.hip) */
+    WRNN_ALGO_DUO = 6,      /* the loop kernel cut for TWO workgroups per CU (MOL): four roles -- rnn1 / rnn2 x {W_ih + fc, W_hh [+ fc3 and
+                               sampling]} -- of <= 128 weight registers, 128 workgroups per 64-CU cluster, so that one wave's MFMAs overlap
+                               the other's loads, pointwise math and barrier waits (csrc/wrnn_duo.hip); for >= 2 groups in flight */
     WRNN_ALGO_SPARSE = 5    /* block-sparse GRU kernel (MOL; BASELINE config 5): needs GRU matrices whose 16x1 block rows
                                keep <= 64 columns (wrnn_pack_sparse_blocks); 8 XCD-local clusters x 2 groups in flight */
 };
@@ -99,7 +102,7 @@ typedef struct wrnn_timer wrnn_timer;
 
 /* What a wrnn_generate* call decided (filled synchronously, before the call returns). */
 typedef struct wrnn_run_info {
-    const char *kernel;      /* "wrnn_loop_kernel" / "wrnn_sparse_kernel" / "wrnn_stream_kernel" */
+    const char *kernel;      /* "wrnn_duo_kernel" / "wrnn_loop_kernel" / "wrnn_sparse_kernel" / "wrnn_stream_kernel" */
     int32_t units_per_wg;    /* hidden units per workgroup (16; stream: 0) */
     int32_t clusters;        /* independent CU clusters, each holding one copy of the weights */
     int32_t depth;           /* groups of <= 16 segments in flight per cluster */
@@ -123,7 +126,8 @@ typedef struct wrnn_options {
                                 t_begin on the same workspace (loop kernel only); `noise` then covers [t_begin, t_end) only,
                                 `out` / force_x / logits always the whole [.., T] tensors */
     int32_t tuning;          /* loop kernel A/B switches for measurements: bit 0 = no one-stage look-ahead of the exchange loads,
-                                bit 1 = full __syncthreads() fences at the stage barriers (default 0 = the fast forms) */
+                                bit 1 = full __syncthreads() fences at the stage barriers (default 0 = the fast forms); bit 2 (duo
+                                kernel) = re-fill the exchange ring with the sentinel before EVERY launch, not only where a round starts */
     const float *force_x;    /* test hook, device [n,T]: value fed back as x_t instead of the sample (teacher forcing) */
     float *logits;           /* test hook, device [T,n,C]: fc3 output of every step (:223) */
     unsigned long long *phase_clocks; /* profiling hook, device [256 workgroups][32] zeroed by the caller: the loop kernel (MOL) adds

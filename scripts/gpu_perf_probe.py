@@ -34,7 +34,9 @@ VARS = {'auto': dict(algo='auto'), 'stream': dict(algo='stream'), 'g1': dict(alg
         'g3': dict(algo='loop', depth=3), 'g4': dict(algo='loop', depth=4), 'g6': dict(algo='loop', depth=6), 'g8': dict(algo='loop', depth=8),
         'c1g1': dict(algo='loop', clusters=1, depth=1), 'c2g1': dict(algo='loop', clusters=2, depth=1), 'c1g2': dict(algo='loop', clusters=1, depth=2),
         'nola': dict(algo='loop', tuning=1), 'fence': dict(algo='loop', tuning=2), 'nola-fence': dict(algo='loop', tuning=3),
-        's1': dict(algo='sparse', depth=1), 's2': dict(algo='sparse', depth=2)}
+        's1': dict(algo='sparse', depth=1), 's2': dict(algo='sparse', depth=2),
+        'd1': dict(algo='duo', depth=1), 'd2': dict(algo='duo', depth=2), 'd3': dict(algo='duo', depth=3), 'd4': dict(algo='duo', depth=4),
+        'd6': dict(algo='duo', depth=6), 'd8': dict(algo='duo', depth=8), 'dauto': dict(algo='duo'), 'd4fill': dict(algo='duo', depth=4, tuning=4)}
 rows = []
 for B in [int(x) for x in args.B.split(',')]:
     stride = 64
@@ -51,7 +53,7 @@ for B in [int(x) for x in args.B.split(',')]:
         opts = VARS[v]
         try:
             depth = opts.get('depth', 0)
-            if depth > 1 and B <= 64 * (depth - 1) and opts['algo'] == 'loop':
+            if depth > 1 and B <= 64 * (depth - 1) and opts['algo'] in ('loop', 'duo'):
                 continue                                              # the extra slots would stay empty: same run as a shallower depth
             out = eng.run(mels_up, aux, B, T, stride, noise, hop, **opts)
             out = eng.run(mels_up, aux, B, T, stride, noise, hop, **opts)

@@ -104,7 +104,8 @@ def test_bench_geometry_matches_oracle(gpu):
     assert worst <= MOL_TOL, worst
 
 
-def test_bench_workload_256_segments_matches_oracle(gpu):
+@pytest.mark.parametrize('algo', ['auto', 'loop', 'duo'])
+def test_bench_workload_256_segments_matches_oracle(gpu, algo):
     """THE driver's headline workload (bench.py defaults: 16 utterances x 641 frames, weight seed 0, mel seeds 1234+u ->
     256 folded segments x 12,100 steps in ONE call, whatever kernel and split `auto` picks: today 4 clusters x 4 groups in
     flight, conditioning slabs of 192 steps) with parity noise (seeds 77+u), value-checked against the C oracle run per
@@ -113,14 +114,17 @@ def test_bench_workload_256_segments_matches_oracle(gpu):
     from wavernn_amd.synthetic import random_state_dict
     sd = random_state_dict(0, mode='MOL')
     frames = [641] * 16
-    plan, mels_up, aux, flat, refs = _corpus_inputs(sd, 'MOL', frames, [1234 + u for u in range(16)], [77 + u for u in range(16)])
+    if 'bench256' not in _SWEEP:
+        _SWEEP.clear()
+        _SWEEP['bench256'] = _corpus_inputs(sd, 'MOL', frames, [1234 + u for u in range(16)], [77 + u for u in range(16)])
+    plan, mels_up, aux, flat, refs = _SWEEP['bench256']
     assert plan.n_segments == 256 and plan.T == 12100
     eng = LoopEngine(sd, 'MOL', device=gpu)
-    want = eng.plan(256, plan.T)
+    want = eng.plan(256, plan.T, algo=algo)
     out = eng.run_segments(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), plan.seg_pos, plan.seg_lim, plan.T,
-                           torch.from_numpy(flat).to(gpu), HOP, algo='auto').cpu().numpy()
+                           torch.from_numpy(flat).to(gpu), HOP, algo=algo).cpu().numpy()
     info = eng.last_run_info()
-    print(f'bench workload: {info} {eng.last_loop_ms():.1f} ms')
+    print(f'bench workload [{algo}]: {info} {eng.last_loop_ms():.1f} ms')
     assert info['kernel'] == want['kernel'] and (info['clusters'], info['depth'], info['slab_steps']) == (want['clusters'], want['depth'], want['slab_steps'])
     assert info['clusters'] * info['depth'] * 16 >= 256 and info['rounds'] == 1          # all 256 segments in flight at once
     worst = 0.0
@@ -159,9 +163,9 @@ def _sweep_case(sd, mode, n, T, seed):
     return _SWEEP[key]
 
 
-@pytest.mark.parametrize('mode', ['MOL', 'RAW'])
+@pytest.mark.parametrize('mode,algo', [('MOL', 'loop'), ('RAW', 'loop'), ('MOL', 'duo')])
 @pytest.mark.parametrize('clusters', [1, 4])
-def test_every_depth_the_planner_can_pick(gpu, mode, clusters):
+def test_every_depth_the_planner_can_pick(gpu, mode, clusters, algo):
     """Depth 4, 5, 6, 7, 8 groups in flight per cluster x {1, 4} clusters x {MOL, RAW}, value-checked against the C oracle at
     short T.  Segment counts are chosen so that some clusters run `depth` slots and the others `depth - 1` (both parities of
     the number of active slots in one launch: the `last_i` / alternate-sampling branches of wrnn_loop.hip, incl. last slots
@@ -177,7 +181,7 @@ def test_every_depth_the_planner_can_pick(gpu, mode, clusters):
         groups = depth if clusters == 1 else 4 * (depth - 1) + 2
         n = 16 * (groups - 1) + 5
         mels_up, aux, seg_pos, seg_lim, noise, ref = _sweep_case(sd, mode, n, T, 1000 + n)
-        out = eng.run_segments(mels_up.to(gpu), aux.to(gpu), seg_pos, seg_lim, T, noise.to(gpu), HOP, algo='loop', clusters=clusters,
+        out = eng.run_segments(mels_up.to(gpu), aux.to(gpu), seg_pos, seg_lim, T, noise.to(gpu), HOP, algo=algo, clusters=clusters,
                                depth=depth, slab_steps=T // 3 + 1).cpu().numpy()
         info = eng.last_run_info()
         assert (info['clusters'], info['depth'], info['rounds']) == (clusters, depth, 1), info

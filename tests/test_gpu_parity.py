@@ -74,8 +74,19 @@ VARIANTS = {
     'loop-g2-slabs': dict(algo='loop', depth=2, slab_steps=97),       # several conditioning slabs: state saved / restored
     'loop-c1-g3': dict(algo='loop', clusters=1, depth=3, slab_steps=160),
     'loop-c2-g2': dict(algo='loop', clusters=2, depth=2),
+    # the two-workgroups-per-CU form (MOL only): same splits
+    'duo': dict(algo='duo'),
+    'duo-g1': dict(algo='duo', depth=1),
+    'duo-g2-slabs': dict(algo='duo', depth=2, slab_steps=97),
+    'duo-c1-g3': dict(algo='duo', clusters=1, depth=3, slab_steps=160),
+    'duo-c2-g2': dict(algo='duo', clusters=2, depth=2),
 }
-KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'loop': 'wrnn_loop_kernel', 'sparse': 'wrnn_sparse_kernel'}
+KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'loop': 'wrnn_loop_kernel', 'sparse': 'wrnn_sparse_kernel', 'duo': 'wrnn_duo_kernel'}
+
+
+def _skip_unless_supported(mode, opts):
+    if opts.get('algo') == 'duo' and mode != 'MOL':
+        pytest.skip('wrnn_duo_kernel is MoL only (RAW runs on wrnn_loop_kernel)')
 
 
 def test_device_selftests(gpu):
@@ -124,19 +135,25 @@ def test_exchange_layers_match_oracle(gpu, mode):
         assert np.abs(out.cpu().numpy() - ref).max() <= MOL_TOL
 
 
-@pytest.mark.parametrize('mode', ['MOL', 'RAW'])
-def test_step_ranges_continue_bit_exactly(gpu, mode):
-    """`wrnn_options.t_begin / t_end`: the loop run as three calls over [0, 200), [200, 201), [201, T), each with only its
-    own rows of noise, equals the single call bit for bit (the per-group state lives in the workspace between calls)."""
+@pytest.mark.parametrize('mode,algo', [('MOL', 'loop'), ('RAW', 'loop'), ('MOL', 'duo')])
+def test_step_ranges_continue_bit_exactly(gpu, mode, algo):
+    """`wrnn_options.t_begin / t_end`: the loop run as calls over [0, 200), [200, 201), [201, 203), [203, T), each with only its
+    own rows of noise, equals the single call bit for bit (the per-group state lives in the workspace between calls; the duo
+    kernel also carries its exchange ring across launches -- slabs and calls shorter than its 4-step re-arm distance included)."""
     from wavernn_amd.engine import LoopEngine
     cfg = dict(mode=mode, wseed=38, mseed=138, frames=60, batched=True, target=550, overlap=55, seed=98)
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     eng = LoopEngine(sd, mode, device=gpu)
     mu, au, nz = torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), torch.from_numpy(flat).to(gpu)
-    whole = eng.run(mu, au, B, T, stride, nz, 275, algo='loop', slab_steps=128).cpu().numpy()
+    whole = eng.run(mu, au, B, T, stride, nz, 275, algo=algo, slab_steps=128).cpu().numpy()
+    if algo == 'duo':       # ... and the ring re-filled before every launch (tuning bit 2) changes nothing
+        again = eng.run(mu, au, B, T, stride, nz, 275, algo=algo, slab_steps=128, tuning=4).cpu().numpy()
+        assert np.array_equal(again, whole)
+        short = eng.run(mu, au, B, T, stride, nz, 275, algo=algo, slab_steps=3).cpu().numpy()      # slabs shorter than the re-arm distance
+        assert np.array_equal(short, whole)
     out = None
-    for t0, t1 in ((0, 200), (200, 201), (201, T)):
-        out = eng.run(mu, au, B, T, stride, nz[t0:t1].contiguous(), 275, algo='loop', slab_steps=128, t_range=(t0, t1), out=out)
+    for t0, t1 in ((0, 200), (200, 201), (201, 203), (203, T)):
+        out = eng.run(mu, au, B, T, stride, nz[t0:t1].contiguous(), 275, algo=algo, slab_steps=128, t_range=(t0, t1), out=out)
     assert np.array_equal(out.cpu().numpy(), whole)
     with pytest.raises(Exception):
         eng.run(mu, au, B, T, stride, nz[:10].contiguous(), 275, algo='stream', t_range=(0, 10))
@@ -164,6 +181,7 @@ def test_loop_matches_reference_golden(gpu, name, variant):
     from wavernn_amd.engine import LoopEngine
     cfg, g = load_case(name)
     opts = VARIANTS[variant]
+    _skip_unless_supported(cfg['mode'], opts)
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     eng = LoopEngine(sd, cfg['mode'], device=gpu)
     out = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
@@ -181,7 +199,7 @@ def test_loop_matches_reference_golden(gpu, name, variant):
         assert np.abs(out - ref).max() <= MOL_TOL
 
 
-@pytest.mark.parametrize('variant', ['stream', 'loop', 'loop-g2-slabs'])
+@pytest.mark.parametrize('variant', ['stream', 'loop', 'loop-g2-slabs', 'duo', 'duo-g2-slabs'])
 @pytest.mark.parametrize('name', ['raw_batched_60f', 'mol_batched_100f'])
 def test_teacher_forced_logits(gpu, name, variant):
     """Feed the reference's samples back (teacher forcing) and compare every step's fc3 logits with the C
@@ -189,6 +207,7 @@ def test_teacher_forced_logits(gpu, name, variant):
     from oracle import c_oracle as C, wavernn_oracle as O
     from wavernn_amd.engine import LoopEngine
     cfg, g = load_case(name)
+    _skip_unless_supported(cfg['mode'], VARIANTS[variant])
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     mels_f, aux_f, _ = O.conditioning(sd, mel, cfg['batched'], cfg['target'], cfg['overlap'])
     _, ref_logits = C.loop(sd, cfg['mode'], mels_f, aux_f, noise, want_logits=True)     # free run == golden path
@@ -301,7 +320,7 @@ def test_generate_end_to_end(gpu, name, pre, tmp_path):
     assert np.array_equal(torch.empty(4).uniform_(0, 1).numpy(), st.uniform_(4, 0, 1))
 
 
-@pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'loop-c2-g2'])
+@pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'loop-c2-g2', 'duo', 'duo-g1', 'duo-g2-slabs', 'duo-c1-g3', 'duo-c2-g2'])
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_many_segments_all_clusters(gpu, mode, variant):
     """46 folded segments (the last one zero-padded) = 3 groups: one per cluster, all three in flight on one cluster, two
@@ -310,6 +329,7 @@ def test_many_segments_all_clusters(gpu, mode, variant):
     from wavernn_amd.engine import LoopEngine
     cfg = dict(mode=mode, wseed=31, mseed=131, frames=100, batched=True, target=550, overlap=55, seed=91)
     opts = VARIANTS[variant]
+    _skip_unless_supported(mode, opts)
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     assert (B, T) == (46, 660)
     ref = _oracle_free_run(cfg)
@@ -323,7 +343,7 @@ def test_many_segments_all_clusters(gpu, mode, variant):
         assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
 
 
-@pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3'])
+@pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'duo', 'duo-g1', 'duo-g2-slabs', 'duo-c1-g3'])
 def test_more_segments_than_slots(gpu, variant):
     """114 segments x 264 steps (MoL) = 8 groups: two rounds at depth 1 (state buffers per round), one round at depth 2,
     three rounds of 3 on one cluster -- against the C oracle."""
@@ -342,7 +362,7 @@ def test_more_segments_than_slots(gpu, variant):
     assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
 
 
-@pytest.mark.parametrize('variant', ['stream', 'loop', 'loop-g2-slabs'])
+@pytest.mark.parametrize('variant', ['stream', 'loop', 'loop-g2-slabs', 'duo', 'duo-g2-slabs'])
 def test_segment_table_several_utterances(gpu, variant):
     """`run_segments`: three utterances of different length, conditioning concatenated, ONE launch -- every utterance's
     segments must equal that utterance generated alone (C oracle on its own folded conditioning)."""

@@ -21,6 +21,11 @@ hipError_t launch_loop(const LoopArgs &args, int ncl, int mode, hipStream_t stre
 int loop_max_depth(int mode);
 int loop_clusters(int n_cus);
 size_t loop_state_floats(int G);
+hipError_t launch_duo(const LoopArgs &args, int ncl, hipStream_t stream);
+int duo_clusters(int n_cus);
+int duo_max_depth();
+size_t duo_xbuf_bytes(int G);
+size_t duo_xbuf_bytes_max();
 hipError_t launch_sparse(const LoopArgs &args, int G, int ncl, int nbp, hipStream_t stream);
 int sparse_clusters(int n_cus);
 int selftest_mfma(char *msg, size_t n);
@@ -56,6 +61,7 @@ struct wrnn_pack {
     const float *w_ih1, *w_hh1, *b_ih1, *b_hh1, *w_ih2, *w_hh2, *b_ih2, *b_hh2;
     const float *fc1_w, *fc1_b, *fc2_w, *fc2_b, *fc3_w, *fc3_b;
     const float *w_ih1T, *w_hh1T, *w_ih2T, *w_hh2T, *fc1T, *fc2T, *fc3T, *c2_wT, *c3_wT, *c4_wT;
+    const float *fc3f;         // MOL: fc3.weight in A-fragment order (wrnn_duo.hip)
     int sp_nbp;                // 0 = the GRU matrices are not block-sparse enough for wrnn_sparse_kernel; else 48 / 64
     int sp_max_blocks;
     const float *sp_vals;
@@ -139,6 +145,18 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     const size_t o_fc3T = b.add_T(w->fc3_w, C, H, 0, H);
     const size_t o_c2_wT = b.add_T(w->w_ih2, 3 * H, K2, H, AUX);
     const size_t o_c3_wT = b.add_T(w->fc1_w, H, K2, H, AUX), o_c4_wT = b.add_T(w->fc2_w, H, K2, H, AUX);
+    // MOL: fc3 (30 x 512) as two 16-row MFMA A tiles in fragment order: [tile][wave][k-block r][lane (row fi, k-quad kq)][4]
+    // = fc3_w[16 tile + fi][128 wave + 16 r + 4 kq ..], rows >= 30 zero
+    size_t o_fc3f = 0;
+    if (w->mode == WRNN_MODE_MOL) {
+        o_fc3f = b.add(nullptr, (size_t)2 * SEG * H);
+        for (int q = 0; q < 2 * SEG * H / 4; ++q) {
+            const int l6 = q & 63, r = (q >> 6) & 7, wv = (q >> 9) & 3, tile = q >> 11;
+            const int row = 16 * tile + (l6 & 15), kq = l6 >> 4;
+            for (int e = 0; e < 4; ++e)
+                b.host[o_fc3f + (size_t)q * 4 + e] = row < C ? w->fc3_w[(size_t)row * H + 128 * wv + 16 * r + 4 * kq + e] : 0.f;
+        }
+    }
     // ---- block-sparse view of the GRU matrices (16x1 blocks: 16 consecutive rows of one gate x 1 column) -----------
     // usable by wrnn_sparse_kernel when every block row keeps <= 64 columns (~5 % density keeps ~26 +- 5)
     int sp_nbp = 0, sp_max = 0;
@@ -200,6 +218,7 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     p->w_ih1T = base + o_w_ih1T; p->w_hh1T = base + o_w_hh1T; p->w_ih2T = base + o_w_ih2T; p->w_hh2T = base + o_w_hh2T;
     p->fc1T = base + o_fc1T; p->fc2T = base + o_fc2T; p->fc3T = base + o_fc3T;
     p->c2_wT = base + o_c2_wT; p->c3_wT = base + o_c3_wT; p->c4_wT = base + o_c4_wT;
+    p->fc3f = w->mode == WRNN_MODE_MOL ? base + o_fc3f : nullptr;
     p->sp_nbp = sp_nbp; p->sp_max_blocks = sp_max;
     p->sp_vals = sp_nbp ? base + o_spv : nullptr;
     p->sp_cols = sp_nbp ? reinterpret_cast<const int *>(base + o_spc) : nullptr;
@@ -297,7 +316,9 @@ int enqueue_progress(const wrnn_options *o, int done, int T, int n, hipStream_t 
     return WRNN_OK;
 }
 
-enum Kind { K_STREAM, K_LOOP, K_SPARSE };
+enum Kind { K_STREAM, K_LOOP, K_SPARSE, K_DUO };
+constexpr bool DUO_AUTO = false;     // `auto` picks wrnn_duo_kernel (flipped on once it is measured faster: profiles/r03*)
+constexpr int DUO_MIN_DEPTH = 2;
 
 // what a call will run: kernel, split, rounds, slab length
 struct Plan {
@@ -335,7 +356,7 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
     if (pl->t0 == 0 && pl->t1 == 0) pl->t1 = T;
     if (pl->t0 < 0 || pl->t1 > T || pl->t0 >= pl->t1) { set_err("bad step range [%d, %d) of T=%d", pl->t0, pl->t1, T); return WRNN_ERR_ARG; }
     const int algo = o->algo;
-    if (algo != WRNN_ALGO_AUTO && algo != WRNN_ALGO_STREAM && algo != WRNN_ALGO_LOOP && algo != WRNN_ALGO_SPARSE) {
+    if (algo != WRNN_ALGO_AUTO && algo != WRNN_ALGO_STREAM && algo != WRNN_ALGO_LOOP && algo != WRNN_ALGO_SPARSE && algo != WRNN_ALGO_DUO) {
         set_err("unknown algo %d", algo);
         return WRNN_ERR_ARG;
     }
@@ -353,8 +374,12 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
         pl->kind = K_SPARSE; pl->ncl = scl; pl->G = g;
         pl->rounds = (groups + scl * g - 1) / (scl * g);
         if ((double)pl->rounds * T >= 4.0e9) { set_err("too many steps"); return WRNN_ERR_ARG; }
-    } else if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_LOOP) {
+    } else if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_LOOP || algo == WRNN_ALGO_DUO) {
         int ncl = loop_clusters(p->n_cus);
+        if (algo == WRNN_ALGO_DUO && (p->mode != WRNN_MODE_MOL || duo_clusters(p->n_cus) < 1)) {
+            set_err("the two-workgroups-per-CU loop kernel needs MOL and >= 64 CUs (mode %d, device has %d CUs)", p->mode, p->n_cus);
+            return p->mode != WRNN_MODE_MOL ? WRNN_ERR_ARG : WRNN_ERR_RESIDENCY;
+        }
         if (shape_ok && ncl >= 1) {
             if (o->clusters == 1 || o->clusters == 2 || o->clusters == 4) ncl = o->clusters < ncl ? o->clusters : ncl;
             else if (groups < ncl) { int c2 = 1; while (c2 < groups) c2 *= 2; if (c2 < ncl) ncl = c2; }   // no more clusters than groups (rounded up to 1, 2, 4)
@@ -369,6 +394,9 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
                 if (g > gmax) g = gmax;
             }
             pl->kind = K_LOOP; pl->ncl = ncl; pl->G = g;
+            // the two-workgroups-per-CU form (MOL): on request, or when `auto` has >= DUO_MIN_DEPTH groups in flight per cluster
+            // (busy time bounds a step there; with fewer the latency of a slot's chain does, and the duo kernel's chain is one hop longer)
+            if (p->mode == WRNN_MODE_MOL && (algo == WRNN_ALGO_DUO || (algo == WRNN_ALGO_AUTO && DUO_AUTO && g >= DUO_MIN_DEPTH))) pl->kind = K_DUO;
             pl->rounds = (groups + ncl * g - 1) / (ncl * g);
             // balanced rounds of whole segments; every round is cut into <= ncl * g groups of <= 16
             pl->per_round = (B + pl->rounds - 1) / pl->rounds;
@@ -387,7 +415,7 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
             return WRNN_ERR_RESIDENCY;
         }
     }
-    if (pl->kind != K_LOOP && (pl->t0 != 0 || pl->t1 != T)) {
+    if (pl->kind != K_LOOP && pl->kind != K_DUO && (pl->t0 != 0 || pl->t1 != T)) {
         set_err("a partial step range [%d, %d) needs the loop kernel", pl->t0, pl->t1);
         return WRNN_ERR_ARG;
     }
@@ -405,8 +433,8 @@ WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frame
     l.c3f = o;    o = al(o + (size_t)(n_frames + 1) * H * sizeof(float));
     l.c4f = o;    o = al(o + (size_t)(n_frames + 1) * H * sizeof(float));
     const bool mol = p->mode == WRNN_MODE_MOL;
-    if (pl.kind == K_LOOP) {
-        l.xbuf = o;  o = al(o + XBUF_FLOATS * sizeof(float));
+    if (pl.kind == K_LOOP || pl.kind == K_DUO) {
+        l.xbuf = o;  o = al(o + (pl.kind == K_DUO ? duo_xbuf_bytes_max() : XBUF_FLOATS * sizeof(float)));
         l.state = o; o = al(o + (size_t)pl.rounds * loop_state_floats(pl.G) * sizeof(float));
         l.cIf = o;   o = al(o + (size_t)pl.slab * pl.ngr_max * SEG * H * sizeof(float));
         l.npre = o;  if (mol) o = al(o + (size_t)pl.slab * 11 * B * sizeof(float));      // derived MOL noise of one slab
@@ -469,7 +497,7 @@ extern "C" int wrnn_plan_segments(const wrnn_pack *p, int32_t n_segments, int32_
     int rc = make_plan(p, n_segments, T, &whole, &pl);
     if (rc != WRNN_OK) return rc;
     memset(out, 0, sizeof *out);
-    out->kernel = pl.kind == K_LOOP ? "wrnn_loop_kernel" : (pl.kind == K_SPARSE ? "wrnn_sparse_kernel" : "wrnn_stream_kernel");
+    out->kernel = pl.kind == K_DUO ? "wrnn_duo_kernel" : pl.kind == K_LOOP ? "wrnn_loop_kernel" : (pl.kind == K_SPARSE ? "wrnn_sparse_kernel" : "wrnn_stream_kernel");
     out->units_per_wg = pl.kind == K_STREAM ? 0 : 16;
     out->clusters = pl.ncl; out->depth = pl.G; out->rounds = pl.rounds; out->slab_steps = pl.slab;
     return WRNN_OK;
@@ -499,7 +527,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
         pl.t0 = o->t_begin; pl.t1 = o->t_end;
         if (pl.t0 == 0 && pl.t1 == 0) pl.t1 = T;
         if (pl.t0 < 0 || pl.t1 > T || pl.t0 >= pl.t1) { set_err("bad step range [%d, %d) of T=%d", pl.t0, pl.t1, T); return WRNN_ERR_ARG; }
-        if (pl.kind != K_LOOP && (pl.t0 != 0 || pl.t1 != T)) { set_err("a partial step range needs the loop kernel"); return WRNN_ERR_ARG; }
+        if (pl.kind != K_LOOP && pl.kind != K_DUO && (pl.t0 != 0 || pl.t1 != T)) { set_err("a partial step range needs the loop kernel"); return WRNN_ERR_ARG; }
     }
     const WsLayout l = ws_layout(p, pl, B, T, n_frames);
     if (workspace_bytes < l.total) { set_err("workspace %zu < required %zu", workspace_bytes, l.total); return WRNN_ERR_WORKSPACE; }
@@ -531,7 +559,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     memset(&a, 0, sizeof a);
     a.I_w0 = p->I_w0; a.w_ih1 = p->w_ih1; a.w_hh1 = p->w_hh1; a.b_ih1 = p->b_ih1; a.b_hh1 = p->b_hh1;
     a.w_ih2 = p->w_ih2; a.w_hh2 = p->w_hh2; a.b_hh2 = p->b_hh2; a.fc1_w = p->fc1_w; a.fc2_w = p->fc2_w;
-    a.fc3_w = p->fc3_w; a.fc3_b = p->fc3_b;
+    a.fc3_w = p->fc3_w; a.fc3_b = p->fc3_b; a.fc3f = p->fc3f;
     a.w_ih1T = p->w_ih1T; a.w_hh1T = p->w_hh1T; a.w_ih2T = p->w_ih2T; a.w_hh2T = p->w_hh2T;
     a.fc1T = p->fc1T; a.fc2T = p->fc2T; a.fc3T = p->fc3T;
     a.c2f = c.c2f; a.c3f = c.c3f; a.c4f = c.c4f;
@@ -548,9 +576,10 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     memset(&info, 0, sizeof info);
     info.clusters = pl.ncl; info.depth = pl.G; info.rounds = pl.rounds; info.slab_steps = pl.slab;
 
-    if (pl.kind == K_LOOP) {
-        // ---- role-split loop kernel: for every slab of steps { derived noise; for every round { conditioning slab; loop } } ----
-        info.kernel = "wrnn_loop_kernel"; info.units_per_wg = 16;
+    if (pl.kind == K_LOOP || pl.kind == K_DUO) {
+        // ---- role-split loop kernels: for every slab of steps { derived noise; for every round { conditioning slab; loop } } ----
+        const bool duo = pl.kind == K_DUO;
+        info.kernel = duo ? "wrnn_duo_kernel" : "wrnn_loop_kernel"; info.units_per_wg = 16;
         const bool mol = p->mode == WRNN_MODE_MOL;
         a.xbuf = (float *)(ws + l.xbuf);
         a.cIf = (const float *)(ws + l.cIf);
@@ -572,14 +601,18 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                 const int ngr = (nr + SEG - 1) / SEG;
                 c.t0 = s0; c.t1 = s1; c.rb0 = rb0; c.B = nr; c.NG = ngr;
                 HIPCHK(launch_cond_frag(c, p->n_cus, stream));
-                HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, XBUF_FLOATS * sizeof(float), stream));     // every word = the sentinel
+                // every word of the exchange ring = the sentinel.  The duo kernel leaves its ring consistent at the end of a launch
+                // (every step re-arms the entries four steps ahead), so it needs the fill only where a round starts: the first
+                // launch of a call that starts at step 0, or any launch when several rounds share the buffer
+                if (!duo) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, XBUF_FLOATS * sizeof(float), stream));
+                else if (s0 == 0 || pl.rounds > 1 || (o->tuning & 4)) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, duo_xbuf_bytes(pl.G), stream));
                 a.state = (float *)(ws + l.state) + (size_t)r * loop_state_floats(pl.G);
                 a.t0 = s0; a.t1 = s1; a.cI_t0 = s0; a.rb0 = rb0; a.Btot = nr; a.NG = ngr; a.resume = s0 > 0 ? 1 : 0;
                 if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
-                hipError_t e = launch_loop(a, pl.ncl, p->mode, stream);
+                hipError_t e = duo ? launch_duo(a, pl.ncl, stream) : launch_loop(a, pl.ncl, p->mode, stream);
                 if (e != hipSuccess) {
                     (void)hipGetLastError();
-                    set_err("loop kernel cooperative launch failed: %s", hipGetErrorString(e));
+                    set_err("%s cooperative launch failed: %s", info.kernel, hipGetErrorString(e));
                     return e == hipErrorCooperativeLaunchTooLarge ? WRNN_ERR_RESIDENCY : WRNN_ERR_HIP;
                 }
                 if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;

@@ -1,0 +1,630 @@
+// wrnn_duo.hip -- the TWO-WORKGROUPS-PER-CU form of the persistent WaveRNN loop kernel (MOL) for MI355X (gfx950 / CDNA4).
+//
+// Same path, same arithmetic and the same tag-free sentinel exchange in MFMA-fragment order as wrnn_loop.hip (reference
+// models/fatchord_version.py:201-241); what changes is WHO holds WHAT, for one reason (profiles/r02r_summary.md): a
+// wrnn_loop_kernel workgroup keeps 224 weight registers per lane, so it is alone on its CU with ONE wave per SIMD, and a
+// single in-order wave cannot overlap its 256 MFMAs per group-step (8.2 k cycles) with the ~14 k cycles of loads, partial
+// sums, pointwise math, publishes and barrier waits around them -- the matrix pipe idles 63 % of the time.  Here every
+// role of wrnn_loop.hip is cut in two along the line between its critical and its off-critical half:
+//
+//     role 0  A-ih : rnn1 W_ih (3 gate tiles) + fc1 (1 tile)   = 128 weight registers   phases P0 (gates -> h1, x1), P2 (fc1 -> y1)
+//     role 1  B-ih : rnn2 W_ih (3 gate tiles) + fc2 (1 tile)   = 128                    phases P0 (gates -> h2, x2), P2 (fc2 -> y2)
+//     role 2  A-hh : rnn1 W_hh (3 gate tiles)                  =  96                    phase  P1 (gh1(t+1) = W_hh1 . h1(t) + b_hh)
+//     role 3  B-hh : rnn2 W_hh (3 gate tiles)                  =  96                    phase  P1 (gh2(t+1)) [+ fc3 and sampling, below]
+//
+// so a workgroup fits 256 registers per lane and TWO workgroups share a CU: two waves per SIMD, one running MFMAs while the
+// other issues its VALU / LDS / memory work (MI355X guide: the matrix and vector pipes of a SIMD run concurrently for
+// different waves).  A cluster is 128 workgroups on the same 64 CUs; the issued MFMA count per CU and group-step drops from
+// 1024 to ~900 (fc3 below) and, more to the point, can now overlap everything else.
+//
+// What the cut costs: gh(t+1) = W_hh . h(t) + b_hh now crosses workgroups -- three more exchange layers per GRU
+// ([gate][16 units x 16 segments] = 3 KB per workgroup and group-step, read by ONE workgroup, a full step after it was
+// written: off the critical path).  fc3 + sampling (MOL: 30 x 512, 0.4 % of the FLOPs) used to run redundantly in all 32 workgroups of
+// the sampling role (64 of its 256 MFMAs per group-step); here ONE hh workgroup per slot runs it (slot i: role 2 + (i & 1),
+// unit block J = i >> 1), reading the fc3 fragments from L2, and hands x_t to the 32 A-ih workgroups through the 16-word
+// exchange layer wrnn_loop.hip already uses for role-B-sampled slots.  That is one more hop on a slot's chain (this kernel
+// is for >= 2 groups in flight per cluster, where the busy time of a workgroup bounds a step, not the latency of a
+// slot; wrnn_loop_kernel stays the kernel for one group per cluster).
+//
+// Ring discipline (conservative form of wrnn_loop.hip's): 8 ring entries per layer; at step t a wave re-arms its own words of
+// entry (t + 4) % 8 -- data of step t - 4, which every consumer left behind long ago -- and drains its stores at step t + 1;
+// the entry is written again at step t + 3 (gh(t+4), published one step early) or t + 4.  Any poll of that entry belongs to a
+// consumer's step >= t + 4, which exists only if every workgroup of the cluster has published something of its step t + 2
+// or later, i.e. has passed the drain of step t + 1: the re-arm is visible before the poll.
+#include <type_traits>
+
+#include "wrnn_ring.h"
+
+namespace wrnn {
+
+constexpr int DNX = 14;                      // layers: 0 h1  1 h2  2 y1  3 y2  4 -  5 x1  6 x2  7 x_t  8-10 gh1 r,z,n  11-13 gh2 r,z,n
+constexpr int DRING = 8;
+constexpr int DAHEAD = 4;                    // re-arm distance (steps)
+constexpr int DNWGC = 4 * LNJ;               // workgroups per cluster (128)
+constexpr size_t DXBUF_FLOATS = (size_t)LMAXG * MAXCL * DNX * DRING * XT;      // [slot][cluster][layer][ring][XT]
+constexpr int DLOGS = 33;
+constexpr int DPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][slot 0..2][16][16]
+#ifndef DUO_IH_XAHEAD
+#define DUO_IH_XAHEAD false            // ih roles: 128 weight registers leave no room for the one-stage look-ahead of the exchange loads (the co-resident wave covers)
+#endif
+
+struct DuoLds {
+    int off_part, off_log, off_wi0, off_misc, total;
+};
+__host__ __device__ inline DuoLds duo_lds(int G)
+{
+    DuoLds l;
+    int o = G * LGRP;
+    l.off_part = o; o += DPART;
+    l.off_log = o;  o += SEG * DLOGS;
+    l.off_wi0 = o;  o += H;
+    l.off_misc = o; o += 16 + 2 * LMAXG;     // [0] failure flag; [16 + 2 i], [17 + 2 i]: first segment / segment count of slot i
+    l.total = o;
+    return l;
+}
+
+// re-arm THIS WAVE's quarter (16 lanes x 16 bytes) of the workgroup's 1 KB block in up to four layers of one ring entry
+__device__ __forceinline__ void duo_rearm(__amdgpu_buffer_rsrc_t rs, int soff_entry0 /* bytes: layer 0 of the (slot, entry) + block + quarter */,
+                                          int lane, int la, int lb, int lc, int ld)
+{
+    const int which = lane >> 4;
+    const int layer = which == 0 ? la : (which == 1 ? lb : (which == 2 ? lc : ld));
+    if (layer >= 0) {
+        const u32x4 q = {SENT, SENT, SENT, SENT};
+        __builtin_amdgcn_raw_buffer_store_b128(q, rs, layer * (DRING * XT * 4) + (lane & 15) * 16, soff_entry0, 16 /* sc1 */);
+    }
+}
+
+// one fc3 tile with the A fragments read from global memory (L2-resident, fragment order), B in registers; mfma_tile's order
+__device__ __forceinline__ f32x4 mfma1_glb(const float *a_lane /* tile + frag_off(w, 0, lane) */, const float (&b)[32])
+{
+    float4 av[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) av[r] = *reinterpret_cast<const float4 *>(a_lane + 256 * r);
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].x, b[4 * r + 0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].x, b[4 * r + 4], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].y, b[4 * r + 1], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].y, b[4 * r + 5], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].z, b[4 * r + 2], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].z, b[4 * r + 6], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].w, b[4 * r + 3], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].w, b[4 * r + 7], c1, 0, 0, 0);
+    }
+    return c0 + c1;
+}
+
+#define DXL(i, layer, ring) ((((((i) * MAXCL + cl) * DNX + (layer)) * DRING) + (ring)) * XT)
+#define DPARTOF(q) (PART + (q) * (NW * 3 * 256))
+
+// bounded poll of up to three 4-byte words of this thread (sentinel = not written); `live` threads only.  Wave-uniform result.
+__device__ __forceinline__ bool poll3(__amdgpu_buffer_rsrc_t rs, int voff, int s0, int s1, int s2, bool live, unsigned &g0, unsigned &g1,
+                                      unsigned &g2, unsigned *status)
+{
+    unsigned spins = 0;
+    while (__any(live && (g0 == SENT || g1 == SENT || g2 == SENT))) {
+        if ((++spins & 255u) == 0u) {
+            if (spins > SPIN_LIMIT || ld_agent32(status) != 0u) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        g0 = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, s0, 16 /* sc1 */);
+        g1 = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, s1, 16 /* sc1 */);
+        g2 = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, s2, 16 /* sc1 */);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ih workgroup: LA = layer 1 (rnn1 W_ih + fc1; needs x_{t-1} for xi) or layer 2 (rnn2 W_ih + fc2).  Owns the GRU state of its 16
+// units (h, the gate pointwise math) and publishes h / the residual sum / relu(fc).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <bool LA, bool XAHEAD>
+__device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, int cl, int J, int ncl)
+{
+    const int G = a.G;
+    const DuoLds L = duo_lds(G);
+    float *PART = smem + L.off_part, *WI0 = smem + L.off_wi0;
+    int *FAIL = reinterpret_cast<int *>(smem + L.off_misc);
+    int *GEO = FAIL + 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int kbase_lane = KCH * w + 4 * kq;
+    const int pu = 4 * w + (tid & 3), pj = (tid >> 2) & 15;   // pointwise role: (owned unit, segment)
+    const int prow = LU * J + pu;
+    const int T0 = a.t0, T1 = a.t1;
+    const int NR = a.Btot, NGR = a.NG;
+    constexpr int L_H = LA ? 0 : 1, L_XR = LA ? 5 : 6, L_Y = LA ? 2 : 3, L_GH = LA ? 8 : 11;       // layers this role publishes / reads gh from
+    constexpr int L_P0 = LA ? -1 : 5, L_P2 = LA ? 6 : 2;                                           // layers its stages poll
+
+    float A_ih[3][AF], A_fc[AF];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) load_afrag(A_ih[g], LA ? a.w_ih1 : a.w_ih2, LA ? H : H + AUX, g * H + LU * J + fi, true, kbase_lane);
+    load_afrag(A_fc, LA ? a.fc1_w : a.fc2_w, H + AUX, LU * J + fi, true, kbase_lane);
+    float bi_r = 0.f, bi_z = 0.f, bi_n = 0.f;           // layer 1: b_ih1 (layer 2's b_ih2 is inside c2f)
+    if constexpr (LA) { bi_r = a.b_ih1[prow]; bi_z = a.b_ih1[H + prow]; bi_n = a.b_ih1[2 * H + prow]; }
+    const float *bhh = LA ? a.b_hh1 : a.b_hh2;
+    const float bh_r = bhh[prow], bh_z = bhh[H + prow], bh_n = bhh[2 * H + prow];
+
+    for (int q = tid; q < L.total; q += NT) smem[q] = 0.f;
+    __syncthreads();
+    if constexpr (LA) {
+        WI0[2 * tid] = a.I_w0[2 * tid];
+        WI0[2 * tid + 1] = a.I_w0[2 * tid + 1];
+    }
+    int nact = 0;
+    for (int i = 0; i < G; ++i)
+        if (cl + ncl * i < NGR) nact = i + 1;
+    // saved state: the layout of wrnn_loop.hip ([cluster][2 J + layer][slot][LGRP]); GH holds gh(t0) of a resumed launch
+    const size_t state_wg = ((size_t)(cl * LNWGC + 2 * J + (LA ? 0 : 1)) * G) * LGRP;
+    for (int i = 0; i < nact; ++i) {
+        float *GP = smem + i * LGRP;
+        const int g = cl + ncl * i;
+        const int b0 = (int)(((long)g * NR) / NGR), nb = (int)(((long)(g + 1) * NR) / NGR) - b0;
+        if (tid == 0) { GEO[2 * i] = a.rb0 + b0; GEO[2 * i + 1] = nb; }
+        if (a.resume) {
+            const float4 *src = reinterpret_cast<const float4 *>(a.state + state_wg + (size_t)i * LGRP);
+            for (int q = tid; q < LGRP / 4; q += NT) reinterpret_cast<float4 *>(GP)[q] = src[q];
+        } else {
+            // fatchord_version.py:194-196: h1 = h2 = 0, x = 0  =>  gh = W_hh . 0 + b_hh = b_hh
+            GP[tid] = bh_r; GP[256 + tid] = bh_z; GP[512 + tid] = bh_n;
+            GP[O_HOWN + tid] = 0.f;
+            if (tid < SEG) {
+                GP[O_XS + tid] = 0.f;
+                int *SP = reinterpret_cast<int *>(GP + O_SP);
+                const int sc = a.rb0 + b0 + (tid < nb ? tid : nb - 1);
+                SP[tid] = a.seg_pos[sc];
+                SP[SEG + tid] = a.seg_lim[sc];
+                const int p0 = SP[tid] + T0;
+                reinterpret_cast<int *>(GP + O_FR)[SEG * (T0 & 1) + tid] = (p0 < SP[SEG + tid]) ? (p0 / a.hop) : a.NF;
+            }
+        }
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.xbuf, (unsigned)(DXBUF_FLOATS * 4));
+    const int ghoff = (256 * J + tid) * 4;              // byte offset of this thread's (unit, segment) word in a [16 x 16] block
+    float touch = 0.f;
+    int pp = 0;
+    bool ok = true;
+    unsigned fcode = 0u;
+    int t = T0;
+
+    enum { BK_NONE = 0, BK_GATES, BK_RELU };
+    u32x4 x[8];
+    bool xahead = false;
+    int bk = BK_NONE, bi = 0, bpp = 0, bt = 0;
+    float bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
+    unsigned bg0 = 0u, bg1 = 0u, bg2 = 0u;              // gh words of the pending GATES half (loaded in its stage's front)
+    unsigned xtw = 0u;
+
+    auto poll_xt = [&](int i, int ring, int nb, unsigned &v) -> bool {
+        unsigned spins = 0;
+        while (__any(fi < nb && v == SENT)) {
+            if ((++spins & 255u) == 0u) {
+                if (spins > SPIN_LIMIT || ld_agent32(a.status) != 0u) return false;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            v = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, DXL(i, 7, ring) * 4, 16 /* sc1 */);
+        }
+        return true;
+    };
+
+    auto run_back = [&]() -> bool {
+        if (bk == BK_NONE) return true;
+        float *GP = smem + bi * LGRP;
+        const float *PB = DPARTOF(bpp);
+        const int nb = GEO[2 * bi + 1];
+        const int bring = bt % DRING;
+        if (!ok) FAIL[0] = 1;
+        lds_barrier();
+        if (FAIL[0] != 0) return false;
+        if (bk == BK_GATES) {                           // GRU cell pointwise (ATen gru_cell) -> publish h and the residual sum
+            const float gir = get_partial<3>(PB, 0, pu, pj) + bc0;
+            const float giz = get_partial<3>(PB, 1, pu, pj) + bc1;
+            const float gin = get_partial<3>(PB, 2, pu, pj) + bc2;
+            float ghr, ghz, ghn;
+            if (bt > T0) {                              // gh(t) from the hh workgroup of the same unit block (published during step t - 1)
+                const bool got = poll3(xrs, ghoff, DXL(bi, L_GH, bring) * 4, DXL(bi, L_GH + 1, bring) * 4, DXL(bi, L_GH + 2, bring) * 4,
+                                       pj < nb, bg0, bg1, bg2, a.status);
+                if (!got) { ok = false; if (fcode == 0u) fcode = 0x500u | (LA ? 0u : 8u) | 6u; }
+                ghr = __uint_as_float(bg0); ghz = __uint_as_float(bg1); ghn = __uint_as_float(bg2);
+            } else {                                    // first step of a launch: b_hh (t = 0) or the saved gh of the previous launch
+                ghr = GP[tid]; ghz = GP[256 + tid]; ghn = GP[512 + tid];
+            }
+            const float hn = gru_update(gir, giz, gin, ghr, ghz, ghn, GP[O_HOWN + tid]);
+            GP[O_HOWN + tid] = hn;
+            publish4(xrs, (DXL(bi, L_H, bring) + 256 * J) * 4, tid, hn, pj < nb);
+            publish4(xrs, (DXL(bi, L_XR, bring) + 256 * J) * 4, tid, GP[O_XO + tid] + hn, pj < nb);      // x1 = xi + h1 (:212) / x2 = x1 + h2 (:216)
+            if (tid < SEG) {   // conditioning frame of every segment at the NEXT step, into the other half of FR (first read a step from here)
+                const int *SP = reinterpret_cast<const int *>(GP + O_SP);
+                const int p1 = SP[tid] + bt + 1;
+                reinterpret_cast<int *>(GP + O_FR)[SEG * ((bt + 1) & 1) + tid] = (p1 < SP[SEG + tid]) ? (p1 / a.hop) : a.NF;
+            }
+        } else {                                        // fc1 / fc2 + relu -> publish y1 / y2
+            publish4(xrs, (DXL(bi, L_Y, bring) + 256 * J) * 4, tid, fmaxf(get_partial<3>(PB, 0, pu, pj) + bc0, 0.f), pj < nb);
+        }
+        bk = BK_NONE;
+        return true;
+    };
+
+    int ring = 0, tc = 0;
+    // A STAGE (phase ph = 0 gates / 2 fc, slot i), one-stage software pipeline as in wrnn_loop.hip: consume the loads issued a
+    // stage ago, run the previous stage's back half, build the operands, issue the next stage's loads, run the MFMA tiles.
+    auto stage = [&](auto PHC, int i) -> bool {
+        constexpr int ph = decltype(PHC)::value;
+        float *GP = smem + i * LGRP;
+        const int g = cl + ncl * i;
+        const int nb = GEO[2 * i + 1];
+        const float *cIg = a.cIf + ((size_t)tc * NGR + g) * XT;
+        float4 c[8];
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        unsigned g0 = 0u, g1 = 0u, g2 = 0u;
+        constexpr bool polled = !(LA && ph == 0);
+        constexpr int xl = ph == 0 ? L_P0 : L_P2;
+        float b[32];
+        bool ready = false;
+        if (polled) {
+            if (xahead) ready = try_finish(lane, nb, x, b);
+            else issue(xrs, DXL(i, xl, ring) * 4, w, lane, x);
+        }
+        if (ph == 0) {
+            if constexpr (LA) {
+                v0 = bi_r; v1 = bi_z; v2 = bi_n;
+                load_cI(cIg, w, lane, c);
+                if (t > T0)                             // x_{t-1}, sampled by an hh workgroup (first step of a launch: from the state)
+                    xtw = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, DXL(i, 7, (t + DRING - 1) % DRING) * 4, 16 /* sc1 */);
+            } else {
+                const int fr = reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj];
+                v0 = a.c2f[(size_t)fr * 3 * H + prow];
+                v1 = a.c2f[(size_t)fr * 3 * H + H + prow];
+                v2 = a.c2f[(size_t)fr * 3 * H + 2 * H + prow];
+            }
+            if (t > T0) {                               // gh(t) of this slot: consumed by this stage's back half, one stage from now
+                g0 = __builtin_amdgcn_raw_buffer_load_b32(xrs, ghoff, DXL(i, L_GH, ring) * 4, 16 /* sc1 */);
+                g1 = __builtin_amdgcn_raw_buffer_load_b32(xrs, ghoff, DXL(i, L_GH + 1, ring) * 4, 16 /* sc1 */);
+                g2 = __builtin_amdgcn_raw_buffer_load_b32(xrs, ghoff, DXL(i, L_GH + 2, ring) * 4, 16 /* sc1 */);
+            }
+        } else {
+            const int fr = reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj];
+            v0 = (LA ? a.c3f : a.c4f)[(size_t)fr * H + prow];
+        }
+        // ---------------- the previous stage's back half ----------------
+        if (!run_back()) return false;
+        // ---------------- operands -> MFMA tiles -> this wave's partial tiles ----------------
+        if (polled) {
+            unsigned spins = 0;
+            if (!ready) {
+                ok = ok && finish(xrs, DXL(i, xl, ring) * 4, w, lane, nb, x, b, a.status, spins);
+                if (!ok && fcode == 0u) fcode = 0x500u | (LA ? 0u : 8u) | (unsigned)ph;
+            }
+        }
+        if (ph == 2 && i == nact - 1) {
+            // ring hygiene, once per step, after the last layer this workgroup polls in the step has arrived (see the header)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ringn = (t + DAHEAD) % DRING;
+#pragma unroll 1
+            for (int i2 = 0; i2 < nact; ++i2) duo_rearm(xrs, (DXL(i2, 0, ringn) + 256 * J + 64 * w) * 4, lane, L_H, L_Y, L_XR, -1);
+        }
+        {   // the next stage's polled layer, one stage ahead (not across a step boundary)
+            int nph = ph, ni = i + 1;
+            if (ni >= nact) { nph = ph + 2; ni = 0; }
+            xahead = XAHEAD && nph <= 2 && !(LA && nph == 0);
+            if (xahead) issue(xrs, DXL(ni, nph == 0 ? L_P0 : L_P2, ring) * 4, w, lane, x);
+        }
+        if (LA && ph == 0) {
+            float xs = GP[O_XS + fi];
+            if (t > T0) {
+                ok = ok && poll_xt(i, (t + DRING - 1) % DRING, nb, xtw);
+                if (!ok && fcode == 0u) fcode = 0x500u | 0x20u;
+                xs = (fi < nb) ? __uint_as_float(xtw) : 0.f;
+            }
+            make_xi(c, WI0, xs, w, lane, b);            // xi(t) (:208-209)
+        }
+        if (ph == 0 && w == (J >> 3)) {
+            // the owned units' slice of this GRU's input (layer 1: xi, layer 2: x1) -> LDS in publish order, for the residual sum
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r == (J & 7)) *reinterpret_cast<float4 *>(GP + O_XO + 4 * lane) = make_float4(b[4 * r], b[4 * r + 1], b[4 * r + 2], b[4 * r + 3]);
+        }
+        float *PW = DPARTOF(pp);
+        if (ph == 0) {
+            f32x4 o0, o1, o2;
+            mfma3(A_ih[0], A_ih[1], A_ih[2], b, o0, o1, o2);
+            put_partial<3>(PW, w, 0, lane, o0);
+            put_partial<3>(PW, w, 1, lane, o1);
+            put_partial<3>(PW, w, 2, lane, o2);
+            bk = BK_GATES;
+        } else {
+            put_partial<3>(PW, w, 0, lane, mfma1(A_fc, b));
+            bk = BK_RELU;
+        }
+        if (LA && ph == 2 && t + 1 < T1) {     // pull the next step's conditioning block of this group (32 KB) into this XCD's L2
+            asm volatile("" ::"v"(touch));
+            touch = a.cIf[((size_t)(tc + 1) * NGR + g) * XT + 32 * tid];
+        }
+        bi = i; bpp = pp; bt = t; bc0 = v0; bc1 = v1; bc2 = v2; bg0 = g0; bg1 = g1; bg2 = g2;
+        pp ^= 1;
+        return true;
+    };
+
+    for (; t < T1; ++t) {
+        ring = t % DRING;
+        tc = t - a.cI_t0;
+#pragma unroll 1
+        for (int i = 0; i < nact; ++i)
+            if (!stage(std::integral_constant<int, 0>{}, i)) goto bail;
+#pragma unroll 1
+        for (int i = 0; i < nact; ++i)
+            if (!stage(std::integral_constant<int, 2>{}, i)) goto bail;
+    }
+    if (!run_back()) goto bail;
+    // ---- what the next launch of this round needs from the ring: gh(T1) of every slot (published during step T1 - 1) and, for
+    //      layer 1, x_{T1-1} -> the saved state
+#pragma unroll 1
+    for (int i = 0; i < nact; ++i) {
+        float *GP = smem + i * LGRP;
+        const int nb = GEO[2 * i + 1];
+        const int r1 = T1 % DRING;
+        unsigned g0 = __builtin_amdgcn_raw_buffer_load_b32(xrs, ghoff, DXL(i, L_GH, r1) * 4, 16 /* sc1 */);
+        unsigned g1 = __builtin_amdgcn_raw_buffer_load_b32(xrs, ghoff, DXL(i, L_GH + 1, r1) * 4, 16 /* sc1 */);
+        unsigned g2 = __builtin_amdgcn_raw_buffer_load_b32(xrs, ghoff, DXL(i, L_GH + 2, r1) * 4, 16 /* sc1 */);
+        ok = ok && poll3(xrs, ghoff, DXL(i, L_GH, r1) * 4, DXL(i, L_GH + 1, r1) * 4, DXL(i, L_GH + 2, r1) * 4, pj < nb, g0, g1, g2, a.status);
+        GP[tid] = __uint_as_float(g0); GP[256 + tid] = __uint_as_float(g1); GP[512 + tid] = __uint_as_float(g2);
+        if constexpr (LA) {
+            unsigned v = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, DXL(i, 7, (T1 + DRING - 1) % DRING) * 4, 16 /* sc1 */);
+            ok = ok && poll_xt(i, (T1 + DRING - 1) % DRING, nb, v);
+            GP[O_XS + fi] = (fi < nb) ? __uint_as_float(v) : 0.f;
+        }
+    }
+    if (!ok) { if (fcode == 0u) fcode = 0x500u | 0x21u; FAIL[0] = 1; }
+    __syncthreads();
+    if (FAIL[0] != 0) goto bail;
+    asm volatile("" ::"v"(touch));
+    for (int i = 0; i < nact; ++i) {
+        const float4 *GP = reinterpret_cast<const float4 *>(smem + i * LGRP);
+        float4 *dst = reinterpret_cast<float4 *>(a.state + state_wg + (size_t)i * LGRP);
+        for (int q = tid; q < LGRP / 4; q += NT) dst[q] = GP[q];
+    }
+    return;
+bail:
+    if (fcode != 0u) report_failure(a.status, fcode, blockIdx.x, t, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// hh workgroup: gh(t+1) = W_hh . h(t) + b_hh of its 16 units for every slot (off the critical path), and -- for at most one slot --
+// fc3 + mixture-of-logistics sampling (utils/distribution.py:87-123).  Keeps no state between launches.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <bool LA>
+__device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, int J, int ncl)
+{
+    const int G = a.G;
+    const DuoLds L = duo_lds(G);
+    float *PART = smem + L.off_part, *LOG = smem + L.off_log;
+    int *FAIL = reinterpret_cast<int *>(smem + L.off_misc);
+    int *GEO = FAIL + 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int kbase_lane = KCH * w + 4 * kq;
+    const int pu = 4 * w + (tid & 3), pj = (tid >> 2) & 15;
+    const int prow = LU * J + pu;
+    const int T0 = a.t0, T1 = a.t1, C = a.C;
+    const int NR = a.Btot, Nall = a.Nall, NGR = a.NG;
+    constexpr int L_H = LA ? 0 : 1, L_GH = LA ? 8 : 11;
+
+    float A_hh[3][AF];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) load_afrag(A_hh[g], LA ? a.w_hh1 : a.w_hh2, H, g * H + LU * J + fi, true, kbase_lane);
+    const float *bhh = LA ? a.b_hh1 : a.b_hh2;
+    const float bh_r = bhh[prow], bh_z = bhh[H + prow], bh_n = bhh[2 * H + prow];
+    const float b3a = a.fc3_b[tid >> 4];                                        // logit row tid >> 4
+    const float b3b = (16 + (tid >> 4) < 30) ? a.fc3_b[16 + (tid >> 4)] : 0.f;
+
+    for (int q = tid; q < L.total; q += NT) smem[q] = 0.f;
+    __syncthreads();
+    int nact = 0;
+    for (int i = 0; i < G; ++i)
+        if (cl + ncl * i < NGR) nact = i + 1;
+    if (tid == 0) {
+        for (int i = 0; i < nact; ++i) {
+            const int g = cl + ncl * i;
+            const int b0 = (int)(((long)g * NR) / NGR), nb = (int)(((long)(g + 1) * NR) / NGR) - b0;
+            GEO[2 * i] = a.rb0 + b0; GEO[2 * i + 1] = nb;
+        }
+    }
+    __syncthreads();
+    // the slot this workgroup samples: slot s <-> hh role (s & 1 ? layer 2 : layer 1), unit block s >> 1
+    const int my_slot = (J < LMAXG / 2) ? 2 * J + (LA ? 0 : 1) : -1;
+    const bool sampler = my_slot >= 0 && my_slot < nact;
+
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.xbuf, (unsigned)(DXBUF_FLOATS * 4));
+    int pp = 0;
+    bool ok = true;
+    unsigned fcode = 0u;
+    int t = T0;
+    enum { BK_NONE = 0, BK_GH, BK_SAMPLE };
+    u32x4 x[8];
+    bool xahead = false;
+    int bk = BK_NONE, bi = 0, bpp = 0, bt = 0;
+    float bc0 = 0.f, bc1 = 0.f;
+
+    auto run_back = [&]() -> bool {
+        if (bk == BK_NONE) return true;
+        const float *PB = DPARTOF(bpp);
+        const int nb = GEO[2 * bi + 1];
+        if (!ok) FAIL[0] = 1;
+        lds_barrier();
+        if (FAIL[0] != 0) return false;
+        if (bk == BK_GH) {                              // gh(t+1) of the owned (unit, segment) -> ring entry (t + 1): consumed by the ih workgroup J at step t + 1
+            const float g0 = get_partial<3>(PB, 0, pu, pj) + bh_r, g1 = get_partial<3>(PB, 1, pu, pj) + bh_z, g2 = get_partial<3>(PB, 2, pu, pj) + bh_n;
+            const int r1 = (bt + 1) % DRING;
+            publish4(xrs, (DXL(bi, L_GH, r1) + 256 * J) * 4, tid, g0, pj < nb);
+            publish4(xrs, (DXL(bi, L_GH + 1, r1) + 256 * J) * 4, tid, g1, pj < nb);
+            publish4(xrs, (DXL(bi, L_GH + 2, r1) + 256 * J) * 4, tid, g2, pj < nb);
+        } else {                                        // fc3 logits -> sample x_t (utils/distribution.py:102-121)
+            const int b0 = GEO[2 * bi];
+            {   // 30 logit rows x 16 segments: thread (row tid >> 4 and 16 + row, segment tid & 15)
+                const int row = tid >> 4, sj = tid & 15;
+                const float lg = get_partial<3>(PB, 0, row, sj) + b3a;
+                const float lg2 = get_partial<3>(PB, 1, row, sj) + b3b;
+                LOG[sj * DLOGS + row] = lg;
+                if (a.dbg_logits && sj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + sj) * C + row] = lg;
+                if (row < 14) {
+                    LOG[sj * DLOGS + 16 + row] = lg2;
+                    if (a.dbg_logits && sj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + sj) * C + 16 + row] = lg2;
+                }
+            }
+            lds_barrier();
+            {   // 16-lane row = one segment (su), lane sm = mixture; bc0 / bc1 = this thread's pre-transformed noise
+                const int su = tid >> 4, sm = tid & 15;
+                float best = (sm < 10) ? mol_gumbel_pre(LOG[su * DLOGS + sm], bc0) : -INFINITY;
+                int bidx = sm;
+                argmax_row16(best, bidx);
+                if (sm == 0 && su < nb) {
+                    float xv = mol_sample_pre(LOG[su * DLOGS + 10 + bidx], LOG[su * DLOGS + 20 + bidx], bc1);
+                    a.out[(size_t)(b0 + su) * a.T + bt] = xv;
+                    if (a.force_x) xv = a.force_x[(size_t)(b0 + su) * a.T + bt];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xv), xrs, su * 4, DXL(bi, 7, bt % DRING) * 4, 16 /* sc1 */);
+                }
+            }
+        }
+        bk = BK_NONE;
+        return true;
+    };
+
+    int ring = 0;
+    // kind 1: gh stage of slot i (polls h(t)); kind 3: sampling stage of my_slot (polls y2(t))
+    auto stage = [&](auto KC, int i) -> bool {
+        constexpr int kind = decltype(KC)::value;
+        const int nb = GEO[2 * i + 1];
+        float v0 = 0.f, v1 = 0.f;
+        float b[32];
+        bool ready = false;
+        if (xahead) ready = try_finish(lane, nb, x, b);
+        else issue(xrs, DXL(i, kind == 1 ? L_H : 3, ring) * 4, w, lane, x);
+        if (kind == 3) {
+            // this step's sampling noise, pre-transformed (wrnn_noise_mol_kernel): thread (segment tid >> 4, mixture tid & 15)
+            const int b0 = GEO[2 * i];
+            const int su = tid >> 4, sm = tid & 15;
+            const float *nrow = a.noise_pre + (size_t)(t - a.noise_t0) * 11 * Nall;
+            const int suc = su < nb ? su : nb - 1;
+            v0 = nrow[(size_t)(b0 + suc) * 10 + (sm < 10 ? sm : 9)];
+            v1 = nrow[(size_t)10 * Nall + b0 + suc];
+        }
+        if (!run_back()) return false;
+        {
+            unsigned spins = 0;
+            if (!ready) {
+                ok = ok && finish(xrs, DXL(i, kind == 1 ? L_H : 3, ring) * 4, w, lane, nb, x, b, a.status, spins);
+                if (!ok && fcode == 0u) fcode = 0x600u | (LA ? 0u : 8u) | (unsigned)kind;
+            }
+        }
+        const bool last = sampler ? (kind == 3) : (i == nact - 1);
+        if (last) {
+            // ring hygiene (see the header): drain, then re-arm this wave's words of entry (t + 4) % 8 -- its gh blocks of every
+            // slot (they are written again at step t + 3) and the x_t words of the slot it samples
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ringn = (t + DAHEAD) % DRING;
+#pragma unroll 1
+            for (int i2 = 0; i2 < nact; ++i2) duo_rearm(xrs, (DXL(i2, 0, ringn) + 256 * J + 64 * w) * 4, lane, L_GH, L_GH + 1, L_GH + 2, -1);
+            if (sampler && lane == 48) {                // the 4 x_t words this wave publishes (segments 4 w ..)
+                const u32x4 q = {SENT, SENT, SENT, SENT};
+                __builtin_amdgcn_raw_buffer_store_b128(q, xrs, 16 * w, DXL(my_slot, 7, ringn) * 4, 16 /* sc1 */);
+            }
+        }
+        {   // the next stage's polled layer, one stage ahead (not across a step boundary)
+            xahead = false;
+            if (kind == 1) {
+                if (i + 1 < nact) { xahead = true; issue(xrs, DXL(i + 1, L_H, ring) * 4, w, lane, x); }
+                else if (sampler) { xahead = true; issue(xrs, DXL(my_slot, 3, ring) * 4, w, lane, x); }
+            }
+        }
+        float *PW = DPARTOF(pp);
+        if (kind == 1) {
+            f32x4 o0, o1, o2;
+            mfma3(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
+            put_partial<3>(PW, w, 0, lane, o0);
+            put_partial<3>(PW, w, 1, lane, o1);
+            put_partial<3>(PW, w, 2, lane, o2);
+            bk = BK_GH;
+        } else {
+            put_partial<3>(PW, w, 0, lane, mfma1_glb(a.fc3f + frag_off(w, 0, lane), b));
+            put_partial<3>(PW, w, 1, lane, mfma1_glb(a.fc3f + XT + frag_off(w, 0, lane), b));
+            bk = BK_SAMPLE;
+        }
+        bi = i; bpp = pp; bt = t; bc0 = v0; bc1 = v1;
+        pp ^= 1;
+        return true;
+    };
+
+    for (; t < T1; ++t) {
+        ring = t % DRING;
+#pragma unroll 1
+        for (int i = 0; i < nact; ++i)
+            if (!stage(std::integral_constant<int, 1>{}, i)) goto bail;
+        if (sampler) {
+            if (!stage(std::integral_constant<int, 3>{}, my_slot)) goto bail;
+        }
+    }
+    if (!run_back()) goto bail;
+    return;
+bail:
+    if (fcode != 0u) report_failure(a.status, fcode, blockIdx.x, t, tid);
+}
+#undef DXL
+#undef DPARTOF
+
+// Grid = clusters x 128 workgroups of 256 threads (two per CU), cooperative launch.  Workgroup wg of a cluster: role wg & 3, unit
+// block wg >> 2.  Whole XCDs per cluster (speed only: nothing depends on the placement).
+__global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int cl, wg;
+    const int ncl = gridDim.x / DNWGC;
+    {
+        const int b = blockIdx.x, nblk = gridDim.x;
+        if (nblk % 8 == 0 && ncl >= 1 && 8 % ncl == 0) {
+            const int xpc = 8 / ncl, per_xcd = nblk / 8;
+            const int xcd = b % 8;
+            cl = xcd / xpc;
+            wg = (xcd % xpc) * per_xcd + b / 8;
+        } else {
+            cl = b / DNWGC;
+            wg = b % DNWGC;
+        }
+    }
+    const int role = wg & 3, J = wg >> 2;
+    if (role == 0) duo_ih<true, DUO_IH_XAHEAD>(a, smem, cl, J, ncl);
+    else if (role == 1) duo_ih<false, DUO_IH_XAHEAD>(a, smem, cl, J, ncl);
+    else if (role == 2) duo_hh<true>(a, smem, cl, J, ncl);
+    else duo_hh<false>(a, smem, cl, J, ncl);
+}
+
+size_t duo_lds_bytes(int G) { return (size_t)duo_lds(G).total * sizeof(float); }
+size_t duo_xbuf_bytes(int G) { return (size_t)G * MAXCL * DNX * DRING * XT * sizeof(float); }     // the slots a launch with depth G touches: a prefix
+size_t duo_xbuf_bytes_max() { return DXBUF_FLOATS * sizeof(float); }
+int duo_max_depth() { return LMAXG; }
+
+// clusters this device can host at two workgroups per CU (64 CUs per cluster, as wrnn_loop_kernel)
+int duo_clusters(int n_cus)
+{
+    int ncl = n_cus / LNWGC;
+    if (ncl > MAXCL) ncl = MAXCL;
+    while (ncl > 1 && (8 % ncl) != 0) --ncl;
+    return ncl;
+}
+
+hipError_t launch_duo(const LoopArgs &args, int ncl, hipStream_t stream)
+{
+    if (ncl < 1 || args.G < 1 || args.G > LMAXG || !args.fc3f) return hipErrorInvalidValue;
+    const size_t lds = duo_lds_bytes(args.G);
+    const void *fn = (const void *)wrnn_duo_kernel;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    LoopArgs a = args;
+    void *params[] = {(void *)&a};
+    return hipLaunchCooperativeKernel(fn, dim3(ncl * DNWGC), dim3(NT), params, (unsigned)lds, stream);
+}
+
+}  // namespace wrnn

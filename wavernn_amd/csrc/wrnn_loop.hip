@@ -36,21 +36,10 @@
 // accumulator chains per tile, partials added in wave order), so results are bit-identical to those kernels.
 #include <type_traits>
 
-#include "wrnn_tiles.h"
+#include "wrnn_ring.h"
 
 namespace wrnn {
 
-constexpr int LU = 16;                       // hidden units per workgroup
-constexpr int LNJ = H / LU;                  // workgroups per role per cluster (32)
-constexpr int LNWGC = 2 * LNJ;               // workgroups per cluster (64)
-constexpr int XT = SEG * H;                  // floats of one layer in fragment order (8192)
-constexpr unsigned SENT = 0xFFFFFFFFu;       // "not written yet"
-
-// LDS carve (floats).  Per group: GH[3][256], HOWN[256], XS[16], SP[32 ints] (segment table), FR[2][16 ints] (conditioning frame
-// of every segment at step t in FR[t & 1]; the other half is filled for step t+1 during step t)
-//   XO[256]: the owned 16 units x 16 segments of the residual input of this workgroup's GRU (role A: xi, role B: x1), in publish order
-constexpr int LGRP = 3 * 256 + 256 + 16 + 32 + 32 + 256;
-constexpr int O_HOWN = 768, O_XS = 1024, O_SP = 1040, O_FR = 1072, O_XO = 1104;
 constexpr int LOGS = 33;                     // row stride of the logits scratch (32 would put a column's 16 writers on one bank)
 constexpr int LPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][slot 0..2][16][16]
 struct LoopLds {
@@ -69,181 +58,6 @@ __host__ __device__ inline LoopLds loop_lds(int mode, int G)
     l.off_prof = o; o += 2 * 32;                           // [4 phases][8] u64 phase clocks (profiling builds)
     l.total = o;
     return l;
-}
-
-// workgroup barrier that hands over LDS only: waits for this wave's LDS traffic (lgkmcnt), not -- as __syncthreads() does through
-// its fences -- for every global load and store it has in flight (vmcnt)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// fragment-order offset (floats) of (wave w, k-block r, lane): 4 consecutive k of one segment
-__device__ __forceinline__ int frag_off(int w, int r, int lane) { return ((w * 8 + r) * 64 + lane) * 4; }
-
-// This wave's 8 B fragments of one exchanged layer (byte offset soff in the exchange buffer), as two halves so a stage can put
-// work between them: issue() fires the 8 buffer_load_dwordx4 (sc1); finish() checks that no word is still the sentinel and,
-// only if one is, falls into the polling loop (re-load, bounded spin).  Lanes of segments >= nb are not waited for (their
-// columns are garbage, used by nothing).  Wave-uniform result.
-__device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, int soff, int w, int lane, u32x4 (&x)[8])
-{
-    const int voff = frag_off(w, 0, lane) * 4;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + r * 1024, soff, 16 /* sc1 */);
-}
-// non-blocking form: true (and b filled) if the fragments already in x carry no sentinel
-__device__ __forceinline__ bool try_finish(int lane, int nb, const u32x4 (&x)[8], float (&b)[32])
-{
-    const bool live = (lane & 15) < nb;
-    unsigned m = 0u;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) m = max(max(m, max(x[r].x, x[r].y)), max(x[r].z, x[r].w));
-    if (!__all(m != SENT || !live)) return false;
-    // columns of absent segments (ragged last group) keep whatever the buffer holds -- the sentinel, a NaN: an MFMA column, the
-    // partial sums and the pointwise math are all per segment, nothing of an absent segment is ever published or written out
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        b[4 * r + 0] = __uint_as_float(x[r].x);
-        b[4 * r + 1] = __uint_as_float(x[r].y);
-        b[4 * r + 2] = __uint_as_float(x[r].z);
-        b[4 * r + 3] = __uint_as_float(x[r].w);
-    }
-    return true;
-}
-__device__ __forceinline__ bool finish(__amdgpu_buffer_rsrc_t rs, int soff, int w, int lane, int nb, u32x4 (&x)[8], float (&b)[32],
-                                       unsigned *status, unsigned &spins)
-{
-    const int voff = frag_off(w, 0, lane) * 4;
-    const bool live = (lane & 15) < nb;
-    spins = 0;
-    for (;;) {
-        // the sentinel is the largest unsigned value: ONE compare of the running maximum of the 32 words (a chain of v_max3_u32
-        // in the vector unit) instead of 32 compare / scalar-and pairs, which serialise on the VALU -> SALU hand-off
-        unsigned m = 0u;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) m = max(max(m, max(x[r].x, x[r].y)), max(x[r].z, x[r].w));
-        if (__all(m != SENT || !live)) break;
-        ++spins;
-        if ((spins & 255u) == 0u) {
-            if (spins > SPIN_LIMIT || ld_agent32(status) != 0u) return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + r * 1024, soff, 16 /* sc1 */);
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        b[4 * r + 0] = __uint_as_float(x[r].x);
-        b[4 * r + 1] = __uint_as_float(x[r].y);
-        b[4 * r + 2] = __uint_as_float(x[r].z);
-        b[4 * r + 3] = __uint_as_float(x[r].w);
-    }
-    return true;
-}
-
-// One value per thread (unit u = 4 (tid >> 6) + (tid & 3), segment j = (tid >> 2) & 15) -> the workgroup's 1 KB block of a
-// layer: the four units of a quad are gathered with DPP and stored by the quad's first lane as ONE 16-byte sc1 store.
-// `soff` = byte offset of the block in the exchange buffer; `on` = this quad publishes (segment live, rows owned).
-__device__ __forceinline__ void publish4(__amdgpu_buffer_rsrc_t rs, int soff /* bytes: layer + block */, int tid, float v, bool on)
-{
-    const int iv = __builtin_bit_cast(int, v);
-    const int v0 = __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xF, 0xF, true);     // quad_perm [0,0,0,0]
-    const int v1 = __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xF, 0xF, true);     // [1,1,1,1]
-    const int v2 = __builtin_amdgcn_update_dpp(0, iv, 0xAA, 0xF, 0xF, true);     // [2,2,2,2]
-    const int v3 = __builtin_amdgcn_update_dpp(0, iv, 0xFF, 0xF, 0xF, true);     // [3,3,3,3]
-    if (on && (tid & 3) == 0) {
-        const u32x4 q = {(unsigned)v0, (unsigned)v1, (unsigned)v2, (unsigned)v3};
-        __builtin_amdgcn_raw_buffer_store_b128(q, rs, (tid & ~3) * 4, soff, 16 /* sc1 */);
-    }
-}
-
-// Re-arm (fill with the sentinel) THIS WAVE's quarter (64 floats = 16 lanes x 16 bytes) of the workgroup's block in up to
-// four layers of a ring slot: lanes 0-15 layer la, 16-31 lb, 32-47 lc, 48-63 ld (< 0: none).  Each wave re-arms exactly the
-// words it later publishes, so its own program order + the vmcnt(0) drain at the end of the next step order re-arm before data.
-__device__ __forceinline__ void rearm(__amdgpu_buffer_rsrc_t rs, int soff_slot0 /* bytes: layer 0 of the slot + block + quarter */,
-                                      int lane, int la, int lb, int lc, int ld)
-{
-    const int which = lane >> 4;
-    const int layer = which == 0 ? la : (which == 1 ? lb : (which == 2 ? lc : ld));
-    if (layer >= 0) {
-        const u32x4 q = {SENT, SENT, SENT, SENT};
-        __builtin_amdgcn_raw_buffer_store_b128(q, rs, layer * (XRING * XT * 4) + (lane & 15) * 16, soff_slot0, 16 /* sc1 */);
-    }
-}
-
-// MFMA tiles with the B fragments already in registers; per tile the accumulation order is mfma_tile's (even r -> chain 0,
-// odd r -> chain 1, chain 0 + chain 1), so results are bit-identical to the LDS-operand forms of wrnn_tiles.h.
-__device__ __forceinline__ void mfma3(const float (&a0)[AF], const float (&a1)[AF], const float (&a2)[AF], const float (&b)[32],
-                                      f32x4 &o0, f32x4 &o1, f32x4 &o2)
-{
-    f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00, c20 = c00, c21 = c00;
-#pragma unroll
-    for (int r = 0; r < 8; r += 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + e], b[4 * r + e], c00, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + e], b[4 * r + e], c10, 0, 0, 0);
-            c20 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[4 * r + e], b[4 * r + e], c20, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + 4 + e], b[4 * r + 4 + e], c01, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + 4 + e], b[4 * r + 4 + e], c11, 0, 0, 0);
-            c21 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[4 * r + 4 + e], b[4 * r + 4 + e], c21, 0, 0, 0);
-        }
-    }
-    o0 = c00 + c01;
-    o1 = c10 + c11;
-    o2 = c20 + c21;
-}
-__device__ __forceinline__ f32x4 mfma1(const float (&a)[AF], const float (&b)[32])
-{
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-#pragma unroll
-    for (int r = 0; r < 8; r += 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + e], b[4 * r + e], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * r + 4 + e], b[4 * r + 4 + e], c1, 0, 0, 0);
-        }
-    }
-    return c0 + c1;
-}
-
-// one fc3 tile with the A operand in LDS (fragment order, this wave's slice at `a_lane`), B in registers; mfma_tile's order
-__device__ __forceinline__ f32x4 mfma1_lds(const float *a_lane /* F3 tile + frag_off(w, 0, lane) */, const float (&b)[32])
-{
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-#pragma unroll
-    for (int r = 0; r < 8; r += 2) {
-        const float4 a0 = *reinterpret_cast<const float4 *>(a_lane + 256 * r);
-        const float4 a1 = *reinterpret_cast<const float4 *>(a_lane + 256 * (r + 1));
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b[4 * r + 0], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b[4 * r + 4], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b[4 * r + 1], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b[4 * r + 5], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b[4 * r + 2], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b[4 * r + 6], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b[4 * r + 3], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b[4 * r + 7], c1, 0, 0, 0);
-    }
-    return c0 + c1;
-}
-
-// this wave's 8 conditioning fragments cI(t) of one group (plain loads: written by the previous kernel on the stream)
-__device__ __forceinline__ void load_cI(const float *cI_grp, int w, int lane, float4 (&c)[8])
-{
-    const float4 *cp = reinterpret_cast<const float4 *>(cI_grp + frag_off(w, 0, lane));
-#pragma unroll
-    for (int r = 0; r < 8; ++r) c[r] = cp[r * 64];
-}
-
-// xi(t) = W_I[:,0] * x_{t-1} + cI(t)   (fatchord_version.py:208-209 with the conditioning part hoisted), this wave's fragments
-__device__ __forceinline__ void make_xi(const float4 (&c)[8], const float *WI0, float xs, int w, int lane, float (&b)[32])
-{
-    const int k0 = KCH * w + 4 * (lane >> 4);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const float4 wv = *reinterpret_cast<const float4 *>(WI0 + k0 + 16 * r);
-        b[4 * r + 0] = fmaf(wv.x, xs, c[r].x);
-        b[4 * r + 1] = fmaf(wv.y, xs, c[r].y);
-        b[4 * r + 2] = fmaf(wv.z, xs, c[r].z);
-        b[4 * r + 3] = fmaf(wv.w, xs, c[r].w);
-    }
 }
 
 // The whole life of one workgroup in one role (compile-time, so the two roles are disjoint code with separate register
