@@ -378,6 +378,42 @@ def main():
                         'mfma_frac': round(2.0 * nnz * 8 * (plan.n_segments // n_utt) * T / (k8 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 5)}
                 except Exception as e:
                     res['config']['batch_of_8_utterances'] = {'error': repr(e)}
+        if not args.no_single and world == 1 and args.prune == 0 and args.corpus == 'batch' and mode == 'MOL':
+            # the other two single-GPU configurations of BASELINE.json on the SAME 16-utterance geometry, so that they are in the
+            # driver's record too: the bit-exact 9-bit mu-law mode (config 1's model, batched) and config 5 (95 % block-sparse GRUs)
+            def side_config(sd2, mode2, label):
+                try:
+                    m2 = WaveRNN(**SHIPPED, mode=mode2)
+                    m2.num_params = lambda *a, **k: 0
+                    m2.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd2.items()}, strict=True)
+                    m2 = m2.to(dev).eval()
+                    e2 = m2._loop_engine()
+
+                    def p2():
+                        generate_corpus(m2, mels, target, overlap, True, seeds, noise_source=noise_source, finish='own', check=False)
+                        e2.status()
+                    p2()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(2):
+                        p2()
+                    torch.cuda.synchronize()
+                    d = (time.perf_counter() - t0) / 2
+                    k2, i2 = e2.last_loop_ms(), e2.last_run_info()
+                    nnz2 = int(sum(np.count_nonzero(sd2[k]) for k in wkeys))
+                    out = {'what': label, 'mode': mode2, 'segments': n_local, 'samples_per_s': round(wave_total / d, 1),
+                           'realtime_factor': round(wave_total / d / SAMPLE_RATE, 2), 'ms_per_pass': round(d * 1e3, 3),
+                           'loop_kernel_ms': round(k2, 3), 'split': i2, 'weights_nnz': nnz2,
+                           'mfma_frac': round(2.0 * nnz2 * n_local * T / (k2 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 5)}
+                    del e2
+                    m2._engine = None
+                    return out
+                except Exception as e:
+                    return {'what': label, 'error': repr(e)}
+            res['config']['raw'] = side_config(random_state_dict(0, mode='RAW'), 'RAW', "9-bit mu-law ('bits', the bit-exact mode) on the same batch")
+            from wavernn_amd.prune import block_prune_state_dict
+            res['config']['config5'] = side_config(block_prune_state_dict(random_state_dict(0, mode='MOL'), 0.95, (16, 1))[0], 'MOL',
+                                                   'BASELINE config 5: GRU matrices 95 % block-sparse (16x1 blocks) on the same batch')
         if not args.no_cpu_baseline and world == 1:
             try:
                 res['cpu_baseline'] = cpu_baseline(sd, mode, args.frames, target, overlap, args.cpu_seconds)

@@ -199,7 +199,7 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
             eng = model._loop_engine() if loop_fn is None else None
             if noise_source == 'cpu':
                 nz = pack_noise(mode, plan, noise, clo, chi).to(device)
-            elif eng is not None and eng.plan(n_seg, T, algo=model.loop_algo)['kernel'] == 'wrnn_loop_kernel':
+            elif eng is not None and eng.plan(n_seg, T, algo=model.loop_algo)['kernel'] in ('wrnn_loop_kernel', 'wrnn_duo_kernel'):
                 # device noise in slices of steps (RAW is n_classes floats per segment-step): each slice continues the loop; at most
                 # `model.noise_chunk_bytes` of noise are resident (the same bound WaveRNN.generate() keeps)
                 from ._lib import ResidencyError

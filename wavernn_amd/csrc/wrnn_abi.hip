@@ -317,8 +317,8 @@ int enqueue_progress(const wrnn_options *o, int done, int T, int n, hipStream_t 
 }
 
 enum Kind { K_STREAM, K_LOOP, K_SPARSE, K_DUO };
-constexpr bool DUO_AUTO = false;     // `auto` picks wrnn_duo_kernel (flipped on once it is measured faster: profiles/r03*)
-constexpr int DUO_MIN_DEPTH = 2;
+constexpr bool DUO_AUTO = true;      // `auto` picks wrnn_duo_kernel from DUO_MIN_DEPTH groups in flight per cluster on: measured (profiles/r03g_probe_duo.json)
+constexpr int DUO_MIN_DEPTH = 4;     // 1.09x wrnn_loop_kernel at depth 4, 1.29x at depth 8; slower at depth 2 (its slot chain is one hop longer)
 
 // what a call will run: kernel, split, rounds, slab length
 struct Plan {
@@ -396,7 +396,8 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
             pl->kind = K_LOOP; pl->ncl = ncl; pl->G = g;
             // the two-workgroups-per-CU form (MOL): on request, or when `auto` has >= DUO_MIN_DEPTH groups in flight per cluster
             // (busy time bounds a step there; with fewer the latency of a slot's chain does, and the duo kernel's chain is one hop longer)
-            if (p->mode == WRNN_MODE_MOL && (algo == WRNN_ALGO_DUO || (algo == WRNN_ALGO_AUTO && DUO_AUTO && g >= DUO_MIN_DEPTH))) pl->kind = K_DUO;
+            if (p->mode == WRNN_MODE_MOL && (algo == WRNN_ALGO_DUO || (algo == WRNN_ALGO_AUTO && DUO_AUTO && g >= DUO_MIN_DEPTH && ncl == MAXCL)))
+                pl->kind = K_DUO;
             pl->rounds = (groups + ncl * g - 1) / (ncl * g);
             // balanced rounds of whole segments; every round is cut into <= ncl * g groups of <= 16
             pl->per_round = (B + pl->rounds - 1) / pl->rounds;
@@ -610,6 +611,15 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                 a.t0 = s0; a.t1 = s1; a.cI_t0 = s0; a.rb0 = rb0; a.Btot = nr; a.NG = ngr; a.resume = s0 > 0 ? 1 : 0;
                 if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
                 hipError_t e = duo ? launch_duo(a, pl.ncl, stream) : launch_loop(a, pl.ncl, p->mode, stream);
+                if (e == hipErrorCooperativeLaunchTooLarge && duo && o->algo == WRNN_ALGO_AUTO && info.launches == 0 && pl.t0 == 0) {
+                    // two workgroups per CU are not co-resident right now: `auto` falls back to the one-workgroup-per-CU kernel
+                    // (the workspace was sized for the larger of the two layouts)
+                    (void)hipGetLastError();
+                    wrnn_options o2 = *o;
+                    o2.algo = WRNN_ALGO_LOOP;
+                    return wrnn_generate_segments(p, B, T, seg_pos, seg_lim, L, hop, n_frames, mels_up, aux, noise, out, workspace,
+                                                  workspace_bytes, &o2, stream_);
+                }
                 if (e != hipSuccess) {
                     (void)hipGetLastError();
                     set_err("%s cooperative launch failed: %s", info.kernel, hipGetErrorString(e));

@@ -244,7 +244,7 @@ class WaveRNN(nn.Module):
             # the sampling noise is drawn and uploaded in slices of steps (RAW: B * n_classes floats per step), each slice
             # continuing the loop where the previous one stopped (wrnn_options.t_begin / t_end)
             per_step = B * (11 if self.mode == 'MOL' else self.n_classes) * 4
-            resumable = eng.plan(B, T, algo=self.loop_algo)['kernel'] == 'wrnn_loop_kernel'
+            resumable = eng.plan(B, T, algo=self.loop_algo)['kernel'] in ('wrnn_loop_kernel', 'wrnn_duo_kernel')
             chunk = max(1, min(T, self.noise_chunk_bytes // per_step)) if resumable else T
             chunk = -(-T // (-(-T // chunk)))                # equal slices (no short tail slice with its own launches)
             rng_state = torch.get_rng_state() if (self.noise_source == 'cpu' and chunk < T) else None
