@@ -268,6 +268,47 @@ int wrnn_post_unfold(const float *segments, int32_t T, int32_t n_utt, const int3
                      double *out, void *stream);
 const char *wrnn_post_last_error(void);
 
+/*
+ * DRAFT (never run on a GPU) -- BASELINE config 3's caller: the Tacotron decoder loop as one persistent kernel (SURVEY.md
+ * section 8 row f3).  Replaces the per-frame loop of `Tacotron.generate()` (reference models/tacotron.py:396-414) around
+ * `Decoder.forward` (:218-279) for one sentence; the encoder (:24-39, once per sentence) and the post-net stay with the caller.
+ * All pointers are DEVICE pointers to contiguous float32 tensors in the reference's state-dict layouts (`decoder.*`).
+ */
+typedef struct wrnn_taco_weights {
+    uint32_t struct_bytes;
+    int32_t n_mels, prenet1, prenet2, decoder_dims, encoder_width, lstm_dims, attn_filters, attn_kernel;   /* 80 256 128 256 256 512 32 31 */
+    const float *prenet_fc1_w, *prenet_fc1_b, *prenet_fc2_w, *prenet_fc2_b;               /* [256][80] [256] [128][256] [128] */
+    const float *attn_rnn_w_ih, *attn_rnn_w_hh, *attn_rnn_b_ih, *attn_rnn_b_hh;           /* GRUCell [768][384] [768][256] [768] [768] */
+    const float *attn_W_w, *attn_W_b, *attn_conv_w, *attn_L_w, *attn_L_b, *attn_v_w;      /* LSA: [256][256] [256] [32][2][31] [256][32] [256] [256] */
+    const float *rnn_input_w, *rnn_input_b;                                               /* [512][512] [512] */
+    const float *rnn1_w_ih, *rnn1_w_hh, *rnn1_b_ih, *rnn1_b_hh;                           /* LSTMCell [2048][512] x2, [2048] x2 */
+    const float *rnn2_w_ih, *rnn2_w_hh, *rnn2_b_ih, *rnn2_b_hh;
+    const float *mel_proj_w;                                                              /* [n_mels * max_r][512] */
+} wrnn_taco_weights;
+
+typedef struct wrnn_taco_call {
+    uint32_t struct_bytes;
+    int32_t n;               /* encoder positions (<= 1024) */
+    int32_t r, max_r;        /* frames per decoder step (decoder.r) / of the mel_proj view (:262) */
+    int32_t max_steps;       /* decoder steps at most (the reference's `steps` / r) */
+    float stop_threshold;    /* :411 */
+    const float *seq;        /* [n][256] encoder_seq (:403) */
+    const float *seq_proj;   /* [n][256] encoder_seq_proj (:404) */
+    float *mel_out;          /* [max_steps][n_mels][r]: frame block of every step */
+    float *scores_out;       /* [max_steps][n]: attention of every step (:413) */
+    int32_t *steps_done;     /* decoder steps run, including the one that met the stop test */
+    void *workspace;         /* wrnn_taco_workspace_bytes() */
+    size_t workspace_bytes;
+    void *stream;
+} wrnn_taco_call;
+
+size_t wrnn_taco_workspace_bytes(void);
+/* Asynchronous on `stream`.  WRNN_ERR_RESIDENCY if the cooperative grid is refused. */
+int wrnn_taco_decode(int device, const wrnn_taco_weights *w, const wrnn_taco_call *c);
+/* Synchronises `stream`; out4 = {failure flag, code, workgroup, barrier} of the decode that used `workspace` (all 0 = clean). */
+int wrnn_taco_status(const void *workspace, unsigned *out4, void *stream);
+const char *wrnn_taco_last_error(void);
+
 /* Self tests of the device primitives (MFMA fragment layout, inter-workgroup granule all-gather).
  * Synchronous.  WRNN_OK or an error with a message. */
 int wrnn_selftest(int device, int which);

@@ -57,3 +57,99 @@ def test_tacotron_graph_loop_and_vocoder_handoff(tmp_path):
     print(f'config 3 on one MI355X: Tacotron {steps} frames eager {t_eager * 1e3:.0f} ms / HIP-graph decoder loop {t_graph * 1e3:.0f} ms; '
           f'vocoder {t_voc * 1e3:.0f} ms (loop {voc.last_loop_kernel} {voc.last_loop_ms:.0f} ms) for {audio_s:.2f} s of audio = '
           f'{audio_s / (t_graph + t_voc):.1f}x real time end to end')
+
+
+def _tts(dev, seed=3, **override):
+    from wavernn_amd.synthetic import random_tacotron_state_dict
+    from wavernn_amd.tacotron import TacotronInference
+    shapes = json.load(open(os.path.join(HERE, 'golden', 'tacotron_shapes.json')))
+    sd = random_tacotron_state_dict(seed, shapes)
+    sd.update(override)
+    return TacotronInference(sd, device=dev)
+
+
+IDS_TEXT = 'Scientists at the CERN laboratory say they have discovered a new particle.'
+
+
+def test_tacotron_decoder_kernel_matches_the_cpu_mirror():
+    """the decoder loop as ONE persistent kernel (csrc/wrnn_taco.hip, `wrnn_taco_decode`) against (a) the same
+    `TacotronInference` run on the CPU -- which tests/test_tacotron_mirror.py pins bit-exactly to the reference's `Tacotron.generate`
+    (models/tacotron.py:370-430) -- and (b) its eager PyTorch-ROCm loop on the device.  The kernel sums K in another order and 200
+    recurrent steps amplify rounding: 1e-4 on the first 32 frames, the same trajectory (5e-2) on the rest; attention rows are
+    probability vectors."""
+    from wavernn_amd.tacotron import text_to_ids
+    dev = torch.device('cuda', 0)
+    ids = text_to_ids(IDS_TEXT)
+    steps = 200
+    mel_c, lin_c, attn_c = _tts('cpu').generate(ids, steps=steps)                 # the mirror of the reference, on the host
+    tts = _tts(dev)
+    mel_e, lin_e, attn_e = tts.generate(ids, steps=steps)
+    tts.generate(ids, steps=8, kernel=True)                                        # warm-up (module load, workspace)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mel_k, lin_k, attn_k = tts.generate(ids, steps=steps, kernel=True)
+    torch.cuda.synchronize()
+    t_k = time.perf_counter() - t0
+    assert mel_k.shape == mel_c.shape == (80, steps) and attn_k.shape == attn_c.shape
+    d = np.abs(mel_c - mel_k).max(axis=0)
+    de = np.abs(mel_e - mel_k).max(axis=0)
+    print(f'decoder kernel: {steps} frames in {t_k * 1e3:.1f} ms incl. encoder + post-net; max |d mel| per frame vs the CPU mirror', d[:4], '...', d[-4:],
+          'vs eager on the device', de[:4], '...', de[-4:])
+    assert d[:32].max() <= 1e-4, d[:32]
+    assert d.max() <= 5e-2 and np.abs(attn_c - attn_k).max() <= 5e-2
+    assert de[:32].max() <= 1e-4 and de.max() <= 5e-2
+    assert np.abs(lin_c - lin_k)[:, :32].max() <= 1e-3
+    np.testing.assert_allclose(attn_k.sum(axis=1), 1.0, atol=1e-5)
+
+
+def test_tacotron_decoder_kernel_stop_test_and_r():
+    """The stop test of models/tacotron.py:411 (`(mel_frames < stop_threshold).all() and t > 10`) is evaluated inside the kernel:
+    with a threshold every frame is below, the loop must end at the first t > 10 -- the same frame count as the eager loop and
+    the CPU mirror -- and with r = 2 frames per decoder step (the `[:, :, :r]` view of mel_proj, :262) the kernel still agrees."""
+    from wavernn_amd.tacotron import text_to_ids
+    dev = torch.device('cuda', 0)
+    ids = text_to_ids('Hello there.')
+    stop = dict(stop_threshold=torch.tensor(1e9))
+    mel_c, _, attn_c = _tts('cpu', **stop).generate(ids, steps=100)
+    tts = _tts(dev, **stop)
+    mel_e, _, _ = tts.generate(ids, steps=100)
+    mel_k, _, attn_k = tts.generate(ids, steps=100, kernel=True)
+    assert mel_c.shape == mel_e.shape == mel_k.shape == (80, 12), (mel_c.shape, mel_e.shape, mel_k.shape)      # t = 0 .. 11: the first t > 10
+    assert np.abs(mel_c - mel_k).max() <= 1e-4 and attn_k.shape == attn_c.shape
+    r2 = dict(r=torch.tensor(2))
+    if 'decoder.r' in _tts('cpu').p:
+        r2 = {'decoder.r': torch.tensor(2)}
+    mel_c, _, attn_c = _tts('cpu', **r2).generate(ids, steps=40)
+    mel_k, _, attn_k = _tts(dev, **r2).generate(ids, steps=40, kernel=True)
+    assert mel_c.shape == mel_k.shape == (80, 40) and attn_c.shape == attn_k.shape == (20, len(ids))
+    assert np.abs(mel_c - mel_k)[:, :16].max() <= 1e-4 and np.abs(mel_c - mel_k).max() <= 5e-2
+
+
+def test_config3_end_to_end_with_the_decoder_kernel(tmp_path):
+    """BASELINE config 3 end to end on one MI355X with the decoder loop as a persistent kernel: Tacotron (encoder + decoder kernel +
+    post-net) -> `_, m, _` (gen_tacotron.py:142) -> (m + 4) / 8, clip -> the HIP vocoder, timed."""
+    from wavernn_amd.model import WaveRNN
+    from wavernn_amd.synthetic import random_state_dict, SHIPPED
+    from wavernn_amd.tacotron import text_to_ids, tacotron_to_wavernn_mel
+    dev = torch.device('cuda', 0)
+    tts = _tts(dev)
+    ids = text_to_ids(IDS_TEXT)
+    voc = WaveRNN(**SHIPPED, mode='MOL')
+    voc.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in random_state_dict(0, mode='MOL').items()}, strict=True)
+    voc = voc.to(dev)
+    voc.noise_source = 'device'
+    steps = 800
+
+    def run():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, lin, _ = tts.generate(ids, steps=steps, kernel=True)
+        t1 = time.perf_counter()
+        wav = voc.generate(torch.tensor(tacotron_to_wavernn_mel(lin)).unsqueeze(0), tmp_path / 'o.wav', True, 11_000, 550, True)
+        return wav, t1 - t0, time.perf_counter() - t1
+    run()
+    wav, t_tts, t_voc = run()
+    assert wav.shape == ((steps - 1) * 275,) and np.isfinite(wav).all() and np.abs(wav).max() <= 1.0
+    audio_s = wav.shape[0] / 22050
+    print(f'config 3 end to end with the decoder kernel: Tacotron {t_tts * 1e3:.0f} ms ({steps} decoder steps) + vocoder {t_voc * 1e3:.0f} ms '
+          f'({voc.last_loop_kernel} {voc.last_loop_ms:.0f} ms) for {audio_s:.2f} s of audio = {audio_s / (t_tts + t_voc):.1f}x real time')

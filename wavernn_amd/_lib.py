@@ -24,7 +24,8 @@ EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_
            'wrnn_generate_segments', 'wrnn_plan_segments', 'wrnn_status', 'wrnn_timer_create', 'wrnn_timer_destroy', 'wrnn_timer_ms',
            'wrnn_timer_launches', 'wrnn_debug_read_exchange', 'wrnn_selftest', 'wrnn_selftest_metric', 'wrnn_pre_create',
            'wrnn_pre_destroy', 'wrnn_pre_hop', 'wrnn_pre_workspace_bytes', 'wrnn_pre_upsample', 'wrnn_pre_last_error',
-           'wrnn_post_unfold', 'wrnn_post_last_error']
+           'wrnn_post_unfold', 'wrnn_post_last_error', 'wrnn_taco_workspace_bytes', 'wrnn_taco_decode', 'wrnn_taco_status',
+           'wrnn_taco_last_error']
 
 
 class Weights(ctypes.Structure):
@@ -37,6 +38,27 @@ class PreWeights(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('feat_dims', 'compute_dims', 'res_out_dims', 'res_blocks', 'pad')] + \
                [('upsample_factors', ctypes.c_int32 * 3)] + \
                [(n, ctypes.c_void_p) for n in ('conv_in_w', 'bn_in', 'res_w', 'res_bn', 'conv_out_w', 'conv_out_b', 'up_w')]
+
+
+TACO_WEIGHT_FIELDS = ('prenet_fc1_w', 'prenet_fc1_b', 'prenet_fc2_w', 'prenet_fc2_b', 'attn_rnn_w_ih', 'attn_rnn_w_hh', 'attn_rnn_b_ih',
+                      'attn_rnn_b_hh', 'attn_W_w', 'attn_W_b', 'attn_conv_w', 'attn_L_w', 'attn_L_b', 'attn_v_w', 'rnn_input_w', 'rnn_input_b',
+                      'rnn1_w_ih', 'rnn1_w_hh', 'rnn1_b_ih', 'rnn1_b_hh', 'rnn2_w_ih', 'rnn2_w_hh', 'rnn2_b_ih', 'rnn2_b_hh', 'mel_proj_w')
+
+
+class TacoWeights(ctypes.Structure):
+    """wrnn_taco_weights (DRAFT: the Tacotron decoder kernel)."""
+    _fields_ = [('struct_bytes', ctypes.c_uint32)] + \
+               [(n, ctypes.c_int32) for n in ('n_mels', 'prenet1', 'prenet2', 'decoder_dims', 'encoder_width', 'lstm_dims', 'attn_filters',
+                                              'attn_kernel')] + \
+               [(n, ctypes.c_void_p) for n in TACO_WEIGHT_FIELDS]
+
+
+class TacoCall(ctypes.Structure):
+    """wrnn_taco_call."""
+    _fields_ = [('struct_bytes', ctypes.c_uint32), ('n', ctypes.c_int32), ('r', ctypes.c_int32), ('max_r', ctypes.c_int32),
+                ('max_steps', ctypes.c_int32), ('stop_threshold', ctypes.c_float), ('seq', ctypes.c_void_p), ('seq_proj', ctypes.c_void_p),
+                ('mel_out', ctypes.c_void_p), ('scores_out', ctypes.c_void_p), ('steps_done', ctypes.c_void_p),
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t), ('stream', ctypes.c_void_p)]
 
 
 class Geometry(ctypes.Structure):
@@ -145,6 +167,10 @@ def lib():
                                    ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                    ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     L.wrnn_post_last_error.restype = ctypes.c_char_p
+    L.wrnn_taco_workspace_bytes.restype = ctypes.c_size_t
+    L.wrnn_taco_decode.argtypes = [ctypes.c_int, ctypes.POINTER(TacoWeights), ctypes.POINTER(TacoCall)]
+    L.wrnn_taco_status.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32 * 4), ctypes.c_void_p]
+    L.wrnn_taco_last_error.restype = ctypes.c_char_p
     L.wrnn_status.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.wrnn_selftest.argtypes = [ctypes.c_int, ctypes.c_int]
     L.wrnn_selftest_metric.restype = ctypes.c_float

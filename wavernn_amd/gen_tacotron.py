@@ -1,6 +1,6 @@
 """`python -m wavernn_amd.gen_tacotron --input_text "..." --tts_weights tts.pyt --voc_weights voc.pyt` -- the `wavernn` vocoder
 path of the reference's TTS CLI (gen_tacotron.py:97-166) on one MI355X: Tacotron (functional PyTorch-ROCm restatement with a
-HIP-graph decoder loop, `tacotron.py`; `_, m, attention = tts_model.generate(x)` :142 -- the vocoder is fed the SECOND return,
+the decoder loop as one persistent HIP kernel, `tacotron.py` / csrc/wrnn_taco.hip; `_, m, attention = tts_model.generate(x)` :142 -- the vocoder is fed the SECOND return,
 the postnet / post_proj output, 80 bins because fft_bins = hp.num_mels) -> (m + 4) / 8, clip (:143-145) -> the MI355X-native `WaveRNN.generate` (:161-163).
 
 Flags follow the reference where they exist (--input_text/-i, --tts_weights, --batched/-b, --unbatched/-u, --target/-t,
@@ -52,7 +52,7 @@ def main(argv=None):
     for i, text in enumerate(texts, 1):
         print(f'\n| Generating {i}/{len(texts)}')
         t0 = time.perf_counter()
-        _, mel, _ = tts.generate(text_to_ids(text), steps=a.steps, graph=True, stop_check_every=32)   # the POSTNET output (:142)
+        _, mel, _ = tts.generate(text_to_ids(text), steps=a.steps, kernel=True)   # the POSTNET output (:142)
         t1 = time.perf_counter()
         m = torch.tensor(tacotron_to_wavernn_mel(mel)).unsqueeze(0)
         name = f'__input_{text[:10]}_{v_type}_{tts_k}k.wav' if a.input_text else f'{i}_{v_type}_{tts_k}k.wav'

@@ -135,8 +135,60 @@ class TacotronInference:
             st[k].copy_(v)
         return mels, scores
 
+    def _decode_kernel(self, seq, seq_proj, steps):
+        """DRAFT: the decoder loop (:396-414) as ONE persistent HIP kernel (csrc/wrnn_taco.hip) through the C ABI
+        (`wrnn_taco_decode`).  Returns (mel (1, n_mels, N) , attention (N / r, n)) device tensors; fails loudly without the
+        extension or a HIP device -- there is no host fallback."""
+        import ctypes
+        from . import _lib
+        dev = self.device
+        if dev.type != 'cuda':
+            raise _lib.WrnnError('the Tacotron decoder kernel needs a HIP device (no CPU fallback)')
+        L = _lib.lib()
+        p, q = self.p, 'decoder.'
+        names = dict(prenet_fc1_w='prenet.fc1.weight', prenet_fc1_b='prenet.fc1.bias', prenet_fc2_w='prenet.fc2.weight',
+                     prenet_fc2_b='prenet.fc2.bias', attn_rnn_w_ih='attn_rnn.weight_ih', attn_rnn_w_hh='attn_rnn.weight_hh',
+                     attn_rnn_b_ih='attn_rnn.bias_ih', attn_rnn_b_hh='attn_rnn.bias_hh', attn_W_w='attn_net.W.weight',
+                     attn_W_b='attn_net.W.bias', attn_conv_w='attn_net.conv.weight', attn_L_w='attn_net.L.weight',
+                     attn_L_b='attn_net.L.bias', attn_v_w='attn_net.v.weight', rnn_input_w='rnn_input.weight',
+                     rnn_input_b='rnn_input.bias', rnn1_w_ih='res_rnn1.weight_ih', rnn1_w_hh='res_rnn1.weight_hh',
+                     rnn1_b_ih='res_rnn1.bias_ih', rnn1_b_hh='res_rnn1.bias_hh', rnn2_w_ih='res_rnn2.weight_ih',
+                     rnn2_w_hh='res_rnn2.weight_hh', rnn2_b_ih='res_rnn2.bias_ih', rnn2_b_hh='res_rnn2.bias_hh',
+                     mel_proj_w='mel_proj.weight')
+        keep = {k: p[q + v].detach().to(dev, torch.float32).contiguous() for k, v in names.items()}
+        w = _lib.TacoWeights()
+        w.struct_bytes = ctypes.sizeof(_lib.TacoWeights)
+        w.n_mels, w.prenet1, w.prenet2 = self.n_mels, keep['prenet_fc1_w'].shape[0], keep['prenet_fc2_w'].shape[0]
+        w.decoder_dims, w.encoder_width, w.lstm_dims = self.decoder_dims, seq.size(2), self.lstm_dims
+        w.attn_filters, w.attn_kernel = keep['attn_conv_w'].shape[0], keep['attn_conv_w'].shape[2]
+        for k, tns in keep.items():
+            setattr(w, k, tns.data_ptr())
+        n = seq.size(1)
+        max_steps = (steps + self.r - 1) // self.r
+        seq_c, proj_c = seq[0].contiguous(), seq_proj[0].contiguous()
+        mel_out = torch.zeros(max_steps, self.n_mels, self.r, device=dev)
+        scores = torch.zeros(max_steps, n, device=dev)
+        done = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(int(L.wrnn_taco_workspace_bytes()), dtype=torch.uint8, device=dev)
+        c = _lib.TacoCall()
+        c.struct_bytes = ctypes.sizeof(_lib.TacoCall)
+        c.n, c.r, c.max_r, c.max_steps, c.stop_threshold = n, self.r, self.max_r, max_steps, self.stop_threshold
+        c.seq, c.seq_proj, c.mel_out, c.scores_out = seq_c.data_ptr(), proj_c.data_ptr(), mel_out.data_ptr(), scores.data_ptr()
+        c.steps_done, c.workspace, c.workspace_bytes = done.data_ptr(), ws.data_ptr(), ws.numel()
+        c.stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = L.wrnn_taco_decode(dev.index or 0, ctypes.byref(w), ctypes.byref(c))
+        if rc != _lib.WRNN_OK:
+            raise _lib.WrnnError(f'wrnn_taco_decode failed (rc={rc}): {L.wrnn_taco_last_error().decode()}')
+        st4 = (ctypes.c_uint32 * 4)()
+        rc = L.wrnn_taco_status(ws.data_ptr(), ctypes.byref(st4), c.stream)
+        if rc != _lib.WRNN_OK or st4[0] != 0:
+            raise _lib.WrnnError(f'Tacotron decoder kernel failed: status {list(st4)} {L.wrnn_taco_last_error().decode()}')
+        k = int(done.item())
+        mel = mel_out[:k].permute(1, 0, 2).reshape(1, self.n_mels, k * self.r)      # frames of step s at columns [s r, (s+1) r)
+        return mel, scores[:k]
+
     @torch.no_grad()
-    def generate(self, ids, steps=2000, graph=False, stop_check_every=1):
+    def generate(self, ids, steps=2000, graph=False, stop_check_every=1, kernel=False):
         """`Tacotron.generate(x, steps)` (:370-430).  Returns numpy (mel (n_mels, N), linear (fft, N), attention (N, n_chars)).
 
         graph=True (CUDA/HIP device): one decoder step is captured as a HIP graph and replayed; the stop test of :411 (`all
@@ -151,7 +203,10 @@ class TacotronInference:
                   c2=z(1, self.lstm_dims), context=z(1, self.decoder_dims), cumulative=z(1, n), attention=z(1, n))
         prenet_in = z(1, self.n_mels)                                              # the <GO> frame
         frames, scores_all = [], []
-        if graph and dev.type == 'cuda':
+        if kernel:
+            mel, scores_all = self._decode_kernel(seq, seq_proj, steps)
+            frames = [mel]
+        elif graph and dev.type == 'cuda':
             out_m, out_s = z(1, self.n_mels, self.r), z(1, n)
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -194,7 +249,7 @@ class TacotronInference:
         mel = torch.cat(frames, dim=2)
         post = self._cbhg(mel, 'postnet', self._post_k)
         linear = F.linear(post, self.p['post_proj.weight']).transpose(1, 2)[0]
-        attn = torch.cat([s.unsqueeze(-1).transpose(1, 2) for s in scores_all], 1)[0]
+        attn = scores_all if kernel else torch.cat([s.unsqueeze(-1).transpose(1, 2) for s in scores_all], 1)[0]
         return mel[0].cpu().numpy(), linear.cpu().numpy(), attn.cpu().numpy()
 
 
