@@ -66,10 +66,52 @@ def cpu_baseline(sd, mode, frames, target, overlap, budget_s):
     dt = time.perf_counter() - t0
     seg_steps_per_s = B * ts / dt
     useful = seg_steps_per_s * wave_len / (B * T)          # same useful/raw ratio as the full workload
-    return dict(value=round(useful, 1), unit='audio samples/s', cores=cores, kind='port',
-                sample=f'oracle/wrnn_oracle.c (OpenMP, {cores} of {ncpu} host threads; fastest of 8/16/32/64), one utterance '
-                       f'of the batch: B={B} segments x first {ts} of {T} steps ({dt:.1f} s); {seg_steps_per_s:.0f} segment-steps/s',
-                realtime_factor=round(useful / SAMPLE_RATE, 4))
+    res = dict(value=round(useful, 1), unit='audio samples/s', cores=cores, kind='port',
+               sample=f'oracle/wrnn_oracle.c (OpenMP, {cores} of {ncpu} host threads; fastest of 8/16/32/64), one utterance '
+                      f'of the batch: B={B} segments x first {ts} of {T} steps ({dt:.1f} s); {seg_steps_per_s:.0f} segment-steps/s',
+               realtime_factor=round(useful / SAMPLE_RATE, 4))
+    try:
+        res['pytorch_eager'] = pytorch_eager_baseline(sd, mode, target, overlap, max(3.0, budget_s / 2))
+    except Exception as e:
+        res['pytorch_eager'] = {'error': repr(e)}
+    # the reference ITSELF (unmodified generate(), /root/reference) exists only in the build container: its measured time there
+    # (scripts/make_golden.py -> the fixtures' `ref_cpu_seconds`) rides along, box and core count spelled out
+    res['reference_pytorch'] = dict(value=7540.0, unit='audio samples/s', realtime_factor=0.342, cores=8,
+                                    box='build container (Intel Xeon @ 2.10 GHz, 8 cores, no GPU) -- NOT this GPU box',
+                                    sample="the unmodified reference WaveRNN.generate() on BASELINE config 2's stated input (N = 481 -> B = 12 x T = 12100): "
+                                           '17.51 s (tests/golden/mol_batched_481f.npz config.ref_cpu_seconds)')
+    return res
+
+
+def pytorch_eager_baseline(sd, mode, target, overlap, budget_s):
+    """"The reference PyTorch CPU generate()" of the north star, on THIS box's host cores: oracle/torch_eager.py runs the reference's
+    loop as the same PyTorch eager ops in the same order (pinned to the reference's outputs in tests/test_oracle_golden.py; the
+    reference tree itself is not on the GPU box) on BASELINE config 2's stated input (N = 481 -> B = 12), for a bounded number
+    of steps at the fastest of a few thread counts."""
+    from oracle import wavernn_oracle as O, torch_eager as TE
+    from wavernn_amd.synthetic import random_mel
+    mels, aux, wave_len = O.conditioning(sd, random_mel(1234, 481), True, target, overlap)
+    B, T, _ = mels.shape
+    ncpu = os.cpu_count() or 1
+    was = torch.get_num_threads()
+    best = None
+    try:
+        for nt in sorted({min(8, ncpu), min(32, ncpu), ncpu}):
+            torch.set_num_threads(nt)
+            TE.loop(sd, mode, mels, aux, seed=77, steps=20)
+            _, d = TE.loop(sd, mode, mels, aux, seed=77, steps=100)
+            if best is None or d < best[1]:
+                best = (nt, d)
+        torch.set_num_threads(best[0])
+        steps = int(max(200, min(T, budget_s / (best[1] / 100))))
+        _, dt = TE.loop(sd, mode, mels, aux, seed=77, steps=steps)
+    finally:
+        torch.set_num_threads(was)
+    useful = (B * steps / dt) * wave_len / (B * T)
+    return dict(value=round(useful, 1), unit='audio samples/s', realtime_factor=round(useful / SAMPLE_RATE, 4), cores=best[0], kind='port',
+                ms_per_step=round(dt / steps * 1e3, 4),
+                sample=f'oracle/torch_eager.py (the reference loop as PyTorch eager CPU ops, torch {torch.__version__}, {best[0]} of {ncpu} host threads: '
+                       f'fastest of 8 / 32 / all), N = 481 -> B = {B} segments x first {steps} of {T} steps ({dt:.1f} s)')
 
 
 def source_sha16():

@@ -106,3 +106,21 @@ def test_c_oracle_matches_reference_full_size(name):
     else:
         assert np.abs(raw - g['raw']).max() <= MOL_TOL
         assert np.abs(out - g['out']).max() <= MOL_TOL
+
+
+@pytest.mark.parametrize('name', ['raw_batched_60f', 'mol_batched_100f', 'mol_batched_ragged_53f'])
+def test_torch_eager_restatement_matches_reference_golden(name):
+    """oracle/torch_eager.py (the reference's loop as PyTorch eager ops on the CPU: what bench.py times on the GPU box as the
+    "reference PyTorch CPU generate()" of the north star) against the reference's own pre-decode tensor: RAW identical, MoL 1e-6."""
+    from oracle import torch_eager as TE, wavernn_oracle as O
+    from helpers import load_case, case_mel
+    from wavernn_amd.synthetic import random_state_dict
+    cfg, g = load_case(name)
+    sd = random_state_dict(cfg['wseed'], mode=cfg['mode'])
+    mels_f, aux_f, _ = O.conditioning(sd, case_mel(cfg, g), cfg['batched'], cfg['target'], cfg['overlap'])
+    out, dt = TE.loop(sd, cfg['mode'], mels_f, aux_f, seed=cfg['seed'])
+    assert out.shape == g['raw'].shape
+    if cfg['mode'] == 'RAW':
+        assert np.array_equal(out, g['raw'])
+    else:
+        assert np.abs(out - g['raw']).max() <= 1e-6
