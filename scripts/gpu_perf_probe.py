@@ -38,7 +38,9 @@ VARS = {'auto': dict(algo='auto'), 'stream': dict(algo='stream'), 'g1': dict(alg
         'd1': dict(algo='duo', depth=1), 'd2': dict(algo='duo', depth=2), 'd3': dict(algo='duo', depth=3), 'd4': dict(algo='duo', depth=4),
         'd8': dict(algo='duo', depth=8), 'dauto': dict(algo='duo'), 'd4fill': dict(algo='duo', depth=4, tuning=4),
         'd8p': dict(algo='duo', depth=8, tuning=8), 'd8i': dict(algo='duo', depth=8, tuning=16), 'd8h': dict(algo='duo', depth=8, tuning=32),
-        'd8pi': dict(algo='duo', depth=8, tuning=24), 'd4p': dict(algo='duo', depth=4, tuning=8), 'd6': dict(algo='duo', depth=6), 'nola8': dict(algo='duo', depth=8, tuning=1)}
+        'd8pi': dict(algo='duo', depth=8, tuning=24), 'd4p': dict(algo='duo', depth=4, tuning=8), 'd6': dict(algo='duo', depth=6), 'nola8': dict(algo='duo', depth=8, tuning=1),
+        'g1nf': dict(algo='loop', depth=1, tuning=4), 'g2nf': dict(algo='loop', depth=2, tuning=4), 'g4nf': dict(algo='loop', depth=4, tuning=4),
+        'g2na': dict(algo='loop', depth=2, tuning=8), 'g4na': dict(algo='loop', depth=4, tuning=8), 'g4nfna': dict(algo='loop', depth=4, tuning=12)}
 rows = []
 for B in [int(x) for x in args.B.split(',')]:
     stride = 64

@@ -74,6 +74,7 @@ VARIANTS = {
     'loop-g2-slabs': dict(algo='loop', depth=2, slab_steps=97),       # several conditioning slabs: state saved / restored
     'loop-c1-g3': dict(algo='loop', clusters=1, depth=3, slab_steps=160),
     'loop-c2-g2': dict(algo='loop', clusters=2, depth=2),
+    'loop-c1-g3-nofuse': dict(algo='loop', clusters=1, depth=3, slab_steps=160, tuning=4),   # fused stages switched off
     # the two-workgroups-per-CU form (MOL only): same splits
     'duo': dict(algo='duo'),
     'duo-g1': dict(algo='duo', depth=1),
@@ -97,6 +98,7 @@ def test_device_selftests(gpu):
     _lib.check(L.wrnn_selftest(0, 1), 'mfma selftest')
     print(L.wrnn_last_error().decode())
     _lib.check(L.wrnn_selftest(0, 2), 'all-gather selftest')
+    _lib.check(L.wrnn_selftest(0, 3), 'tanh_sel == tanhf selftest')     # the fused stages' branch-free tanh, bit for bit
     print(L.wrnn_last_error().decode())
 
 
@@ -320,7 +322,8 @@ def test_generate_end_to_end(gpu, name, pre, tmp_path):
     assert np.array_equal(torch.empty(4).uniform_(0, 1).numpy(), st.uniform_(4, 0, 1))
 
 
-@pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'loop-c2-g2', 'duo', 'duo-g1', 'duo-g2-slabs', 'duo-c1-g3', 'duo-c2-g2'])
+@pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'loop-c2-g2', 'loop-c1-g3-nofuse', 'duo', 'duo-g1', 'duo-g2-slabs',
+                                     'duo-c1-g3', 'duo-c2-g2'])
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_many_segments_all_clusters(gpu, mode, variant):
     """46 folded segments (the last one zero-padded) = 3 groups: one per cluster, all three in flight on one cluster, two
@@ -341,6 +344,21 @@ def test_many_segments_all_clusters(gpu, mode, variant):
         assert bad.size == 0, f'first divergence at (b,t)={bad[0]}'
     else:
         assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
+
+
+@pytest.mark.parametrize('mode', ['MOL', 'RAW'])
+def test_fused_stages_equal_unfused_bitwise(gpu, mode):
+    """The fused stages (pointwise half of the previous group interleaved with the MFMA tiles; tanh without the library's
+    branch) change no bit: the same 46-segment run with wrnn_options.tuning bit 2 (no fusion) is identical."""
+    from wavernn_amd.engine import LoopEngine
+    cfg = dict(mode=mode, wseed=31, mseed=131, frames=100, batched=True, target=550, overlap=55, seed=91)
+    sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
+    eng = LoopEngine(sd, mode, device=gpu)
+    outs = []
+    for tuning in (0, 4, 8, 12):                     # 8: RAW sampled by role A alone (no alternation)
+        outs.append(eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
+                            torch.from_numpy(flat).to(gpu), 275, algo='loop', clusters=1, depth=3, tuning=tuning).cpu().numpy())
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
 
 
 @pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'duo', 'duo-g1', 'duo-g2-slabs', 'duo-c1-g3'])

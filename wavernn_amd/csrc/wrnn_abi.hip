@@ -30,6 +30,7 @@ hipError_t launch_sparse(const LoopArgs &args, int G, int ncl, int nbp, hipStrea
 int sparse_clusters(int n_cus);
 int selftest_mfma(char *msg, size_t n);
 int selftest_allgather(int n_cus, char *msg, size_t n, float *us_per_round);
+int selftest_tanh(char *msg, size_t n);
 }  // namespace wrnn
 
 using namespace wrnn;
@@ -732,6 +733,7 @@ extern "C" int wrnn_selftest(int device, int which)
     int rc;
     if (which == 1) rc = selftest_mfma(msg, sizeof msg);
     else if (which == 2) rc = selftest_allgather(cus, msg, sizeof msg, &g_selftest_metric);
+    else if (which == 3) rc = selftest_tanh(msg, sizeof msg);
     else { set_err("unknown selftest %d", which); return WRNN_ERR_ARG; }
     if (rc != 0) { set_err("selftest %d failed: %s", which, msg); return WRNN_ERR_KERNEL; }
     set_err("selftest %d ok: %s", which, msg);

@@ -110,6 +110,30 @@ __device__ __forceinline__ float gru_update(float gi_r, float gi_z, float gi_n, 
     return (h - n) * z + n;
 }
 
+// tanhf without the library's branch: both of its paths (|x| >= 0.625: 1 - 2 / (exp(2|x|) + 1) with the hardware reciprocal;
+// else the odd polynomial) with the library's own operations and constants, then a select -- the same instructions on the same
+// operands as __ocml_tanh_f32 (checked in the ISA), so bit-identical, and straight-line
+__device__ __forceinline__ float tanh_sel(float x)
+{
+    const float ax = fabsf(x);
+    const float e = expf(ax + ax);
+    const float ra = fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f, 1.0f);
+    const float x2 = x * x;
+    float p = fmaf(__uint_as_float(0xbbbac73du), x2, __uint_as_float(0x3ca908c9u));
+    p = fmaf(x2, p, __uint_as_float(0xbd5c1c4eu));
+    p = fmaf(x2, p, __uint_as_float(0x3e088382u));
+    p = fmaf(x2, p, __uint_as_float(0xbeaaaa99u));
+    const float rb = fmaf(x2, ax * p, ax);
+    return copysignf(!(ax < 0.625f) ? ra : rb, x);
+}
+__device__ __forceinline__ float gru_update_sel(float gi_r, float gi_z, float gi_n, float gh_r, float gh_z, float gh_n, float h)
+{
+    const float r = sigmoid_f(gh_r + gi_r);
+    const float z = sigmoid_f(gh_z + gi_z);
+    const float n = tanh_sel(gi_n + gh_n * r);
+    return (h - n) * z + n;
+}
+
 // utils/distribution.py:106-108  logit_probs - log(-log(u))
 __device__ __forceinline__ float mol_gumbel(float lp, float u) { return lp - logf(-logf(u)); }
 

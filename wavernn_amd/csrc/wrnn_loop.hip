@@ -1,5 +1,15 @@
 // wrnn_loop.hip -- the ROLE-SPLIT pipelined persistent WaveRNN loop kernel (MOL and RAW) for MI355X (gfx950 / CDNA4).
 //
+// Round 3 (measured: profiles/r03i_probe_fused_{mol,raw}.json; bit-identical results, tests/test_gpu_parity.py::test_fused_stages_equal_unfused_bitwise):
+//  (1) RAW: the sampling stages alternate between the roles with >= 2 groups in flight, as MoL's do (role B holds its 16 fc3 rows
+//      too, re-arms the logit rows of the slots it samples, hands x_t over through layer 7): 1.32x at depth 2, 1.43x at depth 4.
+//      wrnn_options.tuning bit 3 = role A alone, as before.
+//  (2) fused stages: the GATES / GH pointwise half of the previous GROUP is interleaved with the MFMA tiles of the next stage of
+//      the same phase (sched_group_barrier 1 MFMA : 6 / 2 VALU); branch-free tanh (tanh_sel: the library's two paths + select,
+//      same instructions), publish4_nb / issue_sel (stores / loads that must not happen go to an out-of-range buffer offset),
+//      frame-index write to a scratch LDS word.  On with >= 4 groups in flight (+1-2 %), off below (it costs 5-9 % at depth 2);
+//      tuning bit 2 switches it off everywhere.
+//
 // Replaces the `for i in range(seq_len)` loop of fatchord/WaveRNN `WaveRNN.generate()` (reference
 // models/fatchord_version.py:201-241) for one ROUND of folded segments (<= clusters x G groups of <= 16) over a range of
 // steps [t0, t1).  Second generation of the clustered design (wrnn_cluster.hip / wrnn_pipe.hip); what changed and why
@@ -118,7 +128,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     WI0[2 * tid] = a.I_w0[2 * tid];
     WI0[2 * tid + 1] = a.I_w0[2 * tid + 1];
     // fc3 -> LDS in A-fragment order: F3[tile s][wave][r][lane (row fi, k-quad kq)][4] = fc3_w[row(s, fi)][128 wave + 16 r + 4 kq ..]
-    for (int q = tid; q < ((roleA || MOL) ? (MOL ? 2 : 1) * (XT / 4) : 0); q += NT) {
+    for (int q = tid; q < (MOL ? 2 : 1) * (XT / 4); q += NT) {      // (both roles: with >= 2 groups in flight role B samples too)
         const int l6 = q & 63, r = (q >> 6) & 7, wv = (q >> 9) & 3, sidx = q >> 11;
         const int rfi = l6 & 15, rkq = l6 >> 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -179,11 +189,11 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     enum { BK_NONE = 0, BK_GATES, BK_GH, BK_RELU, BK_SAMPLE };
     // the exchanged layer a stage polls, by phase (role A phase 0 polls nothing: xi comes from the conditioning slab)
     auto stage_layer = [](int ph) -> int { return roleA ? (ph == 1 ? 0 : (ph == 2 ? 6 : 3)) : (ph == 0 ? 5 : (ph == 1 ? 1 : (ph == 2 ? 2 : 3))); };
-    constexpr int NPH = (roleA || MOL) ? 4 : 3;
+    constexpr int NPH = 4;
     // Who runs fc3 + sampling (phase 3) for slot i.  Only role A needs x_t (for xi), so one group in flight (and RAW) is sampled by
     // role A; with >= 2 groups in flight the MOL sampling stages ALTERNATE -- even slots role A, odd slots role B, which hands
     // x_t to role A through a 16-word exchange layer -- so both roles run 3.5 stages per group-step instead of 4 and 3.
-    const bool alternate = MOL && nact >= 2;
+    const bool alternate = nact >= 2 && (MOL || (a.tuning & 8) == 0);      // (tuning bit 3: RAW sampled by role A alone, as before)
     auto samples = [&](int i) -> bool { return alternate ? (((i & 1) == 0) == roleA) : roleA; };
     // last stage of a step this workgroup executes (the ring hygiene point)
     const int last_ph = (alternate || roleA) ? 3 : 2;
@@ -203,8 +213,44 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     u32x4 x[8];                                          // fragments of the polled layer; issued ONE STAGE AHEAD (before the previous
     bool xahead = false;                                 // stage's MFMA tiles) whenever that stage is in the same step
     const bool lookahead = (a.tuning & 1) == 0, full_fence = (a.tuning & 2) != 0;      // A/B switches (wrnn_options.tuning)
+    // fused stages (below): measured (profiles/r03i_probe_fused_*.json) 1-2 % faster with >= 4 groups in flight, 5-9 % SLOWER with 2 (the
+    // publish of a fused half leaves later, inside the MFMA block, and at depth 2 a step is bound by the latency of that chain)
+    const bool fuse_on = (a.tuning & 4) == 0 && nact >= 4;
     int bk = BK_NONE, bi = 0, bpp = 0, bt = 0, cur_ph = 0;
     float bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
+
+    // The pending half of kind K (GATES / GH; the short RELU half is not worth it) as straight-line code -- no barrier, no branch: stores that must not happen go
+    // to a dropped buffer offset / a scratch LDS word -- so that it can be interleaved with the MFMA tiles of the next stage.
+    auto pointwise_straight = [&](auto KC) {
+        constexpr int K = decltype(KC)::value;
+        float *GP = smem + bi * LGRP;
+        const float *PB = PARTOF(bpp);
+        const int nb = GEO[2 * bi + 1];
+        const int bring = bt % XRING;
+        if constexpr (K == BK_GATES) {
+            const float gir = get_partial<3>(PB, 0, pu, pj) + bc0;
+            const float giz = get_partial<3>(PB, 1, pu, pj) + bc1;
+            const float gin = get_partial<3>(PB, 2, pu, pj) + bc2;
+            const float xo = GP[O_XO + tid];
+            const float hn = gru_update_sel(gir, giz, gin, GP[tid], GP[256 + tid], GP[512 + tid], GP[O_HOWN + tid]);
+            GP[O_HOWN + tid] = hn;
+            publish4_nb(xrs, (XLAYER(bi, roleA ? 0 : 1, bring) + 256 * J) * 4, tid, hn, pj < nb);
+            publish4_nb(xrs, (XLAYER(bi, roleA ? 5 : 6, bring) + 256 * J) * 4, tid, xo + hn, pj < nb);
+        } else if constexpr (K == BK_GH) {
+            const float g0 = get_partial<3>(PB, 0, pu, pj), g1 = get_partial<3>(PB, 1, pu, pj), g2 = get_partial<3>(PB, 2, pu, pj);
+            const int *SP = reinterpret_cast<const int *>(GP + O_SP);
+            const int sl = tid & (SEG - 1);
+            const int p1 = SP[sl] + bt + 1;
+            const int fr = (p1 < SP[SEG + sl]) ? (p1 / a.hop) : a.NF;
+            int *frp = tid < SEG ? reinterpret_cast<int *>(GP + O_FR) + SEG * ((bt + 1) & 1) + tid : FAIL + 8;   // FAIL[8]: scratch word
+            GP[tid] = g0 + bh_r;
+            GP[256 + tid] = g1 + bh_z;
+            GP[512 + tid] = g2 + bh_n;
+            *frp = fr;
+        } else static_assert(K == BK_GATES || K == BK_GH, "fusable kinds");
+
+        bk = BK_NONE;
+    };
 
     // KINDS: bit mask (1 << BK_*) of the halves that can be pending at the call site (compile-time: every site inlines only those,
     // and RAW's heavy sampling half exists at one site only)
@@ -379,6 +425,8 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                                 if (leader) a.out[(size_t)(b0 + sj) * a.T + bt] = x;
                                 if (a.force_x) x = a.force_x[(size_t)(b0 + sj) * a.T + bt];
                                 XS[sj] = x;
+                                if (!roleA && leader)                                       // role B sampled this slot: hand x_t to role A
+                                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), xrs, sj * 4, XLAYER(bi, 7, bring) * 4, 16 /* sc1 */);
                             }
                         }
                     }
@@ -427,6 +475,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
         const int xl = stage_layer(ph);
         float b[32];
         bool ready = false;
+        int la_soff = 0;
         if (polled) {
             if (xahead) ready = try_finish(lane, nb, x, b);
             else issue(xrs, XLAYER(i, xl, ring) * 4, w, lane, x);
@@ -459,7 +508,18 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
         }
         PH(8 * ph + 0);
         // ---------------- the previous stage's back half -------------------------------------------------------------
-        if (!run_back(std::integral_constant<unsigned, KM>{})) return false;
+        // FUSED when it is this phase's own kind (the previous GROUP's half: no data in common with this stage) and this stage's
+        // operands are here: only its barrier runs now, its pointwise math + publish are interleaved with this stage's MFMA tiles
+        // below (the wave issues in order and is alone on its SIMD: otherwise the VALU idles through every 96-MFMA block and the
+        // MFMA pipe through every pointwise half).
+        constexpr int KOWN = ph == 0 ? BK_GATES : BK_GH;       // (phases 0, 1 only)
+        const bool fuse = fuse_on && ph < 2 && bk == KOWN && (!polled || ready);
+        if (fuse) {
+            if (!ok) FAIL[0] = 1;
+            lds_barrier();
+            if (FAIL[0] != 0) return false;
+            PH(8 * ph + 1);
+        } else if (!run_back(std::integral_constant<unsigned, KM>{})) return false;
         // ---------------- front, part 2: operands -> MFMA tiles -> this wave's partial tiles -----------------------
         if (polled) {
             unsigned spins = 0;
@@ -485,7 +545,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
             for (int i2 = 0; i2 < nact; ++i2)
             {
                 rearm(xrs, (XLAYER(i2, 0, ringn) + 256 * J + 64 * w) * 4, lane, roleA ? 0 : 1, roleA ? 2 : 3, roleA ? 5 : 6,
-                      (!MOL && roleA) ? 4 : -1);
+                      (!MOL && samples(i2)) ? 4 : -1);       // RAW: the logit rows this role publishes for the slots it samples
                 if (!roleA && leader && alternate && (i2 & 1) && lane == 48) {   // the 4 x_t words this wave publishes (segments 4 w ..)
                     const u32x4 q = {SENT, SENT, SENT, SENT};
                     __builtin_amdgcn_raw_buffer_store_b128(q, xrs, 16 * w, XLAYER(i2, 7, ringn) * 4, 16 /* sc1 */);
@@ -500,7 +560,10 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                 if (++ni >= nact) { ++nph; ni = 0; }
             } while (nph == 3 && nph < NPH && !samples(ni));
             xahead = lookahead && nph < NPH && !(roleA && nph == 0) && (MOL || nph != 3);
-            if (xahead) issue(xrs, XLAYER(ni, stage_layer(nph), ring) * 4, w, lane, x);
+            la_soff = XLAYER(ni, stage_layer(nph < NPH ? nph : 0), ring) * 4;
+            // a fused GATES half publishes inside the MFMA block: the look-ahead loads are issued there, AFTER its stores
+            // (vmcnt retires in order -- the next stage's wait for these loads must not also wait for younger stores)
+            if (xahead && !(fuse && ph == 0)) issue(xrs, la_soff, w, lane, x);
         }
         if (roleA && ph == 0) {
             float xs = GP[O_XS + fi];
@@ -523,8 +586,18 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
         float *PW = PARTOF(pp);
         if (ph == 0 || (ph == 1)) {                                          // three gate tiles of W_ih (ph 0) / W_hh (ph 1)
             f32x4 o0, o1, o2;
-            if (ph == 0) mfma3(A_ih[0], A_ih[1], A_ih[2], b, o0, o1, o2);
-            else mfma3(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
+            if (fuse) {
+                if constexpr (ph < 2) {
+                    pointwise_straight(std::integral_constant<int, KOWN>{});
+                    if (ph == 0) issue_sel(xrs, la_soff, w, lane, x, xahead);
+                    if (ph == 0) mfma3(A_ih[0], A_ih[1], A_ih[2], b, o0, o1, o2);
+                    else mfma3(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
+                    interleave_mfma_valu<96, (ph == 0 ? 6 : 2)>();
+                }
+            } else {
+                if (ph == 0) mfma3(A_ih[0], A_ih[1], A_ih[2], b, o0, o1, o2);
+                else mfma3(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
+            }
             put_partial<3>(PW, w, 0, lane, o0);
             put_partial<3>(PW, w, 1, lane, o1);
             put_partial<3>(PW, w, 2, lane, o2);

@@ -35,6 +35,13 @@ __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, int soff, int w
 #pragma unroll
     for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + r * 1024, soff, 16 /* sc1 */);
 }
+// issue() without a branch: with on == false the eight loads go to an out-of-range offset (they return zeros, nobody reads them)
+__device__ __forceinline__ void issue_sel(__amdgpu_buffer_rsrc_t rs, int soff, int w, int lane, u32x4 (&x)[8], bool on)
+{
+    const int voff = frag_off(w, 0, lane) * 4 + (on ? 0 : 0x7FFF0000);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + r * 1024, soff, 16 /* sc1 */);
+}
 // non-blocking form: true (and b filled) if the fragments already in x carry no sentinel
 __device__ __forceinline__ bool try_finish(int lane, int nb, const u32x4 (&x)[8], float (&b)[32])
 {
@@ -98,6 +105,32 @@ __device__ __forceinline__ void publish4(__amdgpu_buffer_rsrc_t rs, int soff /* 
     if (on && (tid & 3) == 0) {
         const u32x4 q = {(unsigned)v0, (unsigned)v1, (unsigned)v2, (unsigned)v3};
         __builtin_amdgcn_raw_buffer_store_b128(q, rs, (tid & ~3) * 4, soff, 16 /* sc1 */);
+    }
+}
+
+// publish4 without a branch: quads that do not publish store to an out-of-range buffer offset (the buffer unit drops it), so the
+// store can sit inside one scheduling region with the MFMA tiles of the next stage (fused stages)
+__device__ __forceinline__ void publish4_nb(__amdgpu_buffer_rsrc_t rs, int soff, int tid, float v, bool on)
+{
+    const int iv = __builtin_bit_cast(int, v);
+    const int v0 = __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xF, 0xF, true);
+    const int v1 = __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xF, 0xF, true);
+    const int v2 = __builtin_amdgcn_update_dpp(0, iv, 0xAA, 0xF, 0xF, true);
+    const int v3 = __builtin_amdgcn_update_dpp(0, iv, 0xFF, 0xF, 0xF, true);
+    const u32x4 q = {(unsigned)v0, (unsigned)v1, (unsigned)v2, (unsigned)v3};
+    const int voff = (on && (tid & 3) == 0) ? (tid & ~3) * 4 : 0x7FFFFFF0;      // past num_records: dropped
+    __builtin_amdgcn_raw_buffer_store_b128(q, rs, voff, soff, 16 /* sc1 */);
+}
+
+// 1 MFMA : NV VALU, N times (the fused stages' interleave: the wave issues in order, so the pointwise instructions have to sit
+// BETWEEN the MFMAs -- up to 7 fit in the 32 cycles one 16x16x4 f32 MFMA occupies the pipe)
+template <int N, int NV>
+__device__ __forceinline__ void interleave_mfma_valu()
+{
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
     }
 }
 

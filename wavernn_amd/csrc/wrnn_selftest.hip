@@ -3,6 +3,7 @@
 //      (asymmetric operands, so a transposed fragment layout cannot pass).
 //   2. granule all-gather: NWG co-resident workgroups publish + sweep {tag,value} granules for many rounds,
 //      every word checked, bounded spins; reports microseconds per round.
+//   3. tanh_sel (the branch-free tanh of the fused stages) == tanhf, bit for bit, over a dense sweep of arguments.
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -59,6 +60,33 @@ int selftest_mfma(char *msg, size_t n)
         }
     snprintf(msg, n, "mfma tile max abs err %.3e", worst);
     return worst < 1e-3 ? 0 : 1;
+}
+
+// ---- tanh_sel == tanhf ---------------------------------------------------------------------------------
+// 2^24 arguments: every 2^8-th float bit pattern of both signs (all exponents, NaN / inf / denormals included)
+__global__ void selftest_tanh_kernel(unsigned *mismatches, unsigned *first)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float x = __uint_as_float(i << 8 | (i & 0xFFu));
+    const unsigned a = __float_as_uint(tanhf(x)), b = __float_as_uint(tanh_sel(x));
+    const bool nan_both = (a & 0x7FFFFFFFu) > 0x7F800000u && (b & 0x7FFFFFFFu) > 0x7F800000u;
+    if (a != b && !nan_both) {
+        if (atomicAdd(mismatches, 1u) == 0u) *first = __float_as_uint(x);
+    }
+}
+
+int selftest_tanh(char *msg, size_t n)
+{
+    unsigned *d, h[2] = {0u, 0u};
+    if (hipMalloc(&d, 8) != hipSuccess) { snprintf(msg, n, "hipMalloc failed"); return 1; }
+    hipMemcpy(d, h, 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(selftest_tanh_kernel, dim3(1u << 16), dim3(256), 0, 0, d, d + 1);
+    hipError_t e = hipDeviceSynchronize();
+    hipMemcpy(h, d, 8, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) { snprintf(msg, n, "kernel failed: %s", hipGetErrorString(e)); return 1; }
+    snprintf(msg, n, "tanh_sel vs tanhf over 2^24 arguments: %u bit mismatches (first at 0x%08x)", h[0], h[1]);
+    return h[0] == 0u ? 0 : 1;
 }
 
 // ---- all-gather ------------------------------------------------------------------------------------
