@@ -19,8 +19,12 @@ ap.add_argument('--prune', type=float, default=0.0, help='block-prune the GRU ma
 ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'probe.json'))
 ap.add_argument('--B', default='12,24,64,128,192,256,512')
 ap.add_argument('--variants', default='auto,g1,g2,g4,g8')
+ap.add_argument('--so', default=None, help='A/B builds: load this libwavernn_amd*.so instead of the in-tree one')
 args = ap.parse_args()
 
+if args.so:
+    from wavernn_amd import _lib as _L
+    _L.SO_PATH = os.path.abspath(args.so)
 dev = torch.device('cuda', 0)
 mode, T, hop = args.mode, args.T, 275
 sd = random_state_dict(0, mode=mode)

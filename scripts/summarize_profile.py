@@ -93,8 +93,11 @@ for k, cs in pmc.items():
             if g(c) is not None:
                 lines.append(f'* {c} / SQ_WAVE_CYCLES = {g(c) / wc:.3f}')
         if g('SQ_VALU_MFMA_BUSY_CYCLES') is not None:
-            lines.append(f'* MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_WAVE_CYCLES) = '
-                         f'{g("SQ_VALU_MFMA_BUSY_CYCLES") / (4 * wc):.3f}  (one wave per SIMD)')
+            # SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD, SQ_WAVE_CYCLES quad-cycles per WAVE: with n waves per SIMD the SIMD-time
+            # is 4 * SQ_WAVE_CYCLES / n (grid threads / 64 lanes / 1024 SIMDs of the chip)
+            wps = max(1.0, float(meta[k]['grid']) / 64.0 / 1024.0)
+            lines.append(f'* MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_WAVE_CYCLES / {wps:g} waves per SIMD) = '
+                         f'{g("SQ_VALU_MFMA_BUSY_CYCLES") * wps / (4 * wc):.3f}')
     if g('TCC_HIT_sum') is not None:
         lines.append(f'* L2 hit rate = {g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")):.4f}')
     lines.append('')

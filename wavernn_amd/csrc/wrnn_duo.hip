@@ -55,6 +55,12 @@ constexpr int DPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][slo
 #define DUO_FC_LDS 0
 #endif
 //   DUO_FAST_PW   1 = hardware exp / rcp in the GRU pointwise math (gru_update_fast), 0 = the library forms (gru_update, as wrnn_loop.hip)
+//   DUO_PUBLISH_FIRST 1 = a stage starts with the previous stage's back half (barrier, pointwise, PUBLISH) and only then issues its own
+//                 loads: the publication leaves ~1 k cycles earlier per hop, which is what bounds a step when the slots' chains are
+//                 not hidden (<= 4 groups in flight); 0 = loads first, as wrnn_loop.hip (better latency hiding when busy-bound)
+#ifndef DUO_PUBLISH_FIRST
+#define DUO_PUBLISH_FIRST 1
+#endif
 #ifndef DUO_FAST_PW
 #define DUO_FAST_PW 1
 #endif
@@ -367,6 +373,10 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, int cl, i
         bool ready = false;
         cur = ph == 0 ? 0 : 8;
         if (PROF && tid == 0 && plast == 0) plast = __builtin_amdgcn_s_memtime();
+#if DUO_PUBLISH_FIRST
+        // ---------------- the previous stage's back half FIRST: its publication is what the next hop of its slot's chain waits for ----------------
+        if (!run_back()) return false;
+#endif
         if (polled) {
             if (DUO_IH_XAHEAD && xa == 1) ready = try_finish(lane, nb, x, b);
             else issue(xrs, DXL(i, xl, ring) * 4, w, lane, x);
@@ -394,8 +404,10 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, int cl, i
             v0 = (LA ? a.c3f : a.c4f)[(size_t)fr * H + prow];
         }
         PH(cur + 0);
+#if !DUO_PUBLISH_FIRST
         // ---------------- the previous stage's back half ----------------
         if (!run_back()) return false;
+#endif
         // ---------------- operands -> MFMA tiles -> this wave's partial tiles ----------------
         if (polled) {
             unsigned spins = 0;
@@ -655,6 +667,9 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
         bool ready = false;
         cur = kind == 1 ? 0 : 8;
         if (PROF && tid == 0 && plast == 0) plast = __builtin_amdgcn_s_memtime();
+#if DUO_PUBLISH_FIRST
+        if (!run_back()) return false;
+#endif
         if (xahead) ready = try_finish(lane, nb, x, b);
         else issue(xrs, DXL(i, kind == 1 ? L_H : 3, ring) * 4, w, lane, x);
         if (kind == 3) {
@@ -667,7 +682,9 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
             v1 = nrow[(size_t)10 * Nall + b0 + suc];
         }
         PH(cur + 0);
+#if !DUO_PUBLISH_FIRST
         if (!run_back()) return false;
+#endif
         {
             unsigned spins = 0;
             if (!ready) {
