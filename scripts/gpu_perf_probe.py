@@ -43,6 +43,8 @@ VARS = {'auto': dict(algo='auto'), 'stream': dict(algo='stream'), 'g1': dict(alg
         'd8': dict(algo='duo', depth=8), 'dauto': dict(algo='duo'), 'd4fill': dict(algo='duo', depth=4, tuning=4),
         'd8p': dict(algo='duo', depth=8, tuning=8), 'd8i': dict(algo='duo', depth=8, tuning=16), 'd8h': dict(algo='duo', depth=8, tuning=32),
         'd8pi': dict(algo='duo', depth=8, tuning=24), 'd4p': dict(algo='duo', depth=4, tuning=8), 'd6': dict(algo='duo', depth=6), 'nola8': dict(algo='duo', depth=8, tuning=1),
+        'd4l1': dict(algo='duo', depth=4, tuning=1 << 9), 'd4l2': dict(algo='duo', depth=4, tuning=2 << 9), 'd4l3': dict(algo='duo', depth=4, tuning=3 << 9), 'd4l4': dict(algo='duo', depth=4, tuning=4 << 9),
+        'd8l2': dict(algo='duo', depth=8, tuning=2 << 9), 'd8l3': dict(algo='duo', depth=8, tuning=3 << 9), 'd8l4': dict(algo='duo', depth=8, tuning=4 << 9), 'd8l7': dict(algo='duo', depth=8, tuning=7 << 9),
         'g1nf': dict(algo='loop', depth=1, tuning=4), 'g2nf': dict(algo='loop', depth=2, tuning=4), 'g4nf': dict(algo='loop', depth=4, tuning=4),
         'g2na': dict(algo='loop', depth=2, tuning=8), 'g4na': dict(algo='loop', depth=4, tuning=8), 'g4nfna': dict(algo='loop', depth=4, tuning=12)}
 rows = []

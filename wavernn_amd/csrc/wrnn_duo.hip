@@ -61,6 +61,10 @@ constexpr int DPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][slo
 #ifndef DUO_PUBLISH_FIRST
 #define DUO_PUBLISH_FIRST 1
 #endif
+//   DUO_FC_LAG    the fc stage of slot k - lag follows the gate stage of slot k (see duo_ih's main loop)
+#ifndef DUO_FC_LAG
+#define DUO_FC_LAG 8       // (measured, profiles/r03m_probe_lag.json: the plain order wins at depth 4 and 8; lag 1-2 cost 9-17 %)
+#endif
 #ifndef DUO_FAST_PW
 #define DUO_FAST_PW 1
 #endif
@@ -495,15 +499,25 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, int cl, i
         return true;
     };
 
+    // Order of a step's stages: the gate stage of slot k, then the fc stage of slot k - lag.  lag = nact is wrnn_loop.hip's order (all
+    // gate stages, then all fc stages); a small lag lets a slot's fc stage run as soon as its operand (two hops behind the slot's
+    // gate stage) can be there instead of behind the gate stages of every other slot -- the slots' chains, which bound a step
+    // with <= 4 groups in flight, get shorter.  wrnn_options.tuning bits 9-11: lag (0 = the default)
+    int lag = (a.tuning >> 9) & 7;
+    if (lag == 0) lag = DUO_FC_LAG;
+    if (lag > nact || DUO_IH_XAHEAD) lag = nact;        // (the ih look-ahead variant assumes the plain order)
     for (; t < T1; ++t) {
         ring = t % DRING;
         tc = t - a.cI_t0;
 #pragma unroll 1
-        for (int i = 0; i < nact; ++i)
-            if (!stage(std::integral_constant<int, 0>{}, i)) goto bail;
-#pragma unroll 1
-        for (int i = 0; i < nact; ++i)
-            if (!stage(std::integral_constant<int, 2>{}, i)) goto bail;
+        for (int k = 0; k < nact + lag; ++k) {
+            if (k < nact) {
+                if (!stage(std::integral_constant<int, 0>{}, k)) goto bail;
+            }
+            if (k >= lag) {
+                if (!stage(std::integral_constant<int, 2>{}, k - lag)) goto bail;
+            }
+        }
     }
     if (!run_back()) goto bail;
     // ---- what the next launch of this round needs from the ring: gh(T1) of every slot (published during step T1 - 1) -> the saved
