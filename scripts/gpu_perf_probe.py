@@ -45,6 +45,7 @@ VARS = {'auto': dict(algo='auto'), 'stream': dict(algo='stream'), 'g1': dict(alg
         'd8pi': dict(algo='duo', depth=8, tuning=24), 'd4p': dict(algo='duo', depth=4, tuning=8), 'd6': dict(algo='duo', depth=6), 'nola8': dict(algo='duo', depth=8, tuning=1),
         'd4l1': dict(algo='duo', depth=4, tuning=1 << 9), 'd4l2': dict(algo='duo', depth=4, tuning=2 << 9), 'd4l3': dict(algo='duo', depth=4, tuning=3 << 9), 'd4l4': dict(algo='duo', depth=4, tuning=4 << 9),
         'd8l2': dict(algo='duo', depth=8, tuning=2 << 9), 'd8l3': dict(algo='duo', depth=8, tuning=3 << 9), 'd8l4': dict(algo='duo', depth=8, tuning=4 << 9), 'd8l7': dict(algo='duo', depth=8, tuning=7 << 9),
+        'g2ns': dict(algo='loop', depth=2, tuning=16), 'g4ns': dict(algo='loop', depth=4, tuning=16), 'g8ns': dict(algo='loop', depth=8, tuning=16),
         'g1nf': dict(algo='loop', depth=1, tuning=4), 'g2nf': dict(algo='loop', depth=2, tuning=4), 'g4nf': dict(algo='loop', depth=4, tuning=4),
         'g2na': dict(algo='loop', depth=2, tuning=8), 'g4na': dict(algo='loop', depth=4, tuning=8), 'g4nfna': dict(algo='loop', depth=4, tuning=12)}
 rows = []

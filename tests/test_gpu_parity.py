@@ -355,7 +355,7 @@ def test_fused_stages_equal_unfused_bitwise(gpu, mode):
     sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
     eng = LoopEngine(sd, mode, device=gpu)
     outs = []
-    for tuning in (0, 4, 8, 12):                     # 8: RAW sampled by role A alone (no alternation)
+    for tuning in (0, 4, 8, 12, 16, 20):             # 4: no fused stages; 8: RAW sampled by role A alone; 16: RAW sampled redundantly by every workgroup of the role
         outs.append(eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride,
                             torch.from_numpy(flat).to(gpu), 275, algo='loop', clusters=1, depth=3, tuning=tuning).cpu().numpy())
     assert all(np.array_equal(outs[0], o) for o in outs[1:])

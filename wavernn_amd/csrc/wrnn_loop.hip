@@ -195,6 +195,16 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     // x_t to role A through a 16-word exchange layer -- so both roles run 3.5 stages per group-step instead of 4 and 3.
     const bool alternate = nact >= 2 && (MOL || (a.tuning & 8) == 0);      // (tuning bit 3: RAW sampled by role A alone, as before)
     auto samples = [&](int i) -> bool { return alternate ? (((i & 1) == 0) == roleA) : roleA; };
+    // RAW with alternating roles: the softmax + Categorical sampling of a slot (16 segments x 512 classes, 2 KB of noise per segment
+    // and step) runs REDUNDANTLY in all 32 workgroups of the sampling role; in `solo` form every workgroup of that role still publishes its 16
+    // logit rows, but ONE of them (unit block (slot >> 1) % 32: a different one per slot) gathers the logits, samples and hands x_t
+    // to the role-A workgroups through the 16-word layer 7 -- for every slot, not only the role-B-sampled ones.  MEASURED
+    // (profiles/r03n_probe_raw_solo.json): no faster -- 54.9 vs 54.3 us per step at depth 4: a RAW step is bound by the latency of a
+    // slot's chain through the sampling stage, not by the busy time of the 31 workgroups this relieves -- so it is OFF unless
+    // tuning bit 4 asks for it (it does cut the noise reads 32-fold).
+    const bool solo = !MOL && alternate && (a.tuning & 16) != 0;
+    auto sole = [&](int i) -> bool { return samples(i) && J == ((i >> 1) & (LNJ - 1)); };
+    auto from_ring = [&](int i) -> bool { return alternate && ((i & 1) || solo); };      // role A reads x_{t-1} of slot i from layer 7
     // last stage of a step this workgroup executes (the ring hygiene point)
     const int last_ph = (alternate || roleA) ? 3 : 2;
     const int last_i = !alternate ? nact - 1 : (roleA ? ((nact - 1) & ~1) : (((nact - 1) & 1) ? nact - 1 : nact - 2));
@@ -327,6 +337,9 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                 }
             } else {
                 const size_t tn = (size_t)(bt - a.noise_t0);
+                if (solo && !sole(bi)) {                 // not this slot's sampler: publish the owned logit rows, done
+                    publish4(xrs, (XLAYER(bi, 4, bring) + 256 * J) * 4, tid, get_partial<3>(PB, 0, pu, pj) + b3a, pj < nb);
+                } else {
                 // this wave samples segments 4 w .. 4 w + 3 (clamped to the group: a ragged group re-does its last segment, results
                 // discarded): their Exp(1) variates are requested FIRST, so the 2 KB per segment arrive behind the logit exchange
                 float qn[4][8];
@@ -367,7 +380,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                             mx[s4] = fmaxf(mx[s4], lg[s4][e]);
                         }
                     }
-                    if (a.dbg_logits && leader) {
+                    if (a.dbg_logits && (leader || solo)) {
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4)
                             if (4 * w + s4 < nb)
@@ -422,16 +435,17 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                             const int sj = 4 * w + s4;
                             if (sj < nb) {
                                 float x = 2.f * (float)bidx[s4] / ((float)C - 1.f) - 1.f;
-                                if (leader) a.out[(size_t)(b0 + sj) * a.T + bt] = x;
+                                if (leader || solo) a.out[(size_t)(b0 + sj) * a.T + bt] = x;
                                 if (a.force_x) x = a.force_x[(size_t)(b0 + sj) * a.T + bt];
                                 XS[sj] = x;
-                                if (!roleA && leader)                                       // role B sampled this slot: hand x_t to role A
+                                if (solo || (!roleA && leader))                             // hand x_t to the role-A workgroups
                                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), xrs, sj * 4, XLAYER(bi, 7, bring) * 4, 16 /* sc1 */);
                             }
                         }
                     }
                 }
                 lds_barrier();                         // LGT is read by every wave before the next group overwrites it
+                }
             }
             // x_t is read by EVERY wave in this slot's first stage of the next step.  When this sampling half is the one that runs
             // inside that very stage (role A's last sampling stage of a step is slot 0's: one group in flight, or two with
@@ -485,7 +499,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
             if (ph == 0) {
                 v0 = bi_r; v1 = bi_z; v2 = bi_n;
                 load_cI(cIg, w, lane, c);
-                if (alternate && (i & 1) && t > T0)      // x_{t-1} of a slot role B sampled (at the first step of a launch: from the state)
+                if (from_ring(i) && t > T0)              // x_{t-1} of a slot sampled elsewhere (at the first step of a launch: from the state)
                     xtw = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, XLAYER(i, 7, (t + 3) % XRING) * 4, 16 /* sc1 */);
             }
             else if (ph == 2) v0 = a.c3f[(size_t)reinterpret_cast<const int *>(GP + O_FR)[SEG * (t & 1) + pj] * H + prow];
@@ -546,7 +560,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
             {
                 rearm(xrs, (XLAYER(i2, 0, ringn) + 256 * J + 64 * w) * 4, lane, roleA ? 0 : 1, roleA ? 2 : 3, roleA ? 5 : 6,
                       (!MOL && samples(i2)) ? 4 : -1);       // RAW: the logit rows this role publishes for the slots it samples
-                if (!roleA && leader && alternate && (i2 & 1) && lane == 48) {   // the 4 x_t words this wave publishes (segments 4 w ..)
+                if ((solo ? sole(i2) : (!roleA && leader && alternate && (i2 & 1))) && lane == 48) {   // the 4 x_t words this wave publishes (segments 4 w ..)
                     const u32x4 q = {SENT, SENT, SENT, SENT};
                     __builtin_amdgcn_raw_buffer_store_b128(q, xrs, 16 * w, XLAYER(i2, 7, ringn) * 4, 16 /* sc1 */);
                 }
@@ -567,7 +581,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
         }
         if (roleA && ph == 0) {
             float xs = GP[O_XS + fi];
-            if (alternate && (i & 1) && t > T0) {
+            if (from_ring(i) && t > T0) {
                 ok = ok && poll_xt(i, (t + 3) % XRING, nb, xtw);
                 if (!ok && fcode == 0u) fcode = 0x400u | 0x20u;
                 xs = (fi < nb) ? __uint_as_float(xtw) : 0.f;
@@ -647,7 +661,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     if (!run_back(std::integral_constant<unsigned, (roleA ? KM_SAMPLE : (KM_SAMPLE | (1u << BK_RELU)))>{})) goto bail;
     if (roleA && alternate && T1 > T0) {                                // x_{T1-1} of the slots role B sampled -> this launch's saved state
 #pragma unroll 1
-        for (int i = 1; i < nact; i += 2) {
+        for (int i = solo ? 0 : 1; i < nact; i += solo ? 1 : 2) {
             const int nb = GEO[2 * i + 1];
             unsigned v = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, XLAYER(i, 7, (T1 - 1) % XRING) * 4, 16 /* sc1 */);
             ok = ok && poll_xt(i, (T1 - 1) % XRING, nb, v);
