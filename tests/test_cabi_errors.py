@@ -35,7 +35,7 @@ def test_pack_create_argument_checks(L):
     sd = random_state_dict(1, mode='MOL')
     pack = ctypes.c_void_p()
     assert L.wrnn_pack_create(None, 0, ctypes.byref(pack)) == ERR_ARG
-    for over, needle in ((dict(rnn_dims=256), b'rnn_dims=fc_dims=512'), (dict(n_classes=31), b'MOL needs n_classes == 30'),
+    for over, needle in ((dict(rnn_dims=4096), b'unsupported dims'), (dict(n_classes=31), b'MOL needs n_classes == 30'),
                          (dict(mode=7), b'unknown mode'), (dict(fc2_w=None), b'NULL weight pointer')):
         w, keep = _weights(sd, 'MOL', **over)
         assert L.wrnn_pack_create(ctypes.byref(w), 0, ctypes.byref(pack)) == ERR_ARG

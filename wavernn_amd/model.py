@@ -216,8 +216,17 @@ class WaveRNN(nn.Module):
         mels = torch.as_tensor(mels, device=device)
         wave_len = (mels.size(-1) - 1) * self.hop_length
         if self.pre_algo == 'native' and device.type == 'cuda':
-            mels_up, aux = self._pre_engine().upsample(mels.float())
-            return mels_up, aux, wave_len
+            try:
+                mels_up, aux = self._pre_engine().upsample(mels.float())
+                return mels_up, aux, wave_len
+            except _lib.WrnnError as e:
+                # the HIP pre-loop kernels are built for the shipped upsample hparams (feat 80, compute = res_out = 128, pad 2); any
+                # other UpsampleNetwork runs through the nn.Modules below on the device (PyTorch-ROCm / MIOpen) -- still no CPU path
+                if 'this build supports' not in str(e):
+                    raise
+                import warnings
+                warnings.warn(f'wavernn_amd: {e}; up-sampling with the PyTorch-ROCm modules instead')
+                self.pre_algo = 'torch'
         m = _fold.pad_tensor(mels.transpose(1, 2), pad=self.pad, side='both').transpose(1, 2)
         mels_up = self.upsample.upsample_mel(m)[0].contiguous()
         aux = self.upsample.aux_frames(m)[0].transpose(0, 1).contiguous()
