@@ -166,8 +166,8 @@ def _sweep_case(sd, mode, n, T, seed):
 @pytest.mark.parametrize('mode,algo', [('MOL', 'loop'), ('RAW', 'loop'), ('MOL', 'duo')])
 @pytest.mark.parametrize('clusters', [1, 4])
 def test_every_depth_the_planner_can_pick(gpu, mode, clusters, algo):
-    """Depth 4, 5, 6, 7, 8 groups in flight per cluster x {1, 4} clusters x {MOL, RAW}, value-checked against the C oracle at
-    short T.  Segment counts are chosen so that some clusters run `depth` slots and the others `depth - 1` (both parities of
+    """Depth 4, 5, 6, 7, 8 groups in flight per cluster (and 3 for wrnn_duo_kernel, the shallowest depth `auto` picks it
+    at) x {1, 4} clusters x {MOL, RAW}, value-checked against the C oracle at short T.  Segment counts are chosen so that some clusters run `depth` slots and the others `depth - 1` (both parities of
     the number of active slots in one launch: the `last_i` / alternate-sampling branches of wrnn_loop.hip, incl. last slots
     sampled by role B), the last group is ragged (5 segments), three segments end inside the run, and three conditioning
     slabs are crossed (state saved / restored with role-B-sampled x_t in flight)."""
@@ -176,7 +176,7 @@ def test_every_depth_the_planner_can_pick(gpu, mode, clusters, algo):
     sd = random_state_dict(0, mode=mode)
     eng = LoopEngine(sd, mode, device=gpu)
     T = 264 if mode == 'MOL' else 72
-    for depth in (4, 5, 6, 7, 8):
+    for depth in ((3,) if algo == 'duo' else ()) + (4, 5, 6, 7, 8):
         # clusters == 4: groups = 4 (depth - 1) + 2 -> clusters 0, 1 run `depth` slots, clusters 2, 3 `depth - 1`
         groups = depth if clusters == 1 else 4 * (depth - 1) + 2
         n = 16 * (groups - 1) + 5

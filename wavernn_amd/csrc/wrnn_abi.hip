@@ -360,8 +360,8 @@ int enqueue_progress(const wrnn_options *o, int done, int T, int n, hipStream_t 
 }
 
 enum Kind { K_STREAM, K_LOOP, K_SPARSE, K_DUO, K_GENERIC };
-constexpr bool DUO_AUTO = true;      // `auto` picks wrnn_duo_kernel from DUO_MIN_DEPTH groups in flight per cluster on: measured (profiles/r03g_probe_duo.json)
-constexpr int DUO_MIN_DEPTH = 4;     // 1.09x wrnn_loop_kernel at depth 4, 1.29x at depth 8; slower at depth 2 (its slot chain is one hop longer)
+constexpr bool DUO_AUTO = true;      // `auto` picks wrnn_duo_kernel from DUO_MIN_DEPTH groups in flight per cluster on: measured (profiles/r03p_probe_min_depth.json)
+constexpr int DUO_MIN_DEPTH = 3;     // 1.15x wrnn_loop_kernel at depth 3 and 4, 1.29x at depth 8; 0.94x at depth 2 (its slot chain is one hop longer)
 
 // what a call will run: kernel, split, rounds, slab length
 struct Plan {
