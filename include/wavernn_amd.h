@@ -300,6 +300,9 @@ typedef struct wrnn_taco_call {
     void *workspace;         /* wrnn_taco_workspace_bytes() */
     size_t workspace_bytes;
     void *stream;
+    int32_t variant;         /* 0 = auto; 1 = the flag-barrier kernel (weights re-read from L2 every step, any CU count);
+                                2 = the register-resident kernel (128 co-resident workgroups, tagged exchange, r <= 8);
+                                3 = 2 with per-layer shader clocks of workgroup 0 in the last 24 x 8 bytes of the workspace */
 } wrnn_taco_call;
 
 size_t wrnn_taco_workspace_bytes(void);
@@ -308,6 +311,20 @@ int wrnn_taco_decode(int device, const wrnn_taco_weights *w, const wrnn_taco_cal
 /* Synchronises `stream`; out4 = {failure flag, code, workgroup, barrier} of the decode that used `workspace` (all 0 = clean). */
 int wrnn_taco_status(const void *workspace, unsigned *out4, void *stream);
 const char *wrnn_taco_last_error(void);
+
+/* The bidirectional GRU that ends a CBHG (reference models/tacotron.py:95, applied at :137: `x, _ = self.rnn(x)`), one sequence,
+ * hidden size 128 (encoder and post-net of the reference's hparams): one persistent workgroup per direction with W_hh in
+ * registers.  gi_* = W_ih x + b_ih for all frames (a plain GEMM: the caller's).  Errors: wrnn_taco_last_error(). */
+typedef struct wrnn_bigru_call {
+    uint32_t struct_bytes;
+    int32_t T, hidden;                       /* frames; 128 */
+    const float *gi_fwd, *gi_rev;            /* [T][3 hidden] (gates r, z, n as in nn.GRU) */
+    const float *w_hh_fwd, *w_hh_rev;        /* [3 hidden][hidden] */
+    const float *b_hh_fwd, *b_hh_rev;        /* [3 hidden] */
+    float *out;                              /* [T][2 hidden]: forward | reverse, as nn.GRU(bidirectional=True) returns */
+    void *stream;
+} wrnn_bigru_call;
+int wrnn_bigru(int device, const wrnn_bigru_call *c);
 
 /* Self tests of the device primitives (MFMA fragment layout, inter-workgroup granule all-gather).
  * Synchronous.  WRNN_OK or an error with a message. */

@@ -1,0 +1,2 @@
+export TMPDIR=/tmp; mkdir -p gpurun_out
+timeout 500 python -m pytest tests/test_gpu_config3.py -q -x -s 2>&1 | grep -v "^Trainable\|amdgpu.ids" | grep -i "decoder kernel\|config 3\|passed\|failed\|error\|assert" | cut -c1-600 | head -40

@@ -71,8 +71,10 @@ def _tts(dev, seed=3, **override):
 IDS_TEXT = 'Scientists at the CERN laboratory say they have discovered a new particle.'
 
 
-def test_tacotron_decoder_kernel_matches_the_cpu_mirror():
-    """the decoder loop as ONE persistent kernel (csrc/wrnn_taco.hip, `wrnn_taco_decode`) against (a) the same
+@pytest.mark.parametrize('variant', [2, 1], ids=['resident', 'flag-barrier'])
+def test_tacotron_decoder_kernel_matches_the_cpu_mirror(variant):
+    """the decoder loop as ONE persistent kernel (csrc/wrnn_taco.hip, `wrnn_taco_decode`; both forms: the
+    register-resident kernel with the tagged exchange that `auto` picks on a >= 128-CU device, and the flag-barrier kernel) against (a) the same
     `TacotronInference` run on the CPU -- which tests/test_tacotron_mirror.py pins bit-exactly to the reference's `Tacotron.generate`
     (models/tacotron.py:370-430) -- and (b) its eager PyTorch-ROCm loop on the device.  The kernel sums K in another order and 200
     recurrent steps amplify rounding: 1e-4 on the first 32 frames, the same trajectory (5e-2) on the rest; attention rows are
@@ -84,16 +86,16 @@ def test_tacotron_decoder_kernel_matches_the_cpu_mirror():
     mel_c, lin_c, attn_c = _tts('cpu').generate(ids, steps=steps)                 # the mirror of the reference, on the host
     tts = _tts(dev)
     mel_e, lin_e, attn_e = tts.generate(ids, steps=steps)
-    tts.generate(ids, steps=8, kernel=True)                                        # warm-up (module load, workspace)
+    tts.generate(ids, steps=8, kernel=True, kernel_variant=variant)                # warm-up (module load, workspace)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    mel_k, lin_k, attn_k = tts.generate(ids, steps=steps, kernel=True)
+    mel_k, lin_k, attn_k = tts.generate(ids, steps=steps, kernel=True, kernel_variant=variant)
     torch.cuda.synchronize()
     t_k = time.perf_counter() - t0
     assert mel_k.shape == mel_c.shape == (80, steps) and attn_k.shape == attn_c.shape
     d = np.abs(mel_c - mel_k).max(axis=0)
     de = np.abs(mel_e - mel_k).max(axis=0)
-    print(f'decoder kernel: {steps} frames in {t_k * 1e3:.1f} ms incl. encoder + post-net; max |d mel| per frame vs the CPU mirror', d[:4], '...', d[-4:],
+    print(f'decoder kernel (variant {variant}): {steps} frames in {t_k * 1e3:.1f} ms incl. encoder + post-net; max |d mel| per frame vs the CPU mirror', d[:4], '...', d[-4:],
           'vs eager on the device', de[:4], '...', de[-4:])
     assert d[:32].max() <= 1e-4, d[:32]
     assert d.max() <= 5e-2 and np.abs(attn_c - attn_k).max() <= 5e-2
@@ -102,7 +104,8 @@ def test_tacotron_decoder_kernel_matches_the_cpu_mirror():
     np.testing.assert_allclose(attn_k.sum(axis=1), 1.0, atol=1e-5)
 
 
-def test_tacotron_decoder_kernel_stop_test_and_r():
+@pytest.mark.parametrize('variant', [2, 1], ids=['resident', 'flag-barrier'])
+def test_tacotron_decoder_kernel_stop_test_and_r(variant):
     """The stop test of models/tacotron.py:411 (`(mel_frames < stop_threshold).all() and t > 10`) is evaluated inside the kernel:
     with a threshold every frame is below, the loop must end at the first t > 10 -- the same frame count as the eager loop and
     the CPU mirror -- and with r = 2 frames per decoder step (the `[:, :, :r]` view of mel_proj, :262) the kernel still agrees."""
@@ -113,16 +116,45 @@ def test_tacotron_decoder_kernel_stop_test_and_r():
     mel_c, _, attn_c = _tts('cpu', **stop).generate(ids, steps=100)
     tts = _tts(dev, **stop)
     mel_e, _, _ = tts.generate(ids, steps=100)
-    mel_k, _, attn_k = tts.generate(ids, steps=100, kernel=True)
+    mel_k, _, attn_k = tts.generate(ids, steps=100, kernel=True, kernel_variant=variant)
     assert mel_c.shape == mel_e.shape == mel_k.shape == (80, 12), (mel_c.shape, mel_e.shape, mel_k.shape)      # t = 0 .. 11: the first t > 10
     assert np.abs(mel_c - mel_k).max() <= 1e-4 and attn_k.shape == attn_c.shape
     r2 = dict(r=torch.tensor(2))
     if 'decoder.r' in _tts('cpu').p:
         r2 = {'decoder.r': torch.tensor(2)}
     mel_c, _, attn_c = _tts('cpu', **r2).generate(ids, steps=40)
-    mel_k, _, attn_k = _tts(dev, **r2).generate(ids, steps=40, kernel=True)
+    mel_k, _, attn_k = _tts(dev, **r2).generate(ids, steps=40, kernel=True, kernel_variant=variant)
     assert mel_c.shape == mel_k.shape == (80, 40) and attn_c.shape == attn_k.shape == (20, len(ids))
     assert np.abs(mel_c - mel_k)[:, :16].max() <= 1e-4 and np.abs(mel_c - mel_k).max() <= 5e-2
+    # more encoder positions than waves (n > 512: the second position of a wave, 16-deep context sums)
+    long_ids = text_to_ids(' '.join([IDS_TEXT] * 9))
+    assert 512 < len(long_ids) <= 1024
+    mel_c, _, attn_c = _tts('cpu').generate(long_ids, steps=12)
+    mel_k, _, attn_k = _tts(dev).generate(long_ids, steps=12, kernel=True, kernel_variant=variant)
+    assert mel_c.shape == mel_k.shape and attn_c.shape == attn_k.shape == (12, len(long_ids))
+    assert np.abs(mel_c - mel_k).max() <= 1e-4 and np.abs(attn_c - attn_k).max() <= 1e-5
+
+
+@pytest.mark.parametrize('T', [1, 74, 800])
+def test_cbhg_bigru_kernel_matches_torch_gru(T):
+    """`wrnn_bigru` (one persistent workgroup per direction, W_hh in registers) against `nn.GRU(128, 128, bidirectional=True)`'s
+    functional form on the device (MIOpen) and on the CPU (ATen: what the reference runs, models/tacotron.py:95 / :137): another
+    summation order, so a tolerance -- 2e-6 on |h| <= 1 over 800 recurrent steps."""
+    dev = torch.device('cuda', 0)
+    tts = _tts(dev)
+    q = 'postnet.rnn.'
+    flat = [tts.p[q + n_] for n_ in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0', 'weight_ih_l0_reverse',
+                                      'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')]
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(1, T, 128, generator=g)
+    hx = torch.zeros(2, 1, 128)
+    ref_cpu, _ = torch._VF.gru(x, hx, [f.cpu() for f in flat], True, 1, 0.0, False, True, True)
+    ref_dev, _ = torch._VF.gru(x.to(dev), hx.to(dev), flat, True, 1, 0.0, False, True, True)
+    out = tts._bigru(x.to(dev), flat)
+    torch.cuda.synchronize()
+    assert out.shape == ref_cpu.shape == (1, T, 256)
+    assert (out.cpu() - ref_cpu).abs().max().item() <= 2e-6, (out.cpu() - ref_cpu).abs().max().item()
+    assert (out - ref_dev).abs().max().item() <= 2e-6
 
 
 def test_config3_end_to_end_with_the_decoder_kernel(tmp_path):

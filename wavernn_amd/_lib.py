@@ -25,7 +25,7 @@ EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_
            'wrnn_timer_launches', 'wrnn_debug_read_exchange', 'wrnn_selftest', 'wrnn_selftest_metric', 'wrnn_pre_create',
            'wrnn_pre_destroy', 'wrnn_pre_hop', 'wrnn_pre_workspace_bytes', 'wrnn_pre_upsample', 'wrnn_pre_last_error',
            'wrnn_post_unfold', 'wrnn_post_last_error', 'wrnn_taco_workspace_bytes', 'wrnn_taco_decode', 'wrnn_taco_status',
-           'wrnn_taco_last_error']
+           'wrnn_taco_last_error', 'wrnn_bigru']
 
 
 class Weights(ctypes.Structure):
@@ -58,7 +58,13 @@ class TacoCall(ctypes.Structure):
     _fields_ = [('struct_bytes', ctypes.c_uint32), ('n', ctypes.c_int32), ('r', ctypes.c_int32), ('max_r', ctypes.c_int32),
                 ('max_steps', ctypes.c_int32), ('stop_threshold', ctypes.c_float), ('seq', ctypes.c_void_p), ('seq_proj', ctypes.c_void_p),
                 ('mel_out', ctypes.c_void_p), ('scores_out', ctypes.c_void_p), ('steps_done', ctypes.c_void_p),
-                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t), ('stream', ctypes.c_void_p)]
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t), ('stream', ctypes.c_void_p), ('variant', ctypes.c_int32)]
+
+
+class BigruCall(ctypes.Structure):
+    """wrnn_bigru_call."""
+    _fields_ = [('struct_bytes', ctypes.c_uint32), ('T', ctypes.c_int32), ('hidden', ctypes.c_int32)] + \
+               [(n, ctypes.c_void_p) for n in ('gi_fwd', 'gi_rev', 'w_hh_fwd', 'w_hh_rev', 'b_hh_fwd', 'b_hh_rev', 'out', 'stream')]
 
 
 class Geometry(ctypes.Structure):
@@ -171,6 +177,7 @@ def lib():
     L.wrnn_taco_decode.argtypes = [ctypes.c_int, ctypes.POINTER(TacoWeights), ctypes.POINTER(TacoCall)]
     L.wrnn_taco_status.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32 * 4), ctypes.c_void_p]
     L.wrnn_taco_last_error.restype = ctypes.c_char_p
+    L.wrnn_bigru.argtypes = [ctypes.c_int, ctypes.POINTER(BigruCall)]
     L.wrnn_status.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.wrnn_selftest.argtypes = [ctypes.c_int, ctypes.c_int]
     L.wrnn_selftest_metric.restype = ctypes.c_float

@@ -42,7 +42,7 @@ constexpr int DRING = 8;
 constexpr int DAHEAD = 4;                    // re-arm distance (steps)
 constexpr int DNWGC = 4 * LNJ;               // workgroups per cluster (128)
 constexpr size_t DXBUF_FLOATS = (size_t)LMAXG * MAXCL * DNX * DRING * XT;      // [slot][cluster][layer][ring][XT]
-constexpr int DLOGS = 33;
+constexpr int DLOGS = 36;                    // as LOGS of wrnn_loop.hip
 constexpr int DPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][slot 0..2][16][16]
 // Build-time variants of the ih roles (measured on hardware, profiles/r03e_*: the look-ahead bought nothing -- an ih workgroup waits
 // for data that is not published yet, not for load latency -- and the 32 registers it takes had to come from somewhere):
@@ -593,8 +593,8 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
     for (int g = 0; g < 3; ++g) load_afrag(A_hh[g], LA ? a.w_hh1 : a.w_hh2, H, g * H + LU * J + fi, true, kbase_lane);
     const float *bhh = LA ? a.b_hh1 : a.b_hh2;
     const float bh_r = bhh[prow], bh_z = bhh[H + prow], bh_n = bhh[2 * H + prow];
-    const float b3a = a.fc3_b[tid >> 4];                                        // logit row tid >> 4
-    const float b3b = (16 + (tid >> 4) < 30) ? a.fc3_b[16 + (tid >> 4)] : 0.f;
+    const float b3a = a.fc3_b[pu];                                              // logit rows pu and 16 + pu
+    const float b3b = (16 + pu < 30) ? a.fc3_b[16 + pu] : 0.f;
 
     for (int q = tid; q < L.total; q += NT) smem[q] = 0.f;
     __syncthreads();
@@ -643,8 +643,8 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
             }
         } else {                                        // fc3 logits -> sample x_t (utils/distribution.py:102-121)
             const int b0 = GEO[2 * bi];
-            {   // 30 logit rows x 16 segments: thread (row tid >> 4 and 16 + row, segment tid & 15)
-                const int row = tid >> 4, sj = tid & 15;
+            {   // 30 logit rows x 16 segments: thread (rows pu and 16 + pu, segment pj) -- the partial tiles' conflict-free reader mapping
+                const int row = pu, sj = pj;
                 const float lg = get_partial<3>(PB, 0, row, sj) + b3a;
                 const float lg2 = get_partial<3>(PB, 1, row, sj) + b3b;
                 LOG[sj * DLOGS + row] = lg;

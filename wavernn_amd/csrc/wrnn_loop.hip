@@ -50,7 +50,7 @@
 
 namespace wrnn {
 
-constexpr int LOGS = 33;                     // row stride of the logits scratch (32 would put a column's 16 writers on one bank)
+constexpr int LOGS = 36;                     // row stride of the logits scratch: writer lane (row 4w + (l & 3), segment (l >> 2) & 15) -> bank 4 * segment + row: conflict-free
 constexpr int LPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][slot 0..2][16][16]
 struct LoopLds {
     int off_part, off_log, off_wi0, off_f3, off_lgt, off_misc, off_prof, total;
@@ -120,8 +120,8 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     if constexpr (roleA) { bi_r = a.b_ih1[prow]; bi_z = a.b_ih1[H + prow]; bi_n = a.b_ih1[2 * H + prow]; }
     const float *bhh = roleA ? a.b_hh1 : a.b_hh2;
     const float bh_r = bhh[prow], bh_z = bhh[H + prow], bh_n = bhh[2 * H + prow];
-    const float b3a = MOL ? a.fc3_b[tid >> 4] : a.fc3_b[prow];                       // MOL: logit row tid >> 4; RAW: row of the pointwise role
-    const float b3b = (MOL && 16 + (tid >> 4) < 30) ? a.fc3_b[16 + (tid >> 4)] : 0.f;
+    const float b3a = MOL ? a.fc3_b[pu] : a.fc3_b[prow];                             // MOL: logit rows pu and 16 + pu; RAW: row of the pointwise role
+    const float b3b = (MOL && 16 + pu < 30) ? a.fc3_b[16 + pu] : 0.f;
 
     for (int q = tid; q < L.total; q += NT) smem[q] = 0.f;
     __syncthreads();
@@ -309,8 +309,8 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
             float *XS = GP + O_XS;
             const int b0 = GEO[2 * bi];                                   // first segment of the group in the call's segment table
             if constexpr (MOL) {
-                {   // 30 logit rows x 16 segments: thread (row tid >> 4 and 16 + row, segment tid & 15)
-                    const int row = tid >> 4, sj = tid & 15;
+                {   // 30 logit rows x 16 segments: thread (rows pu and 16 + pu, segment pj) -- the partial tiles' conflict-free reader mapping
+                    const int row = pu, sj = pj;
                     const float lg = get_partial<3>(PB, 0, row, sj) + b3a;
                     const float lg2 = get_partial<3>(PB, 1, row, sj) + b3b;      // (rows 30, 31 of the second tile: zero weights, unused)
                     LOG[sj * LOGS + row] = lg;

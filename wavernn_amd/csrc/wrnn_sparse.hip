@@ -195,15 +195,15 @@ __global__ __launch_bounds__(NT, 1) void wrnn_sparse_kernel(const LoopArgs a)
                 {
                     f32x4 o0, o1, o2;
                     sp_tiles3<MPW>(A_ih1, C_ih1, ACT + fi * LDC, o0, o1, o2);
-                    put_partial<SNSLOT>(PART, w, 0, lane, o0);
-                    put_partial<SNSLOT>(PART, w, 1, lane, o1);
-                    put_partial<SNSLOT>(PART, w, 2, lane, o2);
+                    put_partial_rm<SNSLOT>(PART, w, 0, lane, o0);
+                    put_partial_rm<SNSLOT>(PART, w, 1, lane, o1);
+                    put_partial_rm<SNSLOT>(PART, w, 2, lane, o2);
                 }
                 __syncthreads();
                 if (pj < nb) {
-                    const float gir = get_partial<SNSLOT>(PART, 0, 0 * SU + pu, pj) + BI1[0 * SU + pu];
-                    const float giz = get_partial<SNSLOT>(PART, 0, 1 * SU + pu, pj) + BI1[1 * SU + pu];
-                    const float gin = get_partial<SNSLOT>(PART, 0, 2 * SU + pu, pj) + BI1[2 * SU + pu];
+                    const float gir = get_partial_rm<SNSLOT>(PART, 0, 0 * SU + pu, pj) + BI1[0 * SU + pu];
+                    const float giz = get_partial_rm<SNSLOT>(PART, 0, 1 * SU + pu, pj) + BI1[1 * SU + pu];
+                    const float gin = get_partial_rm<SNSLOT>(PART, 0, 2 * SU + pu, pj) + BI1[2 * SU + pu];
                     const float hn = gru_update(gir, giz, gin, GH1[(0 * SU + pu) * SEG + pj], GH1[(1 * SU + pu) * SEG + pj],
                                                 GH1[(2 * SU + pu) * SEG + pj], HOWN1[pu * SEG + pj]);
                     HOWN1[pu * SEG + pj] = hn;
@@ -229,19 +229,19 @@ __global__ __launch_bounds__(NT, 1) void wrnn_sparse_kernel(const LoopArgs a)
                 {
                     f32x4 o0, o1, o2;
                     sp_tiles3<MPW>(A_ih2, C_ih2, ACT + fi * LDC, o0, o1, o2);
-                    put_partial<SNSLOT>(PART, w, 0, lane, o0);
-                    put_partial<SNSLOT>(PART, w, 1, lane, o1);
-                    put_partial<SNSLOT>(PART, w, 2, lane, o2);
+                    put_partial_rm<SNSLOT>(PART, w, 0, lane, o0);
+                    put_partial_rm<SNSLOT>(PART, w, 1, lane, o1);
+                    put_partial_rm<SNSLOT>(PART, w, 2, lane, o2);
                     sp_tiles3<MPW>(A_hh1, C_hh1, HS + fi * LDC, o0, o1, o2);           // gh1(t+1) = W_hh1 . h1(t)
-                    put_partial<SNSLOT>(PART, w, 3, lane, o0);
-                    put_partial<SNSLOT>(PART, w, 4, lane, o1);
-                    put_partial<SNSLOT>(PART, w, 5, lane, o2);
+                    put_partial_rm<SNSLOT>(PART, w, 3, lane, o0);
+                    put_partial_rm<SNSLOT>(PART, w, 4, lane, o1);
+                    put_partial_rm<SNSLOT>(PART, w, 5, lane, o2);
                 }
                 __syncthreads();
                 if (pj < nb) {
-                    const float gir = get_partial<SNSLOT>(PART, 0, 0 * SU + pu, pj) + c2r;
-                    const float giz = get_partial<SNSLOT>(PART, 0, 1 * SU + pu, pj) + c2z;
-                    const float gin = get_partial<SNSLOT>(PART, 0, 2 * SU + pu, pj) + c2n;
+                    const float gir = get_partial_rm<SNSLOT>(PART, 0, 0 * SU + pu, pj) + c2r;
+                    const float giz = get_partial_rm<SNSLOT>(PART, 0, 1 * SU + pu, pj) + c2z;
+                    const float gin = get_partial_rm<SNSLOT>(PART, 0, 2 * SU + pu, pj) + c2n;
                     const float hn = gru_update(gir, giz, gin, GH2[(0 * SU + pu) * SEG + pj], GH2[(1 * SU + pu) * SEG + pj],
                                                 GH2[(2 * SU + pu) * SEG + pj], HOWN2[pu * SEG + pj]);
                     HOWN2[pu * SEG + pj] = hn;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_sparse_kernel(const LoopArgs a)
 #pragma unroll
                 for (int q0 = 0; q0 < (SGR * SEG) / NT; ++q0) {
                     const int q = tid + NT * q0;
-                    GH1[q] = get_partial<SNSLOT>(PART, 3, q >> 4, q & 15) + BH1[q >> 4];
+                    GH1[q] = get_partial_rm<SNSLOT>(PART, 3, q >> 4, q & 15) + BH1[q >> 4];
                 }
             }
 
@@ -266,20 +266,20 @@ __global__ __launch_bounds__(NT, 1) void wrnn_sparse_kernel(const LoopArgs a)
                 bool ok = sweep_layer<true, 16>(grs, soff_cl + i * SLOT_BYTES + 1 * LAYER_BYTES, tag, nb, tid, HS, ACT, a.status);   // h2 -> HS; ACT = x1 + h2
                 if (!ok) report_failure(a.status, 0x400u | 2u, blockIdx.x, t, tid);
                 if (__syncthreads_or(!ok)) return;
-                put_partial<SNSLOT>(PART, w, 0, lane, mfma_tile_pre(A_fc1, ACT + fi * LDC + kbase_lane));
+                put_partial_rm<SNSLOT>(PART, w, 0, lane, mfma_tile_pre(A_fc1, ACT + fi * LDC + kbase_lane));
                 {
                     f32x4 o0, o1, o2;
                     sp_tiles3<MPW>(A_hh2, C_hh2, HS + fi * LDC, o0, o1, o2);           // gh2(t+1) = W_hh2 . h2(t)
-                    put_partial<SNSLOT>(PART, w, 3, lane, o0);
-                    put_partial<SNSLOT>(PART, w, 4, lane, o1);
-                    put_partial<SNSLOT>(PART, w, 5, lane, o2);
+                    put_partial_rm<SNSLOT>(PART, w, 3, lane, o0);
+                    put_partial_rm<SNSLOT>(PART, w, 4, lane, o1);
+                    put_partial_rm<SNSLOT>(PART, w, 5, lane, o2);
                 }
                 __syncthreads();
-                if (pj < nb) publish(G3, tag, pj, prow, fmaxf(get_partial<SNSLOT>(PART, 0, pu, pj) + c3v, 0.f));
+                if (pj < nb) publish(G3, tag, pj, prow, fmaxf(get_partial_rm<SNSLOT>(PART, 0, pu, pj) + c3v, 0.f));
 #pragma unroll
                 for (int q0 = 0; q0 < (SGR * SEG) / NT; ++q0) {
                     const int q = tid + NT * q0;
-                    GH2[q] = get_partial<SNSLOT>(PART, 3, q >> 4, q & 15) + BH2[q >> 4];
+                    GH2[q] = get_partial_rm<SNSLOT>(PART, 3, q >> 4, q & 15) + BH2[q >> 4];
                 }
             }
 
@@ -294,9 +294,9 @@ __global__ __launch_bounds__(NT, 1) void wrnn_sparse_kernel(const LoopArgs a)
                 bool ok = sweep_layer<false, 16>(grs, soff_cl + i * SLOT_BYTES + 2 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y1
                 if (!ok) report_failure(a.status, 0x400u | 3u, blockIdx.x, t, tid);
                 if (__syncthreads_or(!ok)) return;
-                put_partial<SNSLOT>(PART, w, 0, lane, mfma_tile_pre(A_fc2, ACT + fi * LDC + kbase_lane));
+                put_partial_rm<SNSLOT>(PART, w, 0, lane, mfma_tile_pre(A_fc2, ACT + fi * LDC + kbase_lane));
                 __syncthreads();
-                if (pj < nb) publish(G4, tag, pj, prow, fmaxf(get_partial<SNSLOT>(PART, 0, pu, pj) + c4v, 0.f));
+                if (pj < nb) publish(G4, tag, pj, prow, fmaxf(get_partial_rm<SNSLOT>(PART, 0, pu, pj) + c4v, 0.f));
             }
 
             // =========================== S5: fc3, one logit row per workgroup (:223) ==================

@@ -29,17 +29,36 @@ __device__ __forceinline__ f32x4 mfma_tile_lds(const float *w_lane, const float 
     return acc0 + acc1;
 }
 
-// partial tile of wave w, slot s -> part[(w*NSLOT + s)*256 + i*16 + j]
+// partial tile of wave w, slot s, in the accumulator's own fragment order: part[(w*NSLOT + s)*256 + lane*4 + r] = row 4*(lane>>4) + r,
+// segment lane & 15.  ONE conflict-free ds_write_b128 per tile; a reader wave whose lane l takes (row 4q + (l & 3), segment
+// (l >> 2) & 15) -- the (pu, pj) mapping of the loop / duo kernels, the one publish4's quads need -- reads 64 consecutive words
+// (round 2's row-major [16][16] tile made both sides 2-way bank-conflicted: 43 % conflict cycles in profiles/r03k_summary.md).
 template <int NSLOT>
 __device__ __forceinline__ void put_partial(float *part, int w, int s, int lane, f32x4 acc)
 {
-    float *p = part + (w * NSLOT + s) * 256 + ((lane >> 4) * 4) * 16 + (lane & 15);
-    p[0] = acc[0]; p[16] = acc[1]; p[32] = acc[2]; p[48] = acc[3];
+    *reinterpret_cast<f32x4 *>(part + (w * NSLOT + s) * 256 + lane * 4) = acc;
 }
 
 // fragment row ri (0 .. 16*RT-1) of slot block `base` (0 critical / RT off-path), segment j: sum over the 4 waves
 template <int NSLOT>
 __device__ __forceinline__ float get_partial(const float *part, int base, int ri, int j)
+{
+    const int o = (base + (ri >> 4)) * 256 + (((ri & 15) >> 2) * 16 + j) * 4 + (ri & 3);
+    float s = part[o];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s += part[w * NSLOT * 256 + o];
+    return s;
+}
+
+// the row-major form (part[(w*NSLOT + s)*256 + i*16 + j]) for readers that map a 16-lane row to one unit (wrnn_sparse.hip)
+template <int NSLOT>
+__device__ __forceinline__ void put_partial_rm(float *part, int w, int s, int lane, f32x4 acc)
+{
+    float *p = part + (w * NSLOT + s) * 256 + ((lane >> 4) * 4) * 16 + (lane & 15);
+    p[0] = acc[0]; p[16] = acc[1]; p[32] = acc[2]; p[48] = acc[3];
+}
+template <int NSLOT>
+__device__ __forceinline__ float get_partial_rm(const float *part, int base, int ri, int j)
 {
     const int o = (base + (ri >> 4)) * 256 + (ri & 15) * 16 + j;
     float s = part[o];

@@ -93,8 +93,31 @@ class TacotronInference:
         q = prefix + '.rnn.'
         flat = [p[q + n_] for n_ in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0', 'weight_ih_l0_reverse',
                                      'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')]
+        if getattr(self, '_bigru_kernel', False) and x.is_cuda and x.size(0) == 1 and flat[1].shape[1] == 128:
+            return self._bigru(x, flat)
         hx = torch.zeros(2, x.size(0), flat[1].shape[1], device=x.device, dtype=x.dtype)
         out, _ = torch._VF.gru(x, hx, flat, True, 1, 0.0, False, True, True)
+        return out
+
+    def _bigru(self, x, flat):
+        """The CBHG's bidirectional GRU (:95, :137) through `wrnn_bigru` (csrc/wrnn_taco.hip: one persistent workgroup per
+        direction, W_hh in registers) instead of MIOpen's per-step launches; the input products are two plain GEMMs."""
+        import ctypes
+        from . import _lib
+        L = _lib.lib()
+        w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r = [t.contiguous() for t in flat]
+        gi_f = F.linear(x[0], w_ih, b_ih).contiguous()
+        gi_r = F.linear(x[0], w_ih_r, b_ih_r).contiguous()
+        out = torch.empty(1, x.size(1), 256, device=x.device, dtype=torch.float32)
+        c = _lib.BigruCall()
+        c.struct_bytes = ctypes.sizeof(_lib.BigruCall)
+        c.T, c.hidden = x.size(1), 128
+        c.gi_fwd, c.gi_rev, c.w_hh_fwd, c.w_hh_rev = gi_f.data_ptr(), gi_r.data_ptr(), w_hh.data_ptr(), w_hh_r.data_ptr()
+        c.b_hh_fwd, c.b_hh_rev, c.out = b_hh.data_ptr(), b_hh_r.data_ptr(), out.data_ptr()
+        c.stream = torch.cuda.current_stream(x.device).cuda_stream
+        rc = L.wrnn_bigru(x.device.index or 0, ctypes.byref(c))
+        if rc != _lib.WRNN_OK:
+            raise _lib.WrnnError(f'wrnn_bigru failed (rc={rc}): {L.wrnn_taco_last_error().decode()}')
         return out
 
     def encode(self, ids):
@@ -135,9 +158,9 @@ class TacotronInference:
             st[k].copy_(v)
         return mels, scores
 
-    def _decode_kernel(self, seq, seq_proj, steps):
-        """DRAFT: the decoder loop (:396-414) as ONE persistent HIP kernel (csrc/wrnn_taco.hip) through the C ABI
-        (`wrnn_taco_decode`).  Returns (mel (1, n_mels, N) , attention (N / r, n)) device tensors; fails loudly without the
+    def _decode_kernel(self, seq, seq_proj, steps, variant=0):
+        """The decoder loop (:396-414) as ONE persistent HIP kernel (csrc/wrnn_taco.hip) through the C ABI
+        (`wrnn_taco_decode`; variant 0 = auto, 1 = the flag-barrier kernel, 2 = the register-resident kernel).  Returns (mel (1, n_mels, N) , attention (N / r, n)) device tensors; fails loudly without the
         extension or a HIP device -- there is no host fallback."""
         import ctypes
         from . import _lib
@@ -176,6 +199,7 @@ class TacotronInference:
         c.seq, c.seq_proj, c.mel_out, c.scores_out = seq_c.data_ptr(), proj_c.data_ptr(), mel_out.data_ptr(), scores.data_ptr()
         c.steps_done, c.workspace, c.workspace_bytes = done.data_ptr(), ws.data_ptr(), ws.numel()
         c.stream = torch.cuda.current_stream(dev).cuda_stream
+        c.variant = int(variant)
         rc = L.wrnn_taco_decode(dev.index or 0, ctypes.byref(w), ctypes.byref(c))
         if rc != _lib.WRNN_OK:
             raise _lib.WrnnError(f'wrnn_taco_decode failed (rc={rc}): {L.wrnn_taco_last_error().decode()}')
@@ -183,12 +207,13 @@ class TacotronInference:
         rc = L.wrnn_taco_status(ws.data_ptr(), ctypes.byref(st4), c.stream)
         if rc != _lib.WRNN_OK or st4[0] != 0:
             raise _lib.WrnnError(f'Tacotron decoder kernel failed: status {list(st4)} {L.wrnn_taco_last_error().decode()}')
+        self._last_taco_ws = ws                                                    # (variant 3: the profile words are its last 192 bytes)
         k = int(done.item())
         mel = mel_out[:k].permute(1, 0, 2).reshape(1, self.n_mels, k * self.r)      # frames of step s at columns [s r, (s+1) r)
         return mel, scores[:k]
 
     @torch.no_grad()
-    def generate(self, ids, steps=2000, graph=False, stop_check_every=1, kernel=False):
+    def generate(self, ids, steps=2000, graph=False, stop_check_every=1, kernel=False, kernel_variant=0):
         """`Tacotron.generate(x, steps)` (:370-430).  Returns numpy (mel (n_mels, N), linear (fft, N), attention (N, n_chars)).
 
         graph=True (CUDA/HIP device): one decoder step is captured as a HIP graph and replayed; the stop test of :411 (`all
@@ -196,6 +221,7 @@ class TacotronInference:
         output truncated at the first step that met it -- the same result as the eager loop, without a host round trip
         per frame."""
         dev = self.device
+        self._bigru_kernel = bool(kernel) and dev.type == 'cuda'                   # the CBHGs' GRUs as persistent kernels too
         seq, seq_proj = self.encode(ids)
         n = seq.size(1)
         z = lambda *s: torch.zeros(*s, device=dev)
@@ -204,7 +230,7 @@ class TacotronInference:
         prenet_in = z(1, self.n_mels)                                              # the <GO> frame
         frames, scores_all = [], []
         if kernel:
-            mel, scores_all = self._decode_kernel(seq, seq_proj, steps)
+            mel, scores_all = self._decode_kernel(seq, seq_proj, steps, kernel_variant)
             frames = [mel]
         elif graph and dev.type == 'cuda':
             out_m, out_s = z(1, self.n_mels, self.r), z(1, n)
