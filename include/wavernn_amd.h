@@ -127,7 +127,9 @@ typedef struct wrnn_options {
                                 `out` / force_x / logits always the whole [.., T] tensors */
     int32_t tuning;          /* loop kernel A/B switches for measurements: bit 0 = no one-stage look-ahead of the exchange loads,
                                 bit 1 = full __syncthreads() fences at the stage barriers (default 0 = the fast forms); bit 2 (duo
-                                kernel) = re-fill the exchange ring with the sentinel before EVERY launch, not only where a round starts */
+                                kernel) = re-fill the exchange ring with the sentinel before EVERY launch, not only where a round starts;
+                                loop kernel: bit 5 / bit 6 = never / always start a stage with the pending back half (default: up to 2
+                                groups in flight), bit 7 = library exp / tanh in the MoL gate math (default: hardware exp / rcp) */
     const float *force_x;    /* test hook, device [n,T]: value fed back as x_t instead of the sample (teacher forcing) */
     float *logits;           /* test hook, device [T,n,C]: fc3 output of every step (:223) */
     unsigned long long *phase_clocks; /* profiling hook, device [256 workgroups][32] zeroed by the caller: the loop kernel (MOL) adds

@@ -47,6 +47,9 @@ VARS = {'auto': dict(algo='auto'), 'stream': dict(algo='stream'), 'g1': dict(alg
         'd8l2': dict(algo='duo', depth=8, tuning=2 << 9), 'd8l3': dict(algo='duo', depth=8, tuning=3 << 9), 'd8l4': dict(algo='duo', depth=8, tuning=4 << 9), 'd8l7': dict(algo='duo', depth=8, tuning=7 << 9),
         'g2ns': dict(algo='loop', depth=2, tuning=16), 'g4ns': dict(algo='loop', depth=4, tuning=16), 'g8ns': dict(algo='loop', depth=8, tuning=16),
         'g1nf': dict(algo='loop', depth=1, tuning=4), 'g2nf': dict(algo='loop', depth=2, tuning=4), 'g4nf': dict(algo='loop', depth=4, tuning=4),
+        'd3o': dict(algo='duo', depth=3, tuning=128), 'd4o': dict(algo='duo', depth=4, tuning=128), 'd8o': dict(algo='duo', depth=8, tuning=128), 'd6o': dict(algo='duo', depth=6, tuning=128),
+        'g1lf': dict(algo='loop', depth=1, tuning=32), 'g2lf': dict(algo='loop', depth=2, tuning=32), 'g3pf': dict(algo='loop', depth=3, tuning=64),
+        'g4pf': dict(algo='loop', depth=4, tuning=64), 'g1x': dict(algo='loop', depth=1, tuning=128), 'g1lfx': dict(algo='loop', depth=1, tuning=160),
         'g2na': dict(algo='loop', depth=2, tuning=8), 'g4na': dict(algo='loop', depth=4, tuning=8), 'g4nfna': dict(algo='loop', depth=4, tuning=12)}
 rows = []
 for B in [int(x) for x in args.B.split(',')]:

@@ -65,6 +65,7 @@ struct wrnn_pack {
     const float *fc1_w, *fc1_b, *fc2_w, *fc2_b, *fc3_w, *fc3_b;
     const float *w_ih1T, *w_hh1T, *w_ih2T, *w_hh2T, *fc1T, *fc2T, *fc3T, *c2_wT, *c3_wT, *c4_wT;
     const float *fc3f;         // MOL: fc3.weight in A-fragment order (wrnn_duo.hip)
+    const float *fc12f;        // MOL: fc1 / fc2 (first 512 columns) in A-fragment order per unit block (wrnn_duo.hip)
     // dimension-generic pack (any hparams but the shipped ones): only the k-major copies + biases, run by wrnn_generic_kernel
     bool generic;
     int gH, gF, gM, gA;
@@ -200,6 +201,22 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
                 b.host[o_fc3f + (size_t)q * 4 + e] = row < C ? w->fc3_w[(size_t)row * H + 128 * wv + 16 * r + 4 * kq + e] : 0.f;
         }
     }
+    // MOL: fc1 / fc2 rows [16 J, 16 J + 16) x columns [0, 512) per unit block J as one MFMA A tile in fragment order (the aux columns
+    // are hoisted into the c3f / c4f tables): [layer][J][wave][k-block r][lane (row fi, k-quad kq)][4]
+    size_t o_fc12f = 0;
+    if (w->mode == WRNN_MODE_MOL) {
+        o_fc12f = b.add(nullptr, (size_t)2 * H * H);
+        for (int layer = 0; layer < 2; ++layer) {
+            const float *fw = layer == 0 ? w->fc1_w : w->fc2_w;
+            for (int J = 0; J < H / 16; ++J)
+                for (int q = 0; q < 16 * H / 4; ++q) {
+                    const int l6 = q & 63, r = (q >> 6) & 7, wv = (q >> 9) & 3;
+                    const int row = 16 * J + (l6 & 15), kq = l6 >> 4;
+                    for (int e = 0; e < 4; ++e)
+                        b.host[o_fc12f + ((size_t)(layer * (H / 16) + J) * 16 * H) + (size_t)q * 4 + e] = fw[(size_t)row * K2 + 128 * wv + 16 * r + 4 * kq + e];
+                }
+        }
+    }
     // ---- block-sparse view of the GRU matrices (16x1 blocks: 16 consecutive rows of one gate x 1 column) -----------
     // usable by wrnn_sparse_kernel when every block row keeps <= 64 columns (~5 % density keeps ~26 +- 5)
     int sp_nbp = 0, sp_max = 0;
@@ -262,6 +279,7 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     p->fc1T = base + o_fc1T; p->fc2T = base + o_fc2T; p->fc3T = base + o_fc3T;
     p->c2_wT = base + o_c2_wT; p->c3_wT = base + o_c3_wT; p->c4_wT = base + o_c4_wT;
     p->fc3f = w->mode == WRNN_MODE_MOL ? base + o_fc3f : nullptr;
+    p->fc12f = w->mode == WRNN_MODE_MOL ? base + o_fc12f : nullptr;
     p->sp_nbp = sp_nbp; p->sp_max_blocks = sp_max;
     p->sp_vals = sp_nbp ? base + o_spv : nullptr;
     p->sp_cols = sp_nbp ? reinterpret_cast<const int *>(base + o_spc) : nullptr;
@@ -631,7 +649,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     memset(&a, 0, sizeof a);
     a.I_w0 = p->I_w0; a.w_ih1 = p->w_ih1; a.w_hh1 = p->w_hh1; a.b_ih1 = p->b_ih1; a.b_hh1 = p->b_hh1;
     a.w_ih2 = p->w_ih2; a.w_hh2 = p->w_hh2; a.b_hh2 = p->b_hh2; a.fc1_w = p->fc1_w; a.fc2_w = p->fc2_w;
-    a.fc3_w = p->fc3_w; a.fc3_b = p->fc3_b; a.fc3f = p->fc3f;
+    a.fc3_w = p->fc3_w; a.fc3_b = p->fc3_b; a.fc3f = p->fc3f; a.fc12f = p->fc12f;
     a.w_ih1T = p->w_ih1T; a.w_hh1T = p->w_hh1T; a.w_ih2T = p->w_ih2T; a.w_hh2T = p->w_hh2T;
     a.fc1T = p->fc1T; a.fc2T = p->fc2T; a.fc3T = p->fc3T;
     a.c2f = c.c2f; a.c3f = c.c3f; a.c4f = c.c4f;

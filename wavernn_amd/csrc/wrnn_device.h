@@ -77,6 +77,7 @@ struct LoopArgs {
     int t0, t1, cI_t0, noise_t0;        // noise / noise_pre row 0 is step noise_t0, cIf row 0 is step cI_t0
     int tuning;                         // A/B switches of the loop kernel (wrnn_options.tuning)
     int rb0, Nall, G, resume;           // resume != 0: restore the per-group state instead of the zero initial state
+    const float *fc12f;                 // MOL: fc1 / fc2 rows [16 J, 16 J + 16) x the first 512 columns in A-fragment order [layer 2][J 32][wave 4][k-block 8][lane 64][4] (wrnn_duo.hip, DUO_FC_GLB)
     const float *fc3f;                  // MOL: fc3.weight in A-fragment order [tile 2][wave 4][k-block 8][lane 64][4] (wrnn_duo.hip's sampler reads it from L2)
 };
 

@@ -46,13 +46,20 @@ constexpr int DLOGS = 36;                    // as LOGS of wrnn_loop.hip
 constexpr int DPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][slot 0..2][16][16]
 // Build-time variants of the ih roles (measured on hardware, profiles/r03e_*: the look-ahead bought nothing -- an ih workgroup waits
 // for data that is not published yet, not for load latency -- and the 32 registers it takes had to come from somewhere):
-//   DUO_IH_XAHEAD 1 = one-stage look-ahead of the ih roles' operand loads (needs DUO_FC_LDS 1 to fit 256 registers)
+//   DUO_IH_XAHEAD 1 = one-stage look-ahead of the ih roles' operand loads (needs DUO_FC_LDS 1 or DUO_FC_GLB 1 to fit 256 registers)
 //   DUO_FC_LDS    1 = the fc1 / fc2 tile in LDS (A-fragment order) instead of 32 registers
 #ifndef DUO_IH_XAHEAD
 #define DUO_IH_XAHEAD 0
 #endif
 #ifndef DUO_FC_LDS
 #define DUO_FC_LDS 0
+#endif
+//   DUO_FC_GLB    1 = the ih roles read their fc1 / fc2 tile from L2 every fc stage (LoopArgs.fc12f, fragment order, 32 KB per workgroup,
+//                 issued before the operand poll) instead of holding it in 32 registers -- which then carry the look-ahead.
+//                 Measured (profiles/r03x_probe_fc_glb_ih_lookahead.json): alone 3 % slower (0 spills); with DUO_IH_XAHEAD the combined
+//                 kernel still spills 46-55 VGPRs and runs 50 % slower.  Off.
+#ifndef DUO_FC_GLB
+#define DUO_FC_GLB 0
 #endif
 //   DUO_FAST_PW   1 = hardware exp / rcp in the GRU pointwise math (gru_update_fast), 0 = the library forms (gru_update, as wrnn_loop.hip)
 //   DUO_PUBLISH_FIRST 1 = a stage starts with the previous stage's back half (barrier, pointwise, PUBLISH) and only then issues its own
@@ -67,6 +74,18 @@ constexpr int DPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][slo
 #endif
 #ifndef DUO_FAST_PW
 #define DUO_FAST_PW 1
+#endif
+//   DUO_SPLIT_FC  1 = the fc1 / fc2 stages of the odd slots run on the hh workgroups (load balance of the two workgroups of a CU).
+//                 Measured (profiles/r03w_probe_split_fc.json): 9-14 % SLOWER at depth 3-8 -- the hh workgroup then has no registers
+//                 for its one-stage look-ahead (which alone is worth 5-13 %), and its gh stages are less off the chain than the
+//                 phase clocks suggested.  Off.
+#ifndef DUO_SPLIT_FC
+#define DUO_SPLIT_FC 0
+#endif
+//   DUO_HH_XAHEAD 1 = the hh workgroups load the next stage's operand fragments one stage ahead.  With the fc tile next to W_hh (128
+//                 weight registers, DUO_SPLIT_FC) the 32 look-ahead registers spill (71 VGPRs to scratch), as they did in duo_ih: off.
+#ifndef DUO_HH_XAHEAD
+#define DUO_HH_XAHEAD (!DUO_SPLIT_FC)
 #endif
 #ifndef DUO_MFMA3
 #define DUO_MFMA3 mfma3
@@ -106,6 +125,24 @@ __device__ __forceinline__ void duo_rearm(__amdgpu_buffer_rsrc_t rs, int soff_en
         const u32x4 q = {SENT, SENT, SENT, SENT};
         __builtin_amdgcn_raw_buffer_store_b128(q, rs, layer * (DRING * XT * 4) + (lane & 15) * 16, soff_entry0, 16 /* sc1 */);
     }
+}
+
+// one tile with the A fragments already loaded (fragment order), B in registers; mfma_tile's order
+__device__ __forceinline__ f32x4 mfma1_frag(const float4 (&av)[8], const float (&b)[32])
+{
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].x, b[4 * r + 0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].x, b[4 * r + 4], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].y, b[4 * r + 1], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].y, b[4 * r + 5], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].z, b[4 * r + 2], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].z, b[4 * r + 6], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].w, b[4 * r + 3], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].w, b[4 * r + 7], c1, 0, 0, 0);
+    }
+    return c0 + c1;
 }
 
 // one fc3 tile with the A fragments read from global memory (L2-resident, fragment order), B in registers; mfma_tile's order
@@ -148,18 +185,7 @@ __device__ __forceinline__ void mfma3s(const float (&a0)[AF], const float (&a1)[
 #define DXL(i, layer, ring) ((((((i) * MAXCL + cl) * DNX + (layer)) * DRING) + (ring)) * XT)
 #define DPARTOF(q) (PART + (q) * (NW * 3 * 256))
 
-// GRU pointwise math with the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each) instead of the library's expf, tanhf
-// and IEEE divisions: ~25 VALU instead of ~120 on the critical back half of every gate stage.  Same algebra as gru_update
-// (wrnn_device.h); absolute error ~1e-7 per value, the size of the fp32 rounding already present (MoL tolerance 1e-5: tests).
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
-__device__ __forceinline__ float gru_update_fast(float gi_r, float gi_z, float gi_n, float gh_r, float gh_z, float gh_n, float h)
-{
-    const float r = fast_sigmoid(gh_r + gi_r);
-    const float z = fast_sigmoid(gh_z + gi_z);
-    const float n = fast_tanh(gi_n + gh_n * r);
-    return (h - n) * z + n;
-}
+// (fast_sigmoid / fast_tanh / gru_update_fast: wrnn_ring.h)
 
 // bounded poll of this thread's 16-byte gh word {r, z, n, tag}: ONE 16-byte sc1 store by ONE lane, so the word is its own flag (MI355X
 // guide, hand-off form R2) -- tag = consuming step + 1, no sentinel, hence no re-arm store and no ordering rule for these layers
@@ -231,7 +257,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, int cl, i
     float A_ih[3][AF];
 #pragma unroll
     for (int g = 0; g < 3; ++g) load_afrag(A_ih[g], LA ? a.w_ih1 : a.w_ih2, LA ? H : H + AUX, g * H + LU * J + fi, true, kbase_lane);
-#if !DUO_FC_LDS
+#if !DUO_FC_LDS && !DUO_FC_GLB
     float A_fc[AF];
     load_afrag(A_fc, LA ? a.fc1_w : a.fc2_w, H + AUX, LU * J + fi, true, kbase_lane);
 #endif
@@ -296,6 +322,11 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, int cl, i
     const bool prio_mfma = (a.tuning & 8) != 0;          // A/B: raise the wave's priority around its MFMA tiles
     if (a.tuning & 16) __builtin_amdgcn_s_setprio(1);    // A/B: static priority for the ih workgroups (the longer instruction stream)
     const bool lookahead = DUO_IH_XAHEAD && (a.tuning & 1) == 0;          // A/B: bit 0 = no one-stage look-ahead of the operand loads
+    // fc1 / fc2 stages of the ODD slots run on the hh workgroup of the same layer and unit block (which holds the same fc tile): the
+    // ih workgroup's instruction stream is what bounds a busy step (gates + fc = 16 k cycles per group-step against the hh
+    // workgroup's 9 k; profiles/r03g_duo_phase_clocks_depth8.json).  tuning bit 7 = all fc stages here, as before.
+    const bool split_fc = DUO_SPLIT_FC && (a.tuning & 128) == 0 && !DUO_IH_XAHEAD;
+    const int last_fc = split_fc ? ((nact - 1) & ~1) : nact - 1;           // the last fc stage this workgroup runs in a step
     enum { BK_NONE = 0, BK_GATES, BK_RELU };
     // x: the operand fragments of the NEXT stage, loaded one stage ahead (before this stage's MFMA tiles): xa = 1 an exchanged layer
     // (may still hold sentinels: checked at the stage's start), xa = 2 the conditioning slab cI (layer 1's gate stages: plain data)
@@ -392,6 +423,14 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, int cl, i
                 for (int r = 0; r < 8; ++r) c[r] = make_float4(__uint_as_float(x[r].x), __uint_as_float(x[r].y), __uint_as_float(x[r].z), __uint_as_float(x[r].w));
             } else load_cI(a.cIf + ((size_t)tc * NGR + g) * XT, w, lane, c);
         }
+#if DUO_FC_GLB
+        float4 av[8];                                   // the fc tile's A fragments of this wave, in flight under the operand wait
+        if (ph == 2) {
+            const float4 *fp = reinterpret_cast<const float4 *>(a.fc12f + (size_t)((LA ? 0 : LNJ) + J) * XT + frag_off(w, 0, lane));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) av[r] = fp[r * 64];
+        }
+#endif
         if (ph == 0) {
             if constexpr (LA) {
                 v0 = a.b_ih1[prow]; v1 = a.b_ih1[H + prow]; v2 = a.b_ih1[2 * H + prow];      // layer 1: b_ih1 (layer 2's b_ih2 is inside c2f)
@@ -424,7 +463,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, int cl, i
             if (PROF && tid == 0) { PROFL[cur + 6] += 1; PROFL[cur + 7] += !ready; }
         }
         PH(cur + 3);
-        if (ph == 2 && i == nact - 1) {
+        if (ph == 2 && i == last_fc) {
             // ring hygiene, once per step, after the last layer this workgroup polls in the step has arrived (see the header)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int ringn = (t + DAHEAD) % DRING;
@@ -483,13 +522,15 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, int cl, i
         } else {
 #if DUO_FC_LDS
             put_partial<3>(PW, w, 0, lane, mfma1_lds(FC + frag_off(w, 0, lane), b));
+#elif DUO_FC_GLB
+            put_partial<3>(PW, w, 0, lane, mfma1_frag(av, b));
 #else
             put_partial<3>(PW, w, 0, lane, mfma1(A_fc, b));
 #endif
             bk = BK_RELU;
         }
         if (prio_mfma) __builtin_amdgcn_s_setprio(0);
-        if (LA && ph == 2 && t + 1 < T1) {     // pull the next step's conditioning block of this group (32 KB) into this XCD's L2
+        if (LA && ph == 0 && t + 1 < T1) {     // pull the next step's conditioning block of this group (32 KB) into this XCD's L2
             asm volatile("" ::"v"(touch));
             touch = a.cIf[((size_t)(tc + 1) * NGR + g) * XT + 32 * tid];
         }
@@ -514,7 +555,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, int cl, i
             if (k < nact) {
                 if (!stage(std::integral_constant<int, 0>{}, k)) goto bail;
             }
-            if (k >= lag) {
+            if (k >= lag && !(split_fc && ((k - lag) & 1))) {
                 if (!stage(std::integral_constant<int, 2>{}, k - lag)) goto bail;
             }
         }
@@ -586,11 +627,15 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
     const int prow = LU * J + pu;
     const int T0 = a.t0, T1 = a.t1, C = a.C;
     const int NR = a.Btot, Nall = a.Nall, NGR = a.NG;
-    constexpr int L_H = LA ? 0 : 1, L_GH = LA ? 8 : 12;
+    constexpr int L_H = LA ? 0 : 1, L_GH = LA ? 8 : 12, L_Y = LA ? 2 : 3, L_P2 = LA ? 6 : 2;
 
     float A_hh[3][AF];
 #pragma unroll
     for (int g = 0; g < 3; ++g) load_afrag(A_hh[g], LA ? a.w_hh1 : a.w_hh2, H, g * H + LU * J + fi, true, kbase_lane);
+#if DUO_SPLIT_FC
+    float A_fc[AF];                                      // fc1 / fc2 rows of the unit block: the fc stages of the odd slots (see duo_ih)
+    load_afrag(A_fc, LA ? a.fc1_w : a.fc2_w, H + AUX, LU * J + fi, true, kbase_lane);
+#endif
     const float *bhh = LA ? a.b_hh1 : a.b_hh2;
     const float bh_r = bhh[prow], bh_z = bhh[H + prow], bh_n = bhh[2 * H + prow];
     const float b3a = a.fc3_b[pu];                                              // logit rows pu and 16 + pu
@@ -607,8 +652,15 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
         const int b0 = (int)(((long)g * NR) / NGR), nb = (int)(((long)(g + 1) * NR) / NGR) - b0;
         if (tid == 0) { GEO[2 * i] = a.rb0 + b0; GEO[2 * i + 1] = nb; }
         nbpack |= (u64)(unsigned)nb << (8 * i);
+        if (tid < SEG) {                                // segment table of the slot (the conditioning frame of its fc stages)
+            int *SP = reinterpret_cast<int *>(smem + i * DGRP + D_SP);
+            const int sc = a.rb0 + b0 + (tid < nb ? tid : nb - 1);
+            SP[tid] = a.seg_pos[sc];
+            SP[SEG + tid] = a.seg_lim[sc];
+        }
     }
     __syncthreads();
+    const bool split_fc = DUO_SPLIT_FC && (a.tuning & 128) == 0 && !DUO_IH_XAHEAD;
     // the slot this workgroup samples: slot s <-> hh role (s & 1 ? layer 2 : layer 1), unit block s >> 1
     const int my_slot = (J < LMAXG / 2) ? 2 * J + (LA ? 0 : 1) : -1;
     const bool sampler = my_slot >= 0 && my_slot < nact;
@@ -620,7 +672,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
     int t = T0;
     const bool prio_mfma = (a.tuning & 8) != 0;
     if (a.tuning & 32) __builtin_amdgcn_s_setprio(1);    // A/B: static priority for the hh workgroups
-    enum { BK_NONE = 0, BK_GH, BK_SAMPLE };
+    enum { BK_NONE = 0, BK_GH, BK_SAMPLE, BK_RELU };
     u32x4 x[8];
     bool xahead = false;
     int bk = BK_NONE, bi = 0, bpp = 0, bt = 0;
@@ -641,6 +693,8 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
                 const u32x4 q = {__float_as_uint(g0), __float_as_uint(g1), __float_as_uint(g2), (unsigned)bt + 2u};      // tag: consuming step (bt + 1) + 1
                 __builtin_amdgcn_raw_buffer_store_b128(q, xrs, (256 * (J & 7) + tid) * 16, DXL(bi, L_GH + (J >> 3), r1) * 4, 16 /* sc1 */);
             }
+        } else if (bk == BK_RELU) {                     // fc1 / fc2 + relu of an odd slot -> publish y1 / y2 (as duo_ih)
+            publish4(xrs, (DXL(bi, L_Y, bt % DRING) + 256 * J) * 4, tid, fmaxf(get_partial<3>(PB, 0, pu, pj) + bc0, 0.f), pj < nb);
         } else {                                        // fc3 logits -> sample x_t (utils/distribution.py:102-121)
             const int b0 = GEO[2 * bi];
             {   // 30 logit rows x 16 segments: thread (rows pu and 16 + pu, segment pj) -- the partial tiles' conflict-free reader mapping
@@ -674,7 +728,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
     };
 
     int ring = 0;
-    // kind 1: gh stage of slot i (polls h(t)); kind 3: sampling stage of my_slot (polls y2(t))
+    // kind 1: gh stage of slot i (polls h(t)); kind 2: fc stage of an odd slot (polls x2(t) / y1(t)); kind 3: sampling stage of my_slot (polls y2(t))
     auto stage = [&](auto KC, int i) -> bool {
         constexpr int kind = decltype(KC)::value;
         const int nb = (int)((nbpack >> (8 * i)) & 255u);
@@ -686,8 +740,15 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
 #if DUO_PUBLISH_FIRST
         if (!run_back()) return false;
 #endif
-        if (xahead) ready = try_finish(lane, nb, x, b);
-        else issue(xrs, DXL(i, kind == 1 ? L_H : 3, ring) * 4, w, lane, x);
+        constexpr int xl = kind == 1 ? L_H : (kind == 2 ? L_P2 : 3);
+        if (DUO_HH_XAHEAD && xahead) ready = try_finish(lane, nb, x, b);
+        else issue(xrs, DXL(i, xl, ring) * 4, w, lane, x);
+        if (kind == 2) {                                // conditioning frame of (segment pj, step t): aux columns + bias of fc1 / fc2 as per-frame tables
+            const int *SP = reinterpret_cast<const int *>(smem + i * DGRP + D_SP);
+            const int p0 = SP[pj] + t;
+            const int fr = (p0 < SP[SEG + pj]) ? (p0 / a.hop) : a.NF;
+            v0 = (LA ? a.c3f : a.c4f)[(size_t)fr * H + prow];
+        }
         if (kind == 3) {
             // this step's sampling noise, pre-transformed (wrnn_noise_mol_kernel): thread (segment tid >> 4, mixture tid & 15)
             const int b0 = GEO[2 * i];
@@ -704,7 +765,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
         {
             unsigned spins = 0;
             if (!ready) {
-                ok = ok && finish(xrs, DXL(i, kind == 1 ? L_H : 3, ring) * 4, w, lane, nb, x, b, a.status, spins);
+                ok = ok && finish(xrs, DXL(i, xl, ring) * 4, w, lane, nb, x, b, a.status, spins);
                 if (!ok && fcode == 0u) fcode = 0x600u | (LA ? 0u : 8u) | (unsigned)kind;
             }
             if (PROF && tid == 0) { PROFL[cur + 6] += 1; PROFL[cur + 7] += !ready; }
@@ -722,9 +783,16 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
         }
         {   // the next stage's polled layer, one stage ahead (not across a step boundary)
             xahead = false;
-            if (kind == 1 && (a.tuning & 1) == 0) {
-                if (i + 1 < nact) { xahead = true; issue(xrs, DXL(i + 1, L_H, ring) * 4, w, lane, x); }
-                else if (sampler) { xahead = true; issue(xrs, DXL(my_slot, 3, ring) * 4, w, lane, x); }
+            if (DUO_HH_XAHEAD && (a.tuning & 1) == 0 && kind != 3) {
+                int nk = 0, ni = 0;                     // the stage that follows in the step: gh of every slot, fc of the odd ones, sampling
+                if (kind == 1 && i + 1 < nact) { nk = 1; ni = i + 1; }
+                else if (kind == 1 && split_fc && nact >= 2) { nk = 2; ni = 1; }
+                else if (kind == 2 && i + 2 < nact) { nk = 2; ni = i + 2; }
+                else if (sampler) { nk = 3; ni = my_slot; }
+                if (nk != 0) {
+                    xahead = true;
+                    issue(xrs, DXL(ni, nk == 1 ? L_H : (nk == 2 ? L_P2 : 3), ring) * 4, w, lane, x);
+                }
             }
         }
         PH(cur + 4);
@@ -737,6 +805,11 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
             put_partial<3>(PW, w, 1, lane, o1);
             put_partial<3>(PW, w, 2, lane, o2);
             bk = BK_GH;
+        } else if (kind == 2) {
+#if DUO_SPLIT_FC
+            put_partial<3>(PW, w, 0, lane, mfma1(A_fc, b));
+#endif
+            bk = BK_RELU;
         } else {
             put_partial<3>(PW, w, 0, lane, mfma1_glb(a.fc3f + frag_off(w, 0, lane), b));
             put_partial<3>(PW, w, 1, lane, mfma1_glb(a.fc3f + XT + frag_off(w, 0, lane), b));
@@ -754,6 +827,11 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, i
 #pragma unroll 1
         for (int i = 0; i < nact; ++i)
             if (!stage(std::integral_constant<int, 1>{}, i)) goto bail;
+        if (split_fc) {
+#pragma unroll 1
+            for (int i = 1; i < nact; i += 2)
+                if (!stage(std::integral_constant<int, 2>{}, i)) goto bail;
+        }
         if (sampler) {
             if (!stage(std::integral_constant<int, 3>{}, my_slot)) goto bail;
         }

@@ -50,6 +50,7 @@
 
 namespace wrnn {
 
+constexpr int LOOP_PUBFIRST_DEPTH = 2;       // (measured: profiles/r03v_probe_pubfirst.json)
 constexpr int LOGS = 36;                     // row stride of the logits scratch: writer lane (row 4w + (l & 3), segment (l >> 2) & 15) -> bank 4 * segment + row: conflict-free
 constexpr int LPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][slot 0..2][16][16]
 struct LoopLds {
@@ -226,6 +227,14 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
     // fused stages (below): measured (profiles/r03i_probe_fused_*.json) 1-2 % faster with >= 4 groups in flight, 5-9 % SLOWER with 2 (the
     // publish of a fused half leaves later, inside the MFMA block, and at depth 2 a step is bound by the latency of that chain)
     const bool fuse_on = (a.tuning & 4) == 0 && nact >= 4;
+    // PUBLISH FIRST (round 3): with <= LOOP_PUBFIRST_DEPTH groups in flight a step is bounded by the latency of the slots' chains, and
+    // every hop of a chain ends with a back half (barrier, pointwise, publish) that used to wait behind the next stage's load issue
+    // and conditioning reads; there a stage now STARTS with the pending back half.  (Deeper pipelines are busy-bound: loads first,
+    // so they fly under the back half.)  tuning bit 5 = never, bit 6 = always.
+    const bool pubfirst = (a.tuning & 64) != 0 || ((a.tuning & 32) == 0 && nact <= LOOP_PUBFIRST_DEPTH);
+    // MoL: hardware exp / rcp in the GRU pointwise math (gru_update_fast, as wrnn_duo.hip; inside the 1e-5 tolerance); RAW keeps the
+    // library forms (bit-exact class indices).  tuning bit 7 = the library forms for MoL too.
+    const bool fast_pw = MOL && (a.tuning & 128) == 0;
     int bk = BK_NONE, bi = 0, bpp = 0, bt = 0, cur_ph = 0;
     float bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
 
@@ -242,7 +251,8 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
             const float giz = get_partial<3>(PB, 1, pu, pj) + bc1;
             const float gin = get_partial<3>(PB, 2, pu, pj) + bc2;
             const float xo = GP[O_XO + tid];
-            const float hn = gru_update_sel(gir, giz, gin, GP[tid], GP[256 + tid], GP[512 + tid], GP[O_HOWN + tid]);
+            const float hn = fast_pw ? gru_update_fast(gir, giz, gin, GP[tid], GP[256 + tid], GP[512 + tid], GP[O_HOWN + tid])
+                                     : gru_update_sel(gir, giz, gin, GP[tid], GP[256 + tid], GP[512 + tid], GP[O_HOWN + tid]);
             GP[O_HOWN + tid] = hn;
             publish4_nb(xrs, (XLAYER(bi, roleA ? 0 : 1, bring) + 256 * J) * 4, tid, hn, pj < nb);
             publish4_nb(xrs, (XLAYER(bi, roleA ? 5 : 6, bring) + 256 * J) * 4, tid, xo + hn, pj < nb);
@@ -283,7 +293,8 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
             const float gir = get_partial<3>(PB, 0, pu, pj) + bc0;
             const float giz = get_partial<3>(PB, 1, pu, pj) + bc1;
             const float gin = get_partial<3>(PB, 2, pu, pj) + bc2;
-            const float hn = gru_update(gir, giz, gin, GP[tid], GP[256 + tid], GP[512 + tid], GP[O_HOWN + tid]);
+            const float hn = fast_pw ? gru_update_fast(gir, giz, gin, GP[tid], GP[256 + tid], GP[512 + tid], GP[O_HOWN + tid])
+                                     : gru_update(gir, giz, gin, GP[tid], GP[256 + tid], GP[512 + tid], GP[O_HOWN + tid]);
             GP[O_HOWN + tid] = hn;
             publish4(xrs, (XLAYER(bi, roleA ? 0 : 1, bring) + 256 * J) * 4, tid, hn, pj < nb);
             // ... and the residual sum of the owned units, so its consumers load ONE layer: x1 = xi + h1 (:212) for role B's rnn2
@@ -477,8 +488,11 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
         const float *cIg = a.cIf + ((size_t)tc * NGR + g) * XT;
         float4 c[8];
         float v0 = 0.f, v1 = 0.f, v2 = 0.f;           // conditioning / noise values the back half needs
-        cur_ph = ph;
         if (PROF && tid == 0 && plast == 0) plast = __builtin_amdgcn_s_memtime();
+        if (pubfirst) {                                 // (cur_ph still names the stage the half belongs to: its clocks go there)
+            if (!run_back(std::integral_constant<unsigned, KM>{})) return false;
+        }
+        cur_ph = ph;
         // ---------------- front, part 1 --------------------------------------------------------------------------------
         // The polled layer: normally its loads were issued ONE STAGE AGO (before the previous stage's MFMA tiles), so they
         // have landed.  They are consumed FIRST, before anything else touches vector memory: vmcnt retires in order, so a
@@ -527,7 +541,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
         // below (the wave issues in order and is alone on its SIMD: otherwise the VALU idles through every 96-MFMA block and the
         // MFMA pipe through every pointwise half).
         constexpr int KOWN = ph == 0 ? BK_GATES : BK_GH;       // (phases 0, 1 only)
-        const bool fuse = fuse_on && ph < 2 && bk == KOWN && (!polled || ready);
+        const bool fuse = !pubfirst && fuse_on && ph < 2 && bk == KOWN && (!polled || ready);
         if (fuse) {
             if (!ok) FAIL[0] = 1;
             lds_barrier();

@@ -226,4 +226,17 @@ __device__ __forceinline__ void make_xi(const float4 (&c)[8], const float *WI0, 
     }
 }
 
+// GRU pointwise math with the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each) instead of the library's expf, tanhf
+// and IEEE divisions: ~25 VALU instead of ~120 on the critical back half of every gate stage.  Same algebra as gru_update
+// (wrnn_device.h); absolute error ~1e-7 per value, the size of the fp32 rounding already present (MoL tolerance 1e-5: tests).
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float gru_update_fast(float gi_r, float gi_z, float gi_n, float gh_r, float gh_z, float gh_n, float h)
+{
+    const float r = fast_sigmoid(gh_r + gi_r);
+    const float z = fast_sigmoid(gh_z + gi_z);
+    const float n = fast_tanh(gi_n + gh_n * r);
+    return (h - n) * z + n;
+}
+
 }  // namespace wrnn
