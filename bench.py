@@ -326,6 +326,41 @@ def main():
                 'kernel': model.last_loop_kernel, 'split': eng.last_run_info(),
                 'hbm_equivalent_GBps': round(bytes_eq / (k * 1e-3) / 1e9, 1), 'hbm_equivalent_frac': round(bytes_eq / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
+    def config3():
+        """BASELINE config 3 end to end (gen_tacotron.py:131-149): text -> Tacotron (encoder, decoder loop as one persistent
+        kernel, CBHG post-net with its GRUs as persistent kernels) -> `_, m, _` -> (m + 4) / 8 clipped -> this vocoder's
+        `generate()` (batched, target 11000 / overlap 550), random-init Tacotron of the reference's architecture, 800 frames."""
+        import tempfile
+        from wavernn_amd.synthetic import random_tacotron_state_dict
+        from wavernn_amd.tacotron import TacotronInference, text_to_ids, tacotron_to_wavernn_mel
+        shapes = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'wavernn_amd', 'tacotron_shapes.json')))
+        tts = TacotronInference(random_tacotron_state_dict(3, shapes), device=dev)
+        ids = text_to_ids('Scientists at the CERN laboratory say they have discovered a new particle.')
+        was = model.noise_source
+        model.noise_source = 'device'
+        steps = 800
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, 'o.wav')
+
+            def run():
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, lin, _ = tts.generate(ids, steps=steps, kernel=True)
+                t1 = time.perf_counter()
+                wav = model.generate(torch.tensor(tacotron_to_wavernn_mel(lin)).unsqueeze(0), path, True, target, overlap, True)
+                return wav, t1 - t0, time.perf_counter() - t1
+            run()
+            runs = [run() for _ in range(3)]
+        model.noise_source = was
+        model.eval()
+        wav = runs[0][0]
+        t_tts, t_voc = float(np.median([r[1] for r in runs])), float(np.median([r[2] for r in runs]))
+        audio_s = wav.shape[0] / SAMPLE_RATE
+        return {'what': 'BASELINE config 3: Tacotron (800 decoder steps, decoder loop + CBHG GRUs as persistent kernels) -> MoL WaveRNN, one sentence, end to end incl. the WAV write',
+                'tacotron_ms': round(t_tts * 1e3, 2), 'vocoder_ms': round(t_voc * 1e3, 2), 'loop_kernel_ms': round(float(model.last_loop_ms), 2),
+                'kernel': model.last_loop_kernel, 'audio_s': round(audio_s, 3), 'samples': int(wav.shape[0]),
+                'realtime_factor': round(audio_s / (t_tts + t_voc), 2)}
+
     if rank == 0:
         T = plan.T
         n_local = hi0 - lo0                                  # segments this GPU's launches advance (rank 0's block)
@@ -397,6 +432,11 @@ def main():
                 res['config']['single_utterance'] = [single_utterance(481), single_utterance(1001)]
             except Exception as e:
                 res['config']['single_utterance'] = {'error': repr(e)}
+            if mode == 'MOL':
+                try:
+                    res['config']['config3'] = config3()
+                except Exception as e:
+                    res['config']['config3'] = {'error': repr(e)}
             if args.utterances > 8:
                 try:    # round 1's workload (8 utterances = 128 segments per GPU), for continuity
                     sub = mels[:8]

@@ -364,3 +364,12 @@ def test_sliced_generate_degrades_to_stream_when_the_grid_is_refused(tmp_path, m
     whole = draw_steps('MOL', B, T, 30, 'cpu', 'cpu')
     assert abs(calls[1][2] - float(whole.sum())) < 1e-3
     assert torch.equal(after, torch.empty(3).uniform_(0, 1))
+
+
+def test_packaged_tacotron_shapes_equal_the_golden_table():
+    """bench.py's config-3 leg builds its random-init Tacotron from wavernn_amd/tacotron_shapes.json: the same (key, shape, dtype)
+    table scripts/make_golden.py wrote from the reference's module into tests/golden/."""
+    import json
+    a = json.load(open(os.path.join(ROOT, 'wavernn_amd', 'tacotron_shapes.json')))
+    b = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'tacotron_shapes.json')))
+    assert a == b and len(a) > 100

@@ -46,7 +46,7 @@ TACO_WEIGHT_FIELDS = ('prenet_fc1_w', 'prenet_fc1_b', 'prenet_fc2_w', 'prenet_fc
 
 
 class TacoWeights(ctypes.Structure):
-    """wrnn_taco_weights (DRAFT: the Tacotron decoder kernel)."""
+    """wrnn_taco_weights (the Tacotron decoder kernels)."""
     _fields_ = [('struct_bytes', ctypes.c_uint32)] + \
                [(n, ctypes.c_int32) for n in ('n_mels', 'prenet1', 'prenet2', 'decoder_dims', 'encoder_width', 'lstm_dims', 'attn_filters',
                                               'attn_kernel')] + \

@@ -1,5 +1,8 @@
-// wrnn_taco.hip -- DRAFT (compiles; never run on a GPU): the Tacotron DECODER LOOP of BASELINE config 3 as ONE persistent
-// cooperative kernel.
+// wrnn_taco.hip -- the Tacotron side of BASELINE config 3: the DECODER LOOP as ONE persistent
+// cooperative kernel, in two forms -- wrnn_taco_decoder_kernel (flag barriers, weights from L2: any CU count; described here) and
+// wrnn_taco_resident_kernel (register-resident weights, tagged exchange: what runs on an MI355X; further down) -- and the CBHGs'
+// bidirectional GRU as a persistent kernel (wrnn_bigru_kernel).  Parity: tests/test_gpu_config3.py (<= 1e-8 against the CPU mirror
+// of the reference on 200 frames).
 //
 // Replaces the per-frame Python loop of `Tacotron.generate()` (reference models/tacotron.py:396-414) around `Decoder.forward`
 // (:218-279: PreNet :141-155, attention GRUCell, LSA attention :181-207, rnn_input, two residual LSTMCells, mel_proj) for ONE
@@ -9,8 +12,7 @@
 //     (dot products): a WAVE owns a row (or a recurrent UNIT = its 6 / 8 gate rows), lanes split K with 16-byte loads, a DPP /
 //     shuffle butterfly sums the 64 partials.  No MFMA: one column.
 //   * weights (5.9 M f32 = 23.6 MB) are NOT staged: they are immutable, read with plain loads and stay in L2 / MALL between
-//     steps (every row is read by exactly one wave per step).  [Register residency, as in the vocoder kernel, is the follow-up:
-//     DESIGN.md section 9 item 3.]
+//     steps (every row is read by exactly one wave per step).  [Register residency: wrnn_taco_resident_kernel below.]
 //   * activations (<= 512 floats per layer) cross workgroups through a 36 KB workspace with device-coherent (sc1) stores / loads,
 //     layers separated by a flag barrier: every workgroup drains its stores, writes its arrival word, polls all arrival words
 //     (no atomics, bounded spins, failure code in the status words -- the conventions of wrnn_loop.hip).  Ten barriers per step.
