@@ -173,6 +173,44 @@ __global__ __launch_bounds__(256) void wrnn_upstage_kernel(const float *__restri
     }
 }
 
+// The LAST stage through an LDS tile (round 3): wrnn_upstage_kernel<.., true, ..> maps consecutive threads to consecutive CHANNELS of
+// one sample (the output is [sample][channel]), so each of its 2 s + 1 reads per output walks 80 different rows of the input --
+// 0.38 ms per 641-frame utterance (150 GB/s) in profiles/r03k_kernel_stats.csv.  Here a workgroup computes a 64-sample x 80-channel
+// tile with consecutive threads on consecutive SAMPLES of one channel (a wave touches ~7 input words), parks it in LDS and
+// writes it out row by row, coalesced.  Same taps in the same order per output: bit-identical values.
+template <int S>
+__global__ __launch_bounds__(256) void wrnn_upstage_last_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                                const float *__restrict__ taps, int n_in, int s_rt, int indent)
+{
+    constexpr int TQ = 64;
+    __shared__ float tile[TQ][PFEAT + 1];
+    const int s = S > 0 ? S : s_rt;
+    const long n_out = (long)n_in * s, nq = n_out - 2L * indent;
+    for (long q0 = (long)blockIdx.x * TQ; q0 < nq; q0 += (long)gridDim.x * TQ) {
+        for (int e = threadIdx.x; e < TQ * PFEAT; e += 256) {
+            const int c = e / TQ, ql = e % TQ;
+            const long q = q0 + ql + indent;
+            float acc = 0.f;
+            if (q0 + ql < nq) {
+#pragma unroll
+                for (int j = 0; j <= 2 * s; ++j) {
+                    const long u = q + j - s;
+                    float v = 0.f;
+                    if (u >= 0 && u < n_out) v = in[(size_t)c * n_in + (int)(u / s)];
+                    acc = fmaf(taps[j], v, acc);
+                }
+            }
+            tile[ql][c] = acc;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < TQ * PFEAT; e += 256) {
+            const int ql = e / PFEAT, c = e % PFEAT;
+            if (q0 + ql < nq) out[(size_t)(q0 + ql) * PFEAT + c] = tile[ql][c];
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace wrnn
 
 using namespace wrnn;
@@ -284,16 +322,16 @@ extern "C" int wrnn_pre_upsample(const wrnn_pre *p, const float *mel, int32_t n_
     auto grid = [](long total) { long b = (total + 255) / 256; return (unsigned)(b > 65535 ? 65535 : (b < 1 ? 1 : b)); };
     const bool shipped = p->scales[0] == 5 && p->scales[1] == 5 && p->scales[2] == 11;       // hparams.py: voc_upsample_factors
     const unsigned g1 = grid((long)nf * p->scales[0] * PFEAT), g2 = grid((long)nf * p->scales[0] * p->scales[1] * PFEAT);
-    const unsigned g3 = grid((long)n_frames * p->total_scale * PFEAT);
+    const unsigned g3 = grid((long)n_frames * p->total_scale * 4);      // one 64-sample x 80-channel tile per workgroup and trip
     const int n2 = nf * p->scales[0], n3 = n2 * p->scales[1], indent = PPAD * p->total_scale;
     if (shipped) {
         hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 5>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, 5, PPAD, 0);
         hipLaunchKernelGGL((wrnn_upstage_kernel<false, false, 5>), dim3(g2), dim3(256), 0, stream, s1, s2, p->taps[1], n2, 5, 0, 0);
-        hipLaunchKernelGGL((wrnn_upstage_kernel<false, true, 11>), dim3(g3), dim3(256), 0, stream, s2, mels_up, p->taps[2], n3, 11, 0, indent);
+        hipLaunchKernelGGL((wrnn_upstage_last_kernel<11>), dim3(g3), dim3(256), 0, stream, s2, mels_up, p->taps[2], n3, 11, indent);
     } else {
         hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 0>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, p->scales[0], PPAD, 0);
         hipLaunchKernelGGL((wrnn_upstage_kernel<false, false, 0>), dim3(g2), dim3(256), 0, stream, s1, s2, p->taps[1], n2, p->scales[1], 0, 0);
-        hipLaunchKernelGGL((wrnn_upstage_kernel<false, true, 0>), dim3(g3), dim3(256), 0, stream, s2, mels_up, p->taps[2], n3, p->scales[2], 0, indent);
+        hipLaunchKernelGGL((wrnn_upstage_last_kernel<0>), dim3(g3), dim3(256), 0, stream, s2, mels_up, p->taps[2], n3, p->scales[2], indent);
     }
     PRE_HIP(hipGetLastError());
     return WRNN_OK;
