@@ -116,12 +116,13 @@ def pytorch_eager_baseline(sd, mode, target, overlap, budget_s):
 
 def source_sha16():
     """Hash of the kernel sources a measurement belongs to (keys profiles/traffic_latest.json to the code it measured; the
-    workload is matched separately: kernel, mode, segments, T)."""
-    import glob
+    workload is matched separately: kernel, mode, segments, T): the translation units and headers the vocoder's loop kernels,
+    their launcher and the conditioning slabs they read are compiled from -- not the Tacotron / generic / sparse / self-test
+    units, which cannot change what those dispatches move."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, 'wavernn_amd', 'csrc', '*.h*'))):
-        h.update(open(f, 'rb').read())
+    for name in ('wrnn_abi.hip', 'wrnn_cond.hip', 'wrnn_device.h', 'wrnn_duo.hip', 'wrnn_loop.hip', 'wrnn_ring.h', 'wrnn_tiles.h'):
+        h.update(open(os.path.join(ROOT, 'wavernn_amd', 'csrc', name), 'rb').read())
     return h.hexdigest()[:16]
 
 

@@ -148,20 +148,36 @@ __global__ __launch_bounds__(256, 1) void wrnn_cond_frag_kernel(const CondArgs a
         bias[tt] = *reinterpret_cast<const float4 *>(a.I_b + 128 * w + 16 * tt + 4 * kq);
     }
     const long tiles = (long)(a.t1 - a.t0) * a.NG;
-    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    // this thread's 7 input values of a tile ([segment rr][k], q = tid + 256 i): gathered one tile AHEAD, so the two dependent global
+    // loads (segment table -> conditioning row) fly under the previous tile's 224 MFMAs instead of in front of them (round 3: the
+    // kernel ran 105 us per slab at one wave per SIMD, a third of it MFMA)
+    constexpr int NQ = (16 * KCOND + 255) / 256;
+    auto gather = [&](long tile, float (&v)[NQ]) {
         const int t = a.t0 + (int)(tile / a.NG), g = (int)(tile % a.NG);
         const int b0 = a.rb0 + (int)(((long)g * a.B) / a.NG), nb = a.rb0 + (int)(((long)(g + 1) * a.B) / a.NG) - b0;
-        __syncthreads();
-        for (int q = tid; q < 16 * KCOND; q += 256) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = tid + 256 * i;
             const int rr = q / KCOND, k = q % KCOND;
             float val = 0.f;
-            if (rr < nb) {
+            if (q < 16 * KCOND && rr < nb) {
                 const int p = a.seg_pos[b0 + rr] + t;
                 if (p < a.seg_lim[b0 + rr]) val = (k < MEL) ? a.mels_up[(size_t)p * MEL + k] : a.aux[(size_t)(p / a.hop) * 4 * AUX + (k - MEL)];
             }
-            in[rr * CLD + k] = val;
+            v[i] = val;
+        }
+    };
+    float cur[NQ] = {}, nxt[NQ] = {};
+    if (blockIdx.x < tiles) gather(blockIdx.x, cur);
+    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = tid + 256 * i;
+            if (q < 16 * KCOND) in[(q / KCOND) * CLD + q % KCOND] = cur[i];
         }
         __syncthreads();
+        if (tile + gridDim.x < tiles) gather(tile + gridDim.x, nxt);
         float4 bf[CKB];
 #pragma unroll
         for (int r = 0; r < CKB; ++r) bf[r] = *reinterpret_cast<const float4 *>(in + fi * CLD + 16 * r + 4 * kq);
@@ -183,6 +199,8 @@ __global__ __launch_bounds__(256, 1) void wrnn_cond_frag_kernel(const CondArgs a
 #pragma unroll
         for (int tt = 0; tt < 8; ++tt)
             dst[tt * 64] = make_float4(acc[tt][0] + bias[tt].x, acc[tt][1] + bias[tt].y, acc[tt][2] + bias[tt].z, acc[tt][3] + bias[tt].w);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) cur[i] = nxt[i];
     }
 }
 

@@ -330,6 +330,8 @@ __global__ __launch_bounds__(NT, 1) void wrnn_taco_decoder_kernel(const TacoArgs
 // in program order: all reads of step t + 1 before its own LSTM layers are behind it.  (Hence exactly 128 workgroups.)
 // Summation order: lanes split K in float4 chunks as row_dot above, the 64 partials are summed by a DPP tree + 4 read-lanes
 // (not the shuffle butterfly): results differ from the kernel above in the last bits; both are inside the test's tolerance.
+// (Hardware exp / rcp in the gate functions were measured -- profiles/r03ac_taco_profile.json: 28.5 -> 26.6 us per step -- and
+// NOT kept: the error against the CPU mirror of the reference grew from 5e-9 to 2e-5 over 200 frames for 0.7 % of config 3.)
 // =================================================================================================================================
 constexpr int R_NWG = 128, R_NWV = R_NWG * NW;
 constexpr int R_MAXR = 8;
@@ -597,13 +599,10 @@ __global__ __launch_bounds__(NT, 1) void wrnn_taco_resident_kernel(const TacoArg
         {
             float part = 0.f;
             for (int k = tid; k < n; k += NT) part += sc[k];
-            red[tid] = part;
+            part = wave_total(part);                                   // the same tree in every workgroup: the same total everywhere
+            if (lane == 0) red[w] = part;
             __syncthreads();
-            for (int m = NT / 2; m >= 1; m >>= 1) {
-                if (tid < m) red[tid] += red[tid + m];
-                __syncthreads();
-            }
-            const float total = red[0];
+            const float total = (red[0] + red[1]) + (red[2] + red[3]);
             for (int k = tid; k < n; k += NT) {
                 const float v = sc[k] / total;
                 sc[k] = v; att[k] = v; cum[k] += v;
