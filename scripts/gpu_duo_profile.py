@@ -9,8 +9,11 @@ from wavernn_amd.engine import LoopEngine
 from wavernn_amd.synthetic import random_state_dict
 ap = argparse.ArgumentParser()
 ap.add_argument('--depth', type=int, default=8); ap.add_argument('--B', type=int, default=512); ap.add_argument('--T', type=int, default=480)
-ap.add_argument('--tuning', type=int, default=0); ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'duo_phase_clocks.json'))
+ap.add_argument('--tuning', type=int, default=0); ap.add_argument('--so', default=None); ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'duo_phase_clocks.json'))
 a = ap.parse_args()
+if a.so:
+    import wavernn_amd._lib as _L
+    _L.SO_PATH = os.path.abspath(a.so)
 dev = torch.device('cuda', 0)
 eng = LoopEngine(random_state_dict(0, mode='MOL'), 'MOL', device=dev)
 rs = np.random.RandomState(3)
@@ -36,6 +39,7 @@ for name, lo, rows in (('A-ih gates', 0, slice(0, 256, 2)), ('A-ih fc', 8, slice
     res[name] = {n: round(float(x), 1) for n, x in zip(names[:6], per)}
     res[name]['total cycles per group-step'] = round(float(per.sum()), 1)
     res[name]['polled fraction'] = round(float(m[7] / max(m[6], 1)), 4)
-    print(f'{name:12s}', ' '.join(f'{n}={x:7.0f}' for n, x in zip(names[:6], per)), f'| total {per.sum():7.0f} cycles per group-step; polled {m[7] / max(m[6], 1):.3f}')
+    res[name]['slot6 per group-step (DUO_PROF_SPLIT builds: cycles of hygiene + xi)'] = round(float(m[6] / gs), 1)
+    print(f'{name:12s}', ' '.join(f'{n}={x:7.0f}' for n, x in zip(names[:6], per)), f'| total {per.sum():7.0f} cycles per group-step; polled {m[7] / max(m[6], 1):.3f}; slot6 {m[6] / gs:7.0f}')
 print(json.dumps({k: res[k] for k in ('plain_ms', 'profiled_ms', 'us_per_step')}))
 json.dump(res, open(a.out, 'w'), indent=1)
