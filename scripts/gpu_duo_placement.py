@@ -19,12 +19,12 @@ mels_up = torch.from_numpy(rs.uniform(0, 1, (L, 80)).astype(np.float32)).to(dev)
 aux = torch.from_numpy(rs.uniform(-1, 1, (L // hop, 128)).astype(np.float32)).to(dev)
 noise = torch.empty(T, 11 * B, device=dev).uniform_(1e-5, 1 - 1e-5)
 pc = torch.zeros(256, 32, dtype=torch.int64, device=dev)
-eng.run(mels_up, aux, B, T, stride, noise, hop, algo='duo', depth=4, phase_clocks=pc)
+eng.run(mels_up, aux, B, T, stride, noise, hop, algo='duo', depth=4, phase_clocks=pc, tuning=64)
 v = pc.cpu().numpy().reshape(-1)[:512].astype(np.uint64)
 hw = (v & np.uint64(0xFFFFFFFF)).astype(np.uint32)
 xcc = ((v >> np.uint64(32)) & np.uint64(0xFF)).astype(np.uint32)
 meta = (v >> np.uint64(40)).astype(np.uint32)
-role, J, cl = meta & 3, (meta >> 2) & 63, (meta >> 8) & 15
+role, J, cl = meta & 3, (meta >> 2) & 63, (meta >> 8) & 15       # role: bit 0 = rnn2, bit 1 = hh
 vary = np.bitwise_or.reduce(hw) ^ np.bitwise_and.reduce(hw)
 print('HW_ID bits that vary: 0x%08x' % vary)
 key = hw & np.uint32(0x0000FF00)                        # cu_id [11:8], sh_id [12], se_id [15:13]
@@ -34,6 +34,10 @@ for b in range(512):
 hist = collections.Counter()
 for k, lst in sorted(cus.items()):
     hist[tuple(sorted(r for r, _, _, _ in lst))] += 1
+xl = collections.defaultdict(set)
+for b in range(512):
+    xl[(int(cl[b]), int(role[b]) & 1)].add(int(xcc[b]) & 15)
+print('XCCs hosting (cluster, layer):', {k: sorted(v) for k, v in sorted(xl.items())})
 print('CUs seen:', len(cus), ' roles sharing a CU -> number of CUs:', dict(hist))
 for k, lst in list(sorted(cus.items()))[:6]:
     print(k, lst)

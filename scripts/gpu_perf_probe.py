@@ -39,12 +39,16 @@ VARS = {'auto': dict(algo='auto'), 'stream': dict(algo='stream'), 'g1': dict(alg
         'c1g1': dict(algo='loop', clusters=1, depth=1), 'c2g1': dict(algo='loop', clusters=2, depth=1), 'c1g2': dict(algo='loop', clusters=1, depth=2),
         'nola': dict(algo='loop', tuning=1), 'fence': dict(algo='loop', tuning=2), 'nola-fence': dict(algo='loop', tuning=3),
         's1': dict(algo='sparse', depth=1), 's2': dict(algo='sparse', depth=2),
+        # wrnn_duo_kernel (round 4): tuning bit 0 = loads first, bit 1 = publish first (default: by depth), bit 8 = every layer written through
+        # (no XCD-local plain stores), bit 2 = ring re-filled before every launch
         'd1': dict(algo='duo', depth=1), 'd2': dict(algo='duo', depth=2), 'd3': dict(algo='duo', depth=3), 'd4': dict(algo='duo', depth=4),
-        'd8': dict(algo='duo', depth=8), 'dauto': dict(algo='duo'), 'd4fill': dict(algo='duo', depth=4, tuning=4),
-        'd8p': dict(algo='duo', depth=8, tuning=8), 'd8i': dict(algo='duo', depth=8, tuning=16), 'd8h': dict(algo='duo', depth=8, tuning=32),
-        'd8pi': dict(algo='duo', depth=8, tuning=24), 'd4p': dict(algo='duo', depth=4, tuning=8), 'd6': dict(algo='duo', depth=6), 'nola8': dict(algo='duo', depth=8, tuning=1),
-        'd4l1': dict(algo='duo', depth=4, tuning=1 << 9), 'd4l2': dict(algo='duo', depth=4, tuning=2 << 9), 'd4l3': dict(algo='duo', depth=4, tuning=3 << 9), 'd4l4': dict(algo='duo', depth=4, tuning=4 << 9),
-        'd8l2': dict(algo='duo', depth=8, tuning=2 << 9), 'd8l3': dict(algo='duo', depth=8, tuning=3 << 9), 'd8l4': dict(algo='duo', depth=8, tuning=4 << 9), 'd8l7': dict(algo='duo', depth=8, tuning=7 << 9),
+        'd5': dict(algo='duo', depth=5), 'd6': dict(algo='duo', depth=6), 'd8': dict(algo='duo', depth=8), 'dauto': dict(algo='duo'),
+        'd2lf': dict(algo='duo', depth=2, tuning=1), 'd3lf': dict(algo='duo', depth=3, tuning=1), 'd4lf': dict(algo='duo', depth=4, tuning=1),
+        'd6lf': dict(algo='duo', depth=6, tuning=1), 'd8lf': dict(algo='duo', depth=8, tuning=1),
+        'd2pf': dict(algo='duo', depth=2, tuning=2), 'd4pf': dict(algo='duo', depth=4, tuning=2), 'd6pf': dict(algo='duo', depth=6, tuning=2),
+        'd8pf': dict(algo='duo', depth=8, tuning=2),
+        'd4wt': dict(algo='duo', depth=4, tuning=256), 'd8wt': dict(algo='duo', depth=8, tuning=256), 'd4lfwt': dict(algo='duo', depth=4, tuning=257),
+        'd8lfwt': dict(algo='duo', depth=8, tuning=257), 'd1wt': dict(algo='duo', depth=1, tuning=256),
         'g2ns': dict(algo='loop', depth=2, tuning=16), 'g4ns': dict(algo='loop', depth=4, tuning=16), 'g8ns': dict(algo='loop', depth=8, tuning=16),
         'g1nf': dict(algo='loop', depth=1, tuning=4), 'g2nf': dict(algo='loop', depth=2, tuning=4), 'g4nf': dict(algo='loop', depth=4, tuning=4),
         'd3o': dict(algo='duo', depth=3, tuning=128), 'd4o': dict(algo='duo', depth=4, tuning=128), 'd8o': dict(algo='duo', depth=8, tuning=128), 'd6o': dict(algo='duo', depth=6, tuning=128),

@@ -65,7 +65,7 @@ struct wrnn_pack {
     const float *fc1_w, *fc1_b, *fc2_w, *fc2_b, *fc3_w, *fc3_b;
     const float *w_ih1T, *w_hh1T, *w_ih2T, *w_hh2T, *fc1T, *fc2T, *fc3T, *c2_wT, *c3_wT, *c4_wT;
     const float *fc3f;         // MOL: fc3.weight in A-fragment order (wrnn_duo.hip)
-    const float *fc12f;        // MOL: fc1 / fc2 (first 512 columns) in A-fragment order per unit block (wrnn_duo.hip)
+    const float *u1;           // MOL: rnn1.weight_ih . I.weight[:,0] [3H] -- the x_{t-1} term of rnn1's gi (wrnn_duo.hip)
     // dimension-generic pack (any hparams but the shipped ones): only the k-major copies + biases, run by wrnn_generic_kernel
     bool generic;
     int gH, gF, gM, gA;
@@ -201,20 +201,14 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
                 b.host[o_fc3f + (size_t)q * 4 + e] = row < C ? w->fc3_w[(size_t)row * H + 128 * wv + 16 * r + 4 * kq + e] : 0.f;
         }
     }
-    // MOL: fc1 / fc2 rows [16 J, 16 J + 16) x columns [0, 512) per unit block J as one MFMA A tile in fragment order (the aux columns
-    // are hoisted into the c3f / c4f tables): [layer][J][wave][k-block r][lane (row fi, k-quad kq)][4]
-    size_t o_fc12f = 0;
+    // MOL: u1 = rnn1.weight_ih . I.weight[:,0] (double accumulation, rounded once): gi = W_ih . (cI + w0 x) + b = W_ih . cI + x u1 + b
+    size_t o_u1 = 0;
     if (w->mode == WRNN_MODE_MOL) {
-        o_fc12f = b.add(nullptr, (size_t)2 * H * H);
-        for (int layer = 0; layer < 2; ++layer) {
-            const float *fw = layer == 0 ? w->fc1_w : w->fc2_w;
-            for (int J = 0; J < H / 16; ++J)
-                for (int q = 0; q < 16 * H / 4; ++q) {
-                    const int l6 = q & 63, r = (q >> 6) & 7, wv = (q >> 9) & 3;
-                    const int row = 16 * J + (l6 & 15), kq = l6 >> 4;
-                    for (int e = 0; e < 4; ++e)
-                        b.host[o_fc12f + ((size_t)(layer * (H / 16) + J) * 16 * H) + (size_t)q * 4 + e] = fw[(size_t)row * K2 + 128 * wv + 16 * r + 4 * kq + e];
-                }
+        o_u1 = b.add(nullptr, (size_t)3 * H);
+        for (int r = 0; r < 3 * H; ++r) {
+            double acc = 0.0;
+            for (int k = 0; k < H; ++k) acc += (double)w->w_ih1[(size_t)r * H + k] * (double)col0[k];
+            b.host[o_u1 + r] = (float)acc;
         }
     }
     // ---- block-sparse view of the GRU matrices (16x1 blocks: 16 consecutive rows of one gate x 1 column) -----------
@@ -279,7 +273,7 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     p->fc1T = base + o_fc1T; p->fc2T = base + o_fc2T; p->fc3T = base + o_fc3T;
     p->c2_wT = base + o_c2_wT; p->c3_wT = base + o_c3_wT; p->c4_wT = base + o_c4_wT;
     p->fc3f = w->mode == WRNN_MODE_MOL ? base + o_fc3f : nullptr;
-    p->fc12f = w->mode == WRNN_MODE_MOL ? base + o_fc12f : nullptr;
+    p->u1 = w->mode == WRNN_MODE_MOL ? base + o_u1 : nullptr;
     p->sp_nbp = sp_nbp; p->sp_max_blocks = sp_max;
     p->sp_vals = sp_nbp ? base + o_spv : nullptr;
     p->sp_cols = sp_nbp ? reinterpret_cast<const int *>(base + o_spc) : nullptr;
@@ -389,7 +383,7 @@ struct Plan {
 };
 
 struct WsLayout {
-    size_t status, segs, c2f, c3f, c4f;
+    size_t status, xcc, segs, c2f, c3f, c4f;
     size_t gran, cI, npre;              // stream / sparse kernels: granules, whole-T conditioning, derived MOL noise
     size_t xbuf, state, cIf;            // loop kernel: exchange buffer, per-round state, conditioning slab
     size_t total;
@@ -480,6 +474,10 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
                 if (slab > 1024) slab = 1024;
             }
             if (slab > T) slab = T;
+            {   // the conditioning slab is addressed with 32-bit buffer offsets (wrnn_duo.hip)
+                const size_t per_step = (size_t)pl->ngr_max * SEG * H * sizeof(float);
+                if ((size_t)slab * per_step > 0x7FF00000u) slab = (int)(0x7FF00000u / per_step);
+            }
             pl->slab = slab;
         } else if (algo == WRNN_ALGO_LOOP) {
             set_err("the loop kernel needs >= 64 CUs and (MOL or RAW with 512 classes); device has %d CUs, C=%d", p->n_cus, p->C);
@@ -499,6 +497,7 @@ WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frame
     memset(&l, 0, sizeof l);
     size_t o = 0;
     l.status = o; o = al(o + STATUS_WORDS * sizeof(unsigned));
+    l.xcc = o;    o = al(o + XCC_WORDS * sizeof(unsigned));
     l.segs = o;   o = al(o + (size_t)2 * B * sizeof(int));
     if (pl.kind == K_GENERIC) { l.total = o; return l; }
     l.c2f = o;    o = al(o + (size_t)(n_frames + 1) * 3 * H * sizeof(float));
@@ -518,6 +517,27 @@ WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frame
     l.total = o;
     return l;
 }
+// p / hop == __umulhi(p, magic) >> shift for every 0 <= p < 2^31 (Granlund-Montgomery, N = 31: magic = ceil(2^(31 + s) / hop) with
+// s = ceil(log2 hop) fits 32 bits and its error term is <= 2^s); checked below on the multiples of hop and their neighbours.  magic = 0:
+// the kernel divides.
+void hop_magic(int hop, unsigned *magic, int *shift)
+{
+    *magic = 0u; *shift = 0;
+    if (hop < 2) return;
+    int s = 0;
+    while ((1ll << s) < hop) ++s;
+    const unsigned long long m = ((1ull << (31 + s)) + (unsigned long long)hop - 1ull) / (unsigned long long)hop;
+    if (m >> 32) return;
+    const int sh = s - 1;
+    for (long long q = 0; q * hop < (1ll << 31); q += 997) {            // spot check (the bound is a theorem; this guards the arithmetic)
+        for (long long p = q * hop - 1; p <= q * hop + 1; ++p) {
+            if (p < 0 || p >= (1ll << 31)) continue;
+            if ((long long)(((unsigned long long)p * m) >> (32 + sh)) != p / hop) return;
+        }
+    }
+    *magic = (unsigned)m; *shift = sh;
+}
+
 int check_geometry(const wrnn_geometry *g)
 {
     if (!g) { set_err("NULL geometry"); return WRNN_ERR_ARG; }
@@ -649,7 +669,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     memset(&a, 0, sizeof a);
     a.I_w0 = p->I_w0; a.w_ih1 = p->w_ih1; a.w_hh1 = p->w_hh1; a.b_ih1 = p->b_ih1; a.b_hh1 = p->b_hh1;
     a.w_ih2 = p->w_ih2; a.w_hh2 = p->w_hh2; a.b_hh2 = p->b_hh2; a.fc1_w = p->fc1_w; a.fc2_w = p->fc2_w;
-    a.fc3_w = p->fc3_w; a.fc3_b = p->fc3_b; a.fc3f = p->fc3f; a.fc12f = p->fc12f;
+    a.fc3_w = p->fc3_w; a.fc3_b = p->fc3_b; a.fc3f = p->fc3f; a.u1 = p->u1;
     a.w_ih1T = p->w_ih1T; a.w_hh1T = p->w_hh1T; a.w_ih2T = p->w_ih2T; a.w_hh2T = p->w_hh2T;
     a.fc1T = p->fc1T; a.fc2T = p->fc2T; a.fc3T = p->fc3T;
     a.c2f = c.c2f; a.c3f = c.c3f; a.c4f = c.c4f;
@@ -661,6 +681,8 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     a.Btot = B; a.T = T; a.hop = hop; a.NF = n_frames; a.C = p->C;
     a.NG = (B + SEG - 1) / SEG;
     a.Nall = B;
+    a.xcc_tab = (unsigned *)(ws + l.xcc);
+    hop_magic(hop, &a.hop_magic, &a.hop_shift);
 
     wrnn_run_info info;
     memset(&info, 0, sizeof info);
@@ -696,8 +718,10 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                 // launch of a call that starts at step 0, or any launch when several rounds share the buffer
                 if (!duo) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, XBUF_FLOATS * sizeof(float), stream));
                 else if (s0 == 0 || pl.rounds > 1 || (o->tuning & 4)) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, duo_xbuf_bytes(pl.G), stream));
+                if (duo) HIPCHK(hipMemsetAsync(ws + l.xcc, 0, XCC_WORDS * sizeof(unsigned), stream));      // placement handshake of this launch
                 a.state = (float *)(ws + l.state) + (size_t)r * loop_state_floats(pl.G);
                 a.t0 = s0; a.t1 = s1; a.cI_t0 = s0; a.rb0 = rb0; a.Btot = nr; a.NG = ngr; a.resume = s0 > 0 ? 1 : 0;
+                a.kind_tag = duo ? 2 : 1;
                 if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
                 hipError_t e = duo ? launch_duo(a, pl.ncl, stream) : launch_loop(a, pl.ncl, p->mode, stream);
                 if (e == hipErrorCooperativeLaunchTooLarge && duo && o->algo == WRNN_ALGO_AUTO && info.launches == 0 && pl.t0 == 0) {

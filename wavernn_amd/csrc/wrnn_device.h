@@ -29,7 +29,8 @@ constexpr int LMAXG = 8;      // slots (groups in flight) per cluster the exchan
 constexpr int NXLAYER = 8;      // h1, h2, y1, y2, RAW logits, x1 = xi + h1, x2 = x1 + h2, x_t (16 words: samples drawn by role B)
 constexpr int XRING = 4;
 constexpr size_t XBUF_FLOATS = (size_t)MAXCL * LMAXG * NXLAYER * XRING * SEG * H;
-constexpr int STATUS_WORDS = 16;
+constexpr int STATUS_WORDS = 16;    // 0 abort flag, 1 code, 2 wg, 3 step, 4 detail; 8 = the loop kernel kind a call settled on at step 0 (continuations must match)
+constexpr int XCC_WORDS = MAXCL * 128; // wrnn_duo.hip placement handshake
 constexpr int NPROF = 16;     // phase counters per workgroup (wrnn_pipe.hip PROF builds)
 constexpr int MAXWG = 256;    // workgroups of a persistent launch
 
@@ -77,9 +78,28 @@ struct LoopArgs {
     int t0, t1, cI_t0, noise_t0;        // noise / noise_pre row 0 is step noise_t0, cIf row 0 is step cI_t0
     int tuning;                         // A/B switches of the loop kernel (wrnn_options.tuning)
     int rb0, Nall, G, resume;           // resume != 0: restore the per-group state instead of the zero initial state
-    const float *fc12f;                 // MOL: fc1 / fc2 rows [16 J, 16 J + 16) x the first 512 columns in A-fragment order [layer 2][J 32][wave 4][k-block 8][lane 64][4] (wrnn_duo.hip, DUO_FC_GLB)
     const float *fc3f;                  // MOL: fc3.weight in A-fragment order [tile 2][wave 4][k-block 8][lane 64][4] (wrnn_duo.hip's sampler reads it from L2)
+    // ---- wrnn_duo.hip (round 4)
+    const float *u1;                    // [3H] rnn1.weight_ih . I.weight[:,0]: the x_{t-1} term of rnn1's gi, applied in the gates' pointwise half
+    unsigned hop_magic;                 // p / hop == __umulhi(p, hop_magic) >> hop_shift for 0 <= p < 2^31 (0: divide)
+    int hop_shift;
+    unsigned *xcc_tab;                  // [MAXCL * 128] zeroed before every launch: XCC id + 1 of every workgroup (placement handshake)
+    int kind_tag;                       // 1 wrnn_loop_kernel, 2 wrnn_duo_kernel: recorded in status[8] by the launch that starts a call at step 0,
+                                        // checked by every continuing launch (the two kernels keep different state / ring layouts)
 };
+
+// A call's first launch records which loop kernel runs it; a continuation (resume) that was planned onto the other kernel -- e.g. the
+// `auto` fallback from two workgroups per CU to one struck on one slice only -- fails loudly instead of resuming from foreign state.
+__device__ __forceinline__ void check_kind(const LoopArgs &a)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (!a.resume) a.status[8] = (unsigned)a.kind_tag;
+        else if (a.status[8] != (unsigned)a.kind_tag) {
+            if (atomicCAS(a.status + 1, 0u, 0x7F0u | (unsigned)a.kind_tag) == 0u) { a.status[2] = a.status[8]; a.status[3] = (unsigned)a.t0; a.status[4] = 0u; }
+            __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 
 
 // arguments of the dimension-generic loop kernel (wrnn_generic.hip): any rnn / fc / feat / aux dims, nothing hoisted

@@ -1,148 +1,97 @@
 // wrnn_duo.hip -- the TWO-WORKGROUPS-PER-CU form of the persistent WaveRNN loop kernel (MOL) for MI355X (gfx950 / CDNA4).
 //
-// Same path, same arithmetic and the same tag-free sentinel exchange in MFMA-fragment order as wrnn_loop.hip (reference
-// models/fatchord_version.py:201-241); what changes is WHO holds WHAT, for one reason (profiles/r02r_summary.md): a
-// wrnn_loop_kernel workgroup keeps 224 weight registers per lane, so it is alone on its CU with ONE wave per SIMD, and a
-// single in-order wave cannot overlap its 256 MFMAs per group-step (8.2 k cycles) with the ~14 k cycles of loads, partial
-// sums, pointwise math, publishes and barrier waits around them -- the matrix pipe idles 63 % of the time.  Here every
-// role of wrnn_loop.hip is cut in two along the line between its critical and its off-critical half:
+// Same path and the same tag-free sentinel exchange in MFMA-fragment order as wrnn_loop.hip (reference
+// models/fatchord_version.py:201-241); every role of wrnn_loop.hip is cut in two along the line between its critical and its
+// off-critical half so that a workgroup fits 256 registers per lane and TWO workgroups share a CU (two waves per SIMD: one
+// wave's MFMAs run under the other's VALU / LDS / memory / wait time):
 //
-//     role 0  A-ih : rnn1 W_ih (3 gate tiles) + fc1 (1 tile)   = 128 weight registers   phases P0 (gates -> h1, x1), P2 (fc1 -> y1)
-//     role 1  B-ih : rnn2 W_ih (3 gate tiles) + fc2 (1 tile)   = 128                    phases P0 (gates -> h2, x2), P2 (fc2 -> y2)
-//     role 2  A-hh : rnn1 W_hh (3 gate tiles)                  =  96                    phase  P1 (gh1(t+1) = W_hh1 . h1(t) + b_hh)
-//     role 3  B-hh : rnn2 W_hh (3 gate tiles)                  =  96                    phase  P1 (gh2(t+1)) [+ fc3 and sampling, below]
+//     A-ih : rnn1 W_ih (3 gate tiles) + fc1 (1 tile) = 128 weight registers   stages P0 (gates -> h1, x1 = xi + h1), P2 (fc1 -> y1)
+//     B-ih : rnn2 W_ih (3 gate tiles) + fc2 (1 tile) = 128                    stages P0 (gates -> h2, x2 = x1 + h2), P2 (fc2 -> y2)
+//     A-hh : rnn1 W_hh (3 gate tiles)                =  96                    stage  P1 (gh1(t+1) = W_hh1 . h1(t) + b_hh)
+//     B-hh : rnn2 W_hh (3 gate tiles)                =  96                    stage  P1 (gh2(t+1)); workgroup J < groups in flight also runs
+//                                                                             fc3 + the MoL sampling of slot J (fc3 fragments from L2)
 //
-// so a workgroup fits 256 registers per lane and TWO workgroups share a CU: two waves per SIMD, one running MFMAs while the
-// other issues its VALU / LDS / memory work (MI355X guide: the matrix and vector pipes of a SIMD run concurrently for
-// different waves).  A cluster is 128 workgroups on the same 64 CUs; the issued MFMA count per CU and group-step drops from
-// 1024 to ~900 (fc3 below) and, more to the point, can now overlap everything else.
-//
-// What the cut costs: gh(t+1) = W_hh . h(t) + b_hh now crosses workgroups -- three more exchange layers per GRU
-// ([gate][16 units x 16 segments] = 3 KB per workgroup and group-step, read by ONE workgroup, a full step after it was
-// written: off the critical path).  fc3 + sampling (MOL: 30 x 512, 0.4 % of the FLOPs) used to run redundantly in all 32 workgroups of
-// the sampling role (64 of its 256 MFMAs per group-step); here ONE hh workgroup per slot runs it (slot i: role 2 + (i & 1),
-// unit block J = i >> 1), reading the fc3 fragments from L2, and hands x_t to the 32 A-ih workgroups through the 16-word
-// exchange layer wrnn_loop.hip already uses for role-B-sampled slots.  That is one more hop on a slot's chain (this kernel
-// is for >= 2 groups in flight per cluster, where the busy time of a workgroup bounds a step, not the latency of a
-// slot; wrnn_loop_kernel stays the kernel for one group per cluster).
+// Round 4 -- the LEAN form.  Round 3's phase clocks (profiles/r03ab_*, r03ag_*) showed the ih workgroup's serial instruction stream
+// -- 16.7 k cycles per group-step at depth 4 AND at depth 8, 5.2 k of them MFMA -- bounding the step while the hh workgroup idled
+// half of the time, and the ISA showed why: ~500 non-MFMA instructions and ~40 branches per gate stage (failure-flag plumbing,
+// run-time stage kinds, an integer division for the conditioning frame, 64-bit address arithmetic, the xi operand build, the
+// residual slice through LDS).  This version keeps the exchange protocol and the data layout and removes that work:
+//   * xi is never built.  rnn1's gi = W_ih . (cI + w0 x) + b = W_ih . cI + x (W_ih . w0) + b: the conditioning slab is the MFMA
+//     operand as it comes from memory, and the x_{t-1} term -- one FMA per gate with the pack's pre-multiplied vector
+//     u1 = W_ih1 . I.weight[:,0] -- moves into the gates' pointwise half.  x_{t-1} is therefore needed AFTER the gate tiles, not
+//     before them: the sampling -> rnn1 hop of a slot's chain is shorter by one MFMA block.  (fp32 rounding differs from the
+//     reference's order by ~1e-7 relative: this kernel is MoL only, tolerance 1e-5; the bit-exact RAW mode runs on wrnn_loop_kernel.)
+//   * the residual input of the owned units (xi / x1 for the published sums x1 = xi + h1, x2 = x1 + h2) is one 4-byte load per
+//     thread from the layer the stage consumes anyway, not an LDS slice written by one wave behind eight compares;
+//   * stage kinds are compile-time at every call site (a step is: gates of slot 0 | gates of the others | fc of slot 0 | fc of the
+//     others), per-slot byte offsets are 32-bit buffer offsets, the conditioning frame is a multiply-high with a magic constant,
+//     constants of the pointwise role live in registers;
+//   * a bounded spin that expires reports and lets the wave run on (sticky `dead`: later polls are skipped; every wave keeps
+//     its barrier sequence, the launch ends, wrnn_status() reports) -- no failure flag is checked on the hot path;
+//   * one accumulator chain per gate tile (k ascending, the oracle's order; consecutive MFMAs of a chain are 96 cycles apart).
+// Placement (speed only, verified at run time): with 4 clusters a cluster is two XCDs; all rnn1 workgroups (A-ih, A-hh) of a cluster
+// sit on one XCD and all rnn2 workgroups on the other, the ih and the hh workgroup of the same units on one CU.  Every workgroup
+// records its XCC id; where producer and consumers of a layer are seen to share an XCD (h1, gh1 | h2, gh2, y2) the producer's
+// stores are plain write-back stores that stay in that XCD's L2 (consumers always read with sc1 = L2-served loads): no fabric traffic
+// for those layers.  Everything else is written through (sc1) as before.
 //
 // Ring discipline (conservative form of wrnn_loop.hip's): 8 ring entries per layer; at step t a wave re-arms its own words of
 // entry (t + 4) % 8 -- data of step t - 4, which every consumer left behind long ago -- and drains its stores at step t + 1;
-// the entry is written again at step t + 3 (gh(t+4), published one step early) or t + 4.  Any poll of that entry belongs to a
-// consumer's step >= t + 4, which exists only if every workgroup of the cluster has published something of its step t + 2
-// or later, i.e. has passed the drain of step t + 1: the re-arm is visible before the poll.
+// the entry is written again at step t + 4.  Any poll of that entry belongs to a consumer's step >= t + 4, which exists only if every
+// workgroup of the cluster has published something of its step t + 2 or later, i.e. has passed the drain of step t + 1: the re-arm is
+// visible before the poll.  The gh words {r, z, n, tag = consuming step + 1} and nothing else carry a tag: no re-arm for them.
 #include <type_traits>
 
 #include "wrnn_ring.h"
 
 namespace wrnn {
 
-constexpr int DNX = 16;                      // layers: 0 h1  1 h2  2 y1  3 y2  4 -  5 x1  6 x2  7 x_t  8-11 gh1  12-15 gh2 ([32 unit blocks][256 threads][r, z, n, -]: 4 layers' worth)
+constexpr int DNX = 16;                      // layers: 0 h1  1 h2  2 y1  3 y2  4 -  5 x1  6 x2  7 x_t  8-11 gh1  12-15 gh2 ([32 unit blocks][256 threads][r, z, n, tag])
 constexpr int DRING = 8;
 constexpr int DAHEAD = 4;                    // re-arm distance (steps)
 constexpr int DNWGC = 4 * LNJ;               // workgroups per cluster (128)
 constexpr size_t DXBUF_FLOATS = (size_t)LMAXG * MAXCL * DNX * DRING * XT;      // [slot][cluster][layer][ring][XT]
 constexpr int DLOGS = 36;                    // as LOGS of wrnn_loop.hip
-constexpr int DPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][slot 0..2][16][16]
-// Build-time variants of the ih roles (measured on hardware, profiles/r03e_*: the look-ahead bought nothing -- an ih workgroup waits
-// for data that is not published yet, not for load latency -- and the 32 registers it takes had to come from somewhere):
-//   DUO_IH_XAHEAD 1 = one-stage look-ahead of the ih roles' operand loads (needs DUO_FC_LDS 1 or DUO_FC_GLB 1 to fit 256 registers)
-//   DUO_FC_LDS    1 = the fc1 / fc2 tile in LDS (A-fragment order) instead of 32 registers
-#ifndef DUO_IH_XAHEAD
-#define DUO_IH_XAHEAD 0
-#endif
-#ifndef DUO_FC_LDS
-#define DUO_FC_LDS 0
-#endif
-//   DUO_FC_GLB    1 = the ih roles read their fc1 / fc2 tile from L2 every fc stage (LoopArgs.fc12f, fragment order, 32 KB per workgroup,
-//                 issued before the operand poll) instead of holding it in 32 registers -- which then carry the look-ahead.
-//                 Measured (profiles/r03x_probe_fc_glb_ih_lookahead.json): alone 3 % slower (0 spills); with DUO_IH_XAHEAD the combined
-//                 kernel still spills 46-55 VGPRs and runs 50 % slower.  Off.
-#ifndef DUO_FC_GLB
-#define DUO_FC_GLB 0
-#endif
-//   DUO_FAST_PW   1 = hardware exp / rcp in the GRU pointwise math (gru_update_fast), 0 = the library forms (gru_update, as wrnn_loop.hip)
-//   DUO_PUBLISH_FIRST 1 = a stage starts with the previous stage's back half (barrier, pointwise, PUBLISH) and only then issues its own
-//                 loads: the publication leaves ~1 k cycles earlier per hop, which is what bounds a step when the slots' chains are
-//                 not hidden (<= 4 groups in flight); 0 = loads first, as wrnn_loop.hip (better latency hiding when busy-bound)
-#ifndef DUO_PUBLISH_FIRST
-#define DUO_PUBLISH_FIRST 1
-#endif
-//   DUO_FC_LAG    the fc stage of slot k - lag follows the gate stage of slot k (see duo_ih's main loop)
-#ifndef DUO_FC_LAG
-#define DUO_FC_LAG 8       // (measured, profiles/r03m_probe_lag.json: the plain order wins at depth 4 and 8; lag 1-2 cost 9-17 %)
-#endif
-#ifndef DUO_FAST_PW
-#define DUO_FAST_PW 1
-#endif
-//   DUO_SPLIT_FC  1 = the fc1 / fc2 stages of the odd slots run on the hh workgroups (load balance of the two workgroups of a CU).
-//                 Measured (profiles/r03w_probe_split_fc.json): 9-14 % SLOWER at depth 3-8 -- the hh workgroup then has no registers
-//                 for its one-stage look-ahead (which alone is worth 5-13 %), and its gh stages are less off the chain than the
-//                 phase clocks suggested.  Off.
-#ifndef DUO_SPLIT_FC
-#define DUO_SPLIT_FC 0
-#endif
-//   DUO_HH_XAHEAD 1 = the hh workgroups load the next stage's operand fragments one stage ahead.  With the fc tile next to W_hh (128
-//                 weight registers, DUO_SPLIT_FC) the 32 look-ahead registers spill (71 VGPRs to scratch), as they did in duo_ih: off.
-#ifndef DUO_HH_XAHEAD
-#define DUO_HH_XAHEAD (!DUO_SPLIT_FC)
-#endif
-#ifndef DUO_MFMA3
-#define DUO_MFMA3 mfma3
-#endif
-// per-group LDS state of an ih workgroup (floats): HOWN[256] (h of the owned unit x segment), XS[16] (x_{t-1}; layer 1), SP[32 ints]
-// (segment table), FR[2][16 ints] (conditioning frame of every segment at step t in FR[t & 1]), XO[256] (the owned units' slice of
-// the GRU input, for the residual sum).  The saved state of a slot in global memory is [GH 768 = gh(t1)][these DGRP floats] = LGRP.
-constexpr int DGRP = 256 + 16 + 32 + 32 + 256;
-constexpr int D_HOWN = 0, D_XS = 256, D_SP = 272, D_FR = 304, D_XO = 336;
-static_assert(768 + DGRP == LGRP, "saved state layout");
+constexpr int DPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][tile 0..2][lane][4]
+constexpr int XTB = XT * 4;                  // bytes of one layer entry (32 KB)
+constexpr int DLAYERB = DRING * XTB;         // bytes of one layer's ring
+constexpr int DSLOTB = DNX * DLAYERB;        // bytes of one (slot, cluster)
+static_assert((size_t)LMAXG * MAXCL * DSLOTB < 0x7FFFFFFFull, "32-bit buffer offsets");
+// saved state of an ih workgroup's slot in global memory (the slot layout of wrnn_loop.hip, LGRP floats): [0, 768) gh(t1) of the
+// finished launch, [768, 1024) h, [1024, 1040) x_{t1-1} (A-ih), [1040, 1072) segment table
+static_assert(O_HOWN == 768 && O_XS == 1024 && O_SP == 1040, "saved state layout");
 
 struct DuoLds {
-    int off_part, off_log, off_wi0, off_fc, off_misc, off_prof, total;
+    int off_h, off_seg, off_xs, off_part, off_log, off_misc, off_prof, total;
 };
 __host__ __device__ inline DuoLds duo_lds(int G)
 {
     DuoLds l;
-    int o = G * DGRP;
+    int o = 0;
+    l.off_h = o;    o += G * 256;            // h of the owned (unit, segment), per slot (thread-private words)
+    l.off_seg = o;  o += G * 32;             // ints: [slot][16 positions | 16 limits]
+    l.off_xs = o;   o += G * 16;             // A-ih: x_{t0-1} of a continuing launch, x_{t1-1} at its end
     l.off_part = o; o += DPART;
     l.off_log = o;  o += SEG * DLOGS;
-    l.off_wi0 = o;  o += H;
-    l.off_fc = o;   o += DUO_FC_LDS ? XT : 0;    // ih: the 16 owned rows of fc1 / fc2 in A-fragment order (the 4th weight tile lives in LDS so
-                                             // that the registers it would take hold the one-stage look-ahead of the operand loads)
-    l.off_misc = o; o += 16 + 2 * LMAXG;     // [0] failure flag; [16 + 2 i], [17 + 2 i]: first segment / segment count of slot i
+    l.off_misc = o; o += 2 * LMAXG + 2 * DNWGC;      // [2 i], [2 i + 1]: first segment / count of slot i; then the placement table (ints)
     l.off_prof = o; o += 2 * 16;             // [16] u64 phase clocks (profiling builds)
     l.total = o;
     return l;
 }
 
-// re-arm THIS WAVE's quarter (16 lanes x 16 bytes) of the workgroup's 1 KB block in up to four layers of one ring entry
-__device__ __forceinline__ void duo_rearm(__amdgpu_buffer_rsrc_t rs, int soff_entry0 /* bytes: layer 0 of the (slot, entry) + block + quarter */,
-                                          int lane, int la, int lb, int lc, int ld)
+// three gate tiles, ONE accumulator chain per tile: consecutive MFMAs of a chain are 3 issue slots (96 cycles) apart, more than the
+// 40-cycle dependent latency; per output the k terms are summed in ascending order (the oracle's single chain)
+__device__ __forceinline__ void mfma3s(const float (&a0)[AF], const float (&a1)[AF], const float (&a2)[AF], const float (&b)[32],
+                                       f32x4 &o0, f32x4 &o1, f32x4 &o2)
 {
-    const int which = lane >> 4;
-    const int layer = which == 0 ? la : (which == 1 ? lb : (which == 2 ? lc : ld));
-    if (layer >= 0) {
-        const u32x4 q = {SENT, SENT, SENT, SENT};
-        __builtin_amdgcn_raw_buffer_store_b128(q, rs, layer * (DRING * XT * 4) + (lane & 15) * 16, soff_entry0, 16 /* sc1 */);
-    }
-}
-
-// one tile with the A fragments already loaded (fragment order), B in registers; mfma_tile's order
-__device__ __forceinline__ f32x4 mfma1_frag(const float4 (&av)[8], const float (&b)[32])
-{
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
 #pragma unroll
-    for (int r = 0; r < 8; r += 2) {
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].x, b[4 * r + 0], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].x, b[4 * r + 4], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].y, b[4 * r + 1], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].y, b[4 * r + 5], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].z, b[4 * r + 2], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].z, b[4 * r + 6], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].w, b[4 * r + 3], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].w, b[4 * r + 7], c1, 0, 0, 0);
+    for (int k = 0; k < 32; ++k) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[k], b[k], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[k], b[k], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[k], b[k], c2, 0, 0, 0);
     }
-    return c0 + c1;
+    o0 = c0; o1 = c1; o2 = c2;
 }
 
 // one fc3 tile with the A fragments read from global memory (L2-resident, fragment order), B in registers; mfma_tile's order
@@ -166,78 +115,68 @@ __device__ __forceinline__ f32x4 mfma1_glb(const float *a_lane /* tile + frag_of
     return c0 + c1;
 }
 
-// three gate tiles, ONE accumulator chain per tile: consecutive MFMAs of a chain are 3 issue slots (96 cycles) apart, more than the
-// 40-cycle dependent latency, and 12 accumulator registers instead of mfma3's 24 leave room for the look-ahead operands.  Per
-// output the k terms are summed in ascending order (mfma3 sums even and odd k-blocks separately): closer to the oracle's single chain.
-__device__ __forceinline__ void mfma3s(const float (&a0)[AF], const float (&a1)[AF], const float (&a2)[AF], const float (&b)[32],
-                                       f32x4 &o0, f32x4 &o1, f32x4 &o2)
+// the fragments of a wave as MFMA B operands
+__device__ __forceinline__ void frag_to_b(const u32x4 (&x)[8], float (&b)[32])
 {
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[k], b[k], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[k], b[k], c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[k], b[k], c2, 0, 0, 0);
+    for (int r = 0; r < 8; ++r) {
+        b[4 * r + 0] = __uint_as_float(x[r].x);
+        b[4 * r + 1] = __uint_as_float(x[r].y);
+        b[4 * r + 2] = __uint_as_float(x[r].z);
+        b[4 * r + 3] = __uint_as_float(x[r].w);
     }
-    o0 = c0; o1 = c1; o2 = c2;
+}
+// no word of the live segments' fragments is still the sentinel (wave-uniform; one compare of the running unsigned maximum)
+__device__ __forceinline__ bool frag_there(const u32x4 (&x)[8], bool live)
+{
+    unsigned m = 0u;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) m = max(max(m, max(x[r].x, x[r].y)), max(x[r].z, x[r].w));
+    return __all(m != SENT || !live);
 }
 
-#define DXL(i, layer, ring) ((((((i) * MAXCL + cl) * DNX + (layer)) * DRING) + (ring)) * XT)
+// A bounded wait that does not fail the launch's control flow: `there()` (wave-uniform) is re-evaluated after every `reload()`; when
+// the spin limit expires or another workgroup has raised the abort flag the wave marks itself dead -- it skips every later wait and
+// runs on with whatever the buffers hold (its barrier sequence is unchanged, nothing hangs, wrnn_status() reports the failure).
+template <class There, class Reload>
+__device__ __forceinline__ void wait_for(There there, Reload reload, unsigned *status, bool &dead, unsigned code, int step)
+{
+    unsigned spins = 0;
+    while (!dead && !there()) {
+        if ((++spins & 255u) == 0u) {
+            if (ld_agent32(status) != 0u) { dead = true; break; }
+            if (spins > SPIN_LIMIT) { report_failure(status, code, blockIdx.x, step, threadIdx.x); dead = true; break; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+        reload();
+    }
+}
+
+// the workgroup's 1 KB block of a layer: the four units of a quad gathered with DPP, ONE 16-byte store by the quad's first lane;
+// `local`: producer and consumers share an XCD (seen at run time) -> a plain write-back store that stays in its L2, else write-through
+__device__ __forceinline__ void publish4l(__amdgpu_buffer_rsrc_t rs, int soff, int tid, float v, bool on, bool local)
+{
+    const int iv = __builtin_bit_cast(int, v);
+    const int v0 = __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xF, 0xF, true);
+    const int v1 = __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xF, 0xF, true);
+    const int v2 = __builtin_amdgcn_update_dpp(0, iv, 0xAA, 0xF, 0xF, true);
+    const int v3 = __builtin_amdgcn_update_dpp(0, iv, 0xFF, 0xF, 0xF, true);
+    if (on && (tid & 3) == 0) {
+        const u32x4 q = {(unsigned)v0, (unsigned)v1, (unsigned)v2, (unsigned)v3};
+        if (local) __builtin_amdgcn_raw_buffer_store_b128(q, rs, (tid & ~3) * 4, soff, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(q, rs, (tid & ~3) * 4, soff, 16 /* sc1 */);
+    }
+}
+
+// conditioning frame of position p of a segment whose conditioning ends at lim (Stretch2d: constant over a hop; the fold's zero pad -> NF)
+__device__ __forceinline__ int frame_of(int p, int lim, unsigned magic, int shift, int hop, int NF)
+{
+    const int q = magic ? (int)(__umulhi((unsigned)p, magic) >> shift) : p / hop;
+    return p < lim ? q : NF;
+}
+
 #define DPARTOF(q) (PART + (q) * (NW * 3 * 256))
-
-// (fast_sigmoid / fast_tanh / gru_update_fast: wrnn_ring.h)
-
-// bounded poll of this thread's 16-byte gh word {r, z, n, tag}: ONE 16-byte sc1 store by ONE lane, so the word is its own flag (MI355X
-// guide, hand-off form R2) -- tag = consuming step + 1, no sentinel, hence no re-arm store and no ordering rule for these layers
-// (the sentinel fill 0xFFFFFFFF and the tags of earlier laps never match).  `live` threads only.
-__device__ __forceinline__ bool poll_gh(__amdgpu_buffer_rsrc_t rs, int voff, int soff, bool live, unsigned tag, u32x4 &g, unsigned *status)
-{
-    unsigned spins = 0;
-    while (__any(live && g.w != tag)) {
-        if ((++spins & 255u) == 0u) {
-            if (spins > SPIN_LIMIT || ld_agent32(status) != 0u) return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
-        g = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 16 /* sc1 */);
-    }
-    return true;
-}
-
-// bounded poll of up to three 4-byte words of this thread (sentinel = not written); `live` threads only.  Wave-uniform result.
-__device__ __forceinline__ bool poll3(__amdgpu_buffer_rsrc_t rs, int voff, int s0, int s1, int s2, bool live, unsigned &g0, unsigned &g1,
-                                      unsigned &g2, unsigned *status)
-{
-    unsigned spins = 0;
-    while (__any(live && (g0 == SENT || g1 == SENT || g2 == SENT))) {
-        if ((++spins & 255u) == 0u) {
-            if (spins > SPIN_LIMIT || ld_agent32(status) != 0u) return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
-        g0 = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, s0, 16 /* sc1 */);
-        g1 = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, s1, 16 /* sc1 */);
-        g2 = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, s2, 16 /* sc1 */);
-    }
-    return true;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// ih workgroup: LA = layer 1 (rnn1 W_ih + fc1; needs x_{t-1} for xi) or layer 2 (rnn2 W_ih + fc2).  Owns the GRU state of its 16
-// units (h, the gate pointwise math) and publishes h / the residual sum / relu(fc).
-// PROF (thread 0, shader clocks per segment of a stage, [ph0: 0-7, ph2: 8-15]): 0 front issue, 1 barrier wait, 2 back half, 3 operand
-// wait / poll, 4 hygiene + look-ahead issue + operand build, 5 MFMA tiles + partial writes, 6 stages, 7 stages that had to poll
-// ---------------------------------------------------------------------------------------------------------------------------------
-template <bool LA, bool PROF>
-__device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, int cl, int J, int ncl)
-{
-    const int G = a.G;
-    const DuoLds L = duo_lds(G);
-    float *PART = smem + L.off_part, *WI0 = smem + L.off_wi0, *FC = smem + L.off_fc;
-    int *FAIL = reinterpret_cast<int *>(smem + L.off_misc);
-    int *GEO = FAIL + 16;
-    u64 *PROFL = reinterpret_cast<u64 *>(smem + L.off_prof);
-    u64 plast = 0;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-#define PH(k)                                                                  \
+#define PHX(k)                                                                 \
     do {                                                                       \
         if (PROF && tid == 0) {                                                \
             const u64 now_ = __builtin_amdgcn_s_memtime();                     \
@@ -245,6 +184,32 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, int cl, i
             plast = now_;                                                      \
         }                                                                      \
     } while (0)
+
+// What every role needs of the launch geometry: slot i <-> group cl + ncl * i of the round
+struct DuoGeo {
+    int nact;
+    u64 nbpack;                              // segment count of slot i in byte i
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ih workgroup: LA = rnn1 (W_ih + fc1; its gi has the x_{t-1} term) or rnn2 (W_ih + fc2).  Owns the GRU state of its 16 units (h, the
+// gate pointwise math) and publishes h / the residual sum / relu(fc).
+// PF: a stage starts with the previous stage's back half (its publication leaves earlier: shallow pipelines); else the stage's loads are
+// issued first and fly under that back half (deep pipelines).
+// PROF (thread 0, shader clocks per segment of a stage, [gates: 0-7, fc: 8-15]): 0 front issue, 1 barrier wait, 2 back half, 3 operand
+// wait / poll, 4 ring hygiene, 5 MFMA tiles + partial writes, 6 stages, 7 stages whose operand was not there at the first look
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <bool LA, bool PF, bool PROF>
+__device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int cl, const int J, const int ncl, const bool loc_h, const bool loc_y)
+{
+    const int G = a.G;
+    const DuoLds L = duo_lds(G);
+    float *HS = smem + L.off_h, *XS = smem + L.off_xs, *PART = smem + L.off_part;
+    int *SEGT = reinterpret_cast<int *>(smem + L.off_seg);
+    int *GEO = reinterpret_cast<int *>(smem + L.off_misc);
+    u64 *PROFL = reinterpret_cast<u64 *>(smem + L.off_prof);
+    u64 plast = 0;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, kq = lane >> 4;
     const int kbase_lane = KCH * w + 4 * kq;
     const int pu = 4 * w + (tid & 3), pj = (tid >> 2) & 15;   // pointwise role: (owned unit, segment)
@@ -252,610 +217,534 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, int cl, i
     const int T0 = a.t0, T1 = a.t1;
     const int NR = a.Btot, NGR = a.NG;
     constexpr int L_H = LA ? 0 : 1, L_XR = LA ? 5 : 6, L_Y = LA ? 2 : 3, L_GH = LA ? 8 : 12;       // layers this role publishes / reads gh from
-    constexpr int L_P0 = LA ? -1 : 5, L_P2 = LA ? 6 : 2;                                           // layers its stages poll
+    constexpr int L_P0 = 5, L_P2 = LA ? 6 : 2;                                                     // layers its stages poll (rnn1's gates: the slab)
 
-    float A_ih[3][AF];
+    float A_ih[3][AF], A_fc[AF];
 #pragma unroll
     for (int g = 0; g < 3; ++g) load_afrag(A_ih[g], LA ? a.w_ih1 : a.w_ih2, LA ? H : H + AUX, g * H + LU * J + fi, true, kbase_lane);
-#if !DUO_FC_LDS && !DUO_FC_GLB
-    float A_fc[AF];
     load_afrag(A_fc, LA ? a.fc1_w : a.fc2_w, H + AUX, LU * J + fi, true, kbase_lane);
-#endif
-    const float *bhh = LA ? a.b_hh1 : a.b_hh2;
+    // constants of the pointwise role (rnn1: b_ih1, the x_{t-1} vector u1 = W_ih1 . w0, w0 of the owned unit; rnn2's b_ih2 is inside c2f)
+    float cb_r = 0.f, cb_z = 0.f, cb_n = 0.f, ux_r = 0.f, ux_z = 0.f, ux_n = 0.f, w0o = 0.f;
+    if constexpr (LA) {
+        cb_r = a.b_ih1[prow]; cb_z = a.b_ih1[H + prow]; cb_n = a.b_ih1[2 * H + prow];
+        ux_r = a.u1[prow]; ux_z = a.u1[H + prow]; ux_n = a.u1[2 * H + prow];
+        w0o = a.I_w0[prow];
+    }
 
     for (int q = tid; q < L.total; q += NT) smem[q] = 0.f;
     __syncthreads();
-    if constexpr (LA) {
-        WI0[2 * tid] = a.I_w0[2 * tid];
-        WI0[2 * tid + 1] = a.I_w0[2 * tid + 1];
-    }
-#if DUO_FC_LDS
-    {   // fc1 / fc2 rows [16 J, 16 J + 16) -> LDS in A-fragment order: FC[wave][r][lane (row fi, k-quad kq)][4] = W[16 J + fi][128 wave + 16 r + 4 kq ..]
-        const float *fcw = LA ? a.fc1_w : a.fc2_w;
-        for (int q = tid; q < XT / 4; q += NT) {
-            const int l6 = q & 63, r = (q >> 6) & 7, wv = (q >> 9) & 3;
-            reinterpret_cast<float4 *>(FC)[q] =
-                *reinterpret_cast<const float4 *>(fcw + (size_t)(LU * J + (l6 & 15)) * (H + AUX) + KCH * wv + 16 * r + 4 * (l6 >> 4));
-        }
-    }
-#endif
-    int nact = 0;
-    for (int i = 0; i < G; ++i)
-        if (cl + ncl * i < NGR) nact = i + 1;
-    u64 nbpack = 0;                                     // segment count of slot i in byte i (a scalar register pair: no LDS round trip per stage)
-    // saved state: the slot layout of wrnn_loop.hip ([cluster][2 J + layer][slot][LGRP]): [0, 768) = gh(t1) of the finished launch
-    // (the next launch's first step reads it straight from there), then the DGRP floats of the LDS state
+    DuoGeo geo;
+    geo.nact = 0; geo.nbpack = 0;
+    // saved state: the slot layout of wrnn_loop.hip ([cluster][2 J + layer][slot][LGRP])
     const size_t state_wg = ((size_t)(cl * LNWGC + 2 * J + (LA ? 0 : 1)) * G) * LGRP;
-    for (int i = 0; i < nact; ++i) {
-        float *GP = smem + i * DGRP;
+    for (int i = 0; i < G; ++i) {
         const int g = cl + ncl * i;
+        if (g >= NGR) break;
+        geo.nact = i + 1;
         const int b0 = (int)(((long)g * NR) / NGR), nb = (int)(((long)(g + 1) * NR) / NGR) - b0;
         if (tid == 0) { GEO[2 * i] = a.rb0 + b0; GEO[2 * i + 1] = nb; }
-        nbpack |= (u64)(unsigned)nb << (8 * i);
+        geo.nbpack |= (u64)(unsigned)nb << (8 * i);
         if (a.resume) {
-            const float4 *src = reinterpret_cast<const float4 *>(a.state + state_wg + (size_t)i * LGRP + 768);
-            for (int q = tid; q < DGRP / 4; q += NT) reinterpret_cast<float4 *>(GP)[q] = src[q];
-        } else {
-            GP[D_HOWN + tid] = 0.f;                     // fatchord_version.py:194-196: h1 = h2 = 0, x = 0
-            if (tid < SEG) {
-                GP[D_XS + tid] = 0.f;
-                int *SP = reinterpret_cast<int *>(GP + D_SP);
-                const int sc = a.rb0 + b0 + (tid < nb ? tid : nb - 1);
-                SP[tid] = a.seg_pos[sc];
-                SP[SEG + tid] = a.seg_lim[sc];
-                const int p0 = SP[tid] + T0;
-                reinterpret_cast<int *>(GP + D_FR)[SEG * (T0 & 1) + tid] = (p0 < SP[SEG + tid]) ? (p0 / a.hop) : a.NF;
-            }
+            const float *sg = a.state + state_wg + (size_t)i * LGRP;
+            HS[i * 256 + tid] = sg[O_HOWN + tid];
+            if (tid < SEG) XS[i * 16 + tid] = sg[O_XS + tid];
+            if (tid < 2 * SEG) SEGT[i * 32 + tid] = reinterpret_cast<const int *>(sg + O_SP)[tid];
+        } else if (tid < SEG) {                         // fatchord_version.py:194-196: h1 = h2 = 0, x = 0 (LDS is zero)
+            const int sc = a.rb0 + b0 + (tid < nb ? tid : nb - 1);
+            SEGT[i * 32 + tid] = a.seg_pos[sc];
+            SEGT[i * 32 + SEG + tid] = a.seg_lim[sc];
         }
     }
     __syncthreads();
+    const int nact = geo.nact;
+    const u64 nbpack = geo.nbpack;
 
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.xbuf, (unsigned)(DXBUF_FLOATS * 4));
-    const int ghoff = (256 * (J & 7) + tid) * 16;       // byte offset of this thread's {r, z, n, -} gh word in layer L_GH + (J >> 3): eight unit blocks per layer
+    const __amdgpu_buffer_rsrc_t crs = make_rsrc(LA ? a.cIf : a.c2f, 0x7FFFF000u);                 // rnn1: the conditioning slab; rnn2: its per-frame table
+    const __amdgpu_buffer_rsrc_t frs = make_rsrc(LA ? a.c3f : a.c4f, 0x7FFFF000u);                 // per-frame table of fc1 / fc2
+    const int voff_frag = frag_off(w, 0, lane) * 4;     // this lane's first fragment of a layer (bytes)
+    const int voff_own = (((J * 64) + 16 * w + pj) * 4 + (tid & 3)) * 4;      // the layer word of (owned unit pu, segment pj) = its publish position
+    const int voff_gh = (256 * (J & 7) + tid) * 16;     // this thread's {r, z, n, tag} word in layer L_GH + (J >> 3)
+    const int cbase = cl * DSLOTB;                      // slot i: cbase + i * MAXCL * DSLOTB
+    const unsigned magic = a.hop_magic;
+    const int mshift = a.hop_shift;
 
-    float touch = 0.f;
+    bool dead = false;
     int pp = 0;
-    bool ok = true;
-    unsigned fcode = 0u;
     int t = T0;
+    int cur = 0;
+    unsigned touch = 0u;
 
-    const bool prio_mfma = (a.tuning & 8) != 0;          // A/B: raise the wave's priority around its MFMA tiles
-    if (a.tuning & 16) __builtin_amdgcn_s_setprio(1);    // A/B: static priority for the ih workgroups (the longer instruction stream)
-    const bool lookahead = DUO_IH_XAHEAD && (a.tuning & 1) == 0;          // A/B: bit 0 = no one-stage look-ahead of the operand loads
-    // fc1 / fc2 stages of the ODD slots run on the hh workgroup of the same layer and unit block (which holds the same fc tile): the
-    // ih workgroup's instruction stream is what bounds a busy step (gates + fc = 16 k cycles per group-step against the hh
-    // workgroup's 9 k; profiles/r03g_duo_phase_clocks_depth8.json).  tuning bit 7 = all fc stages here, as before.
-    const bool split_fc = DUO_SPLIT_FC && (a.tuning & 128) == 0 && !DUO_IH_XAHEAD;
-    const int last_fc = split_fc ? ((nact - 1) & ~1) : nact - 1;           // the last fc stage this workgroup runs in a step
-    enum { BK_NONE = 0, BK_GATES, BK_RELU };
-    // x: the operand fragments of the NEXT stage, loaded one stage ahead (before this stage's MFMA tiles): xa = 1 an exchanged layer
-    // (may still hold sentinels: checked at the stage's start), xa = 2 the conditioning slab cI (layer 1's gate stages: plain data)
-    u32x4 x[8];
-    int xa = 0;
-    int bk = BK_NONE, bi = 0, bpp = 0, bt = 0;
-    float bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
-    u32x4 bg = {0u, 0u, 0u, 0u};                        // gh word of the pending GATES half (loaded in its stage's front)
-    unsigned xtw = 0u;
-    int cur = 0;                                        // PROF: 0 gate stage, 8 fc stage
-
-    auto poll_xt = [&](int i, int ring, int nb, unsigned &v) -> bool {
-        unsigned spins = 0;
-        while (__any(fi < nb && v == SENT)) {
-            if ((++spins & 255u) == 0u) {
-                if (spins > SPIN_LIMIT || ld_agent32(a.status) != 0u) return false;
-            }
-            __builtin_amdgcn_s_sleep(1);
-            v = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, DXL(i, 7, ring) * 4, 16 /* sc1 */);
-        }
-        return true;
+    // what a stage's front leaves for its back half, one stage later
+    struct Carry {
+        float c0, c1, c2;                               // rnn2 gates: c2f row (aux columns + b_ih2); fc: c3f / c4f value
+        u32x4 gw;                                       // gh word of the slot (gates)
+        unsigned xo, xt;                                // residual input word; x_{t-1} word (rnn1)
+        int i, pp, t;
     };
+    Carry cy;
+    cy.c0 = cy.c1 = cy.c2 = 0.f; cy.gw = u32x4{0u, 0u, 0u, 0u}; cy.xo = cy.xt = 0u; cy.i = 0; cy.pp = 0; cy.t = T0;
 
-    auto run_back = [&]() -> bool {
-        if (bk == BK_NONE) return true;
-        float *GP = smem + bi * DGRP;
-        const float *PB = DPARTOF(bpp);
-        const int nb = (int)((nbpack >> (8 * bi)) & 255u);
-        const int bring = bt % DRING;
-        if (!ok) FAIL[0] = 1;
+    auto slot_nb = [&](int i) -> int { return (int)((nbpack >> (8 * i)) & 255u); };
+
+    // ---------------- back half of a gate stage: 4-wave partial sum, GRU cell pointwise (ATen gru_cell) -> publish h and the residual sum
+    auto back_gates = [&](const Carry &c) {
+        const int bi = c.i, bt = c.t;
+        const float *PB = DPARTOF(c.pp);
+        const int nb = slot_nb(bi);
+        const int sb = cbase + bi * (MAXCL * DSLOTB) + (bt & (DRING - 1)) * XTB;
+        const bool live = pj < nb;
         lds_barrier();
-        if (FAIL[0] != 0) return false;
-        PH(cur + 1);
-        if (bk == BK_GATES) {                           // GRU cell pointwise (ATen gru_cell) -> publish h and the residual sum
-            const float gir = get_partial<3>(PB, 0, pu, pj) + bc0;
-            const float giz = get_partial<3>(PB, 1, pu, pj) + bc1;
-            const float gin = get_partial<3>(PB, 2, pu, pj) + bc2;
-            float ghr, ghz, ghn;
-            if (bt > T0) {                              // gh(t) from the hh workgroup of the same unit block (published during step t - 1)
-                const bool got = poll_gh(xrs, ghoff, DXL(bi, L_GH + (J >> 3), bring) * 4, pj < nb, (unsigned)bt + 1u, bg, a.status);
-                if (!got) { ok = false; if (fcode == 0u) fcode = 0x500u | (LA ? 0u : 8u) | 6u; }
-                ghr = __uint_as_float(bg.x); ghz = __uint_as_float(bg.y); ghn = __uint_as_float(bg.z);
-            } else if (a.resume) {                      // first step of a continuing launch: gh(t0), saved by the launch that ended there
-                const float *sg = a.state + state_wg + (size_t)bi * LGRP;
-                ghr = sg[tid]; ghz = sg[256 + tid]; ghn = sg[512 + tid];
-            } else {                                    // t = 0: gh = W_hh . 0 + b_hh = b_hh
-                ghr = bhh[prow]; ghz = bhh[H + prow]; ghn = bhh[2 * H + prow];
-            }
-            const float hprev = GP[D_HOWN + tid];
-            const float hn = DUO_FAST_PW ? gru_update_fast(gir, giz, gin, ghr, ghz, ghn, hprev) : gru_update(gir, giz, gin, ghr, ghz, ghn, hprev);
-            GP[D_HOWN + tid] = hn;
-            publish4(xrs, (DXL(bi, L_H, bring) + 256 * J) * 4, tid, hn, pj < nb);
-            publish4(xrs, (DXL(bi, L_XR, bring) + 256 * J) * 4, tid, GP[D_XO + tid] + hn, pj < nb);      // x1 = xi + h1 (:212) / x2 = x1 + h2 (:216)
-            if (tid < SEG) {   // conditioning frame of every segment at the NEXT step, into the other half of FR (first read a step from here)
-                const int *SP = reinterpret_cast<const int *>(GP + D_SP);
-                const int p1 = SP[tid] + bt + 1;
-                reinterpret_cast<int *>(GP + D_FR)[SEG * ((bt + 1) & 1) + tid] = (p1 < SP[SEG + tid]) ? (p1 / a.hop) : a.NF;
-            }
-        } else {                                        // fc1 / fc2 + relu -> publish y1 / y2
-            publish4(xrs, (DXL(bi, L_Y, bring) + 256 * J) * 4, tid, fmaxf(get_partial<3>(PB, 0, pu, pj) + bc0, 0.f), pj < nb);
+        PHX(cur + 1);
+        const float pr = get_partial<3>(PB, 0, pu, pj), pz = get_partial<3>(PB, 1, pu, pj), pn = get_partial<3>(PB, 2, pu, pj);
+        const float hprev = HS[bi * 256 + tid];
+        float ghr, ghz, ghn;
+        u32x4 g = c.gw;
+        if (bt > T0) {                                  // gh(t) from the hh workgroup of the same unit block (published during step t - 1)
+            const unsigned tag = (unsigned)bt + 1u;
+            if (__builtin_expect(__any(live && g.w != tag), 0))
+                wait_for([&] { return !__any(live && g.w != tag); },
+                         [&] { g = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, sb + (L_GH + (J >> 3)) * DLAYERB, 16 /* sc1 */); },
+                         a.status, dead, 0x500u | (LA ? 0u : 8u) | 6u, bt);
+            ghr = __uint_as_float(g.x); ghz = __uint_as_float(g.y); ghn = __uint_as_float(g.z);
+        } else if (a.resume) {                          // first step of a continuing launch: gh(t0), saved by the launch that ended there
+            const float *sg = a.state + state_wg + (size_t)bi * LGRP;
+            ghr = sg[tid]; ghz = sg[256 + tid]; ghn = sg[512 + tid];
+        } else {                                        // t = 0: gh = W_hh . 0 + b_hh = b_hh
+            const float *bhh = LA ? a.b_hh1 : a.b_hh2;
+            ghr = bhh[prow]; ghz = bhh[H + prow]; ghn = bhh[2 * H + prow];
         }
-        bk = BK_NONE;
-        PH(cur + 2);
-        return true;
+        float gir, giz, gin, xin;
+        if constexpr (LA) {
+            float xv;
+            if (bt > T0) {                              // x_{t-1}, sampled by a B-hh workgroup
+                unsigned xw = c.xt;
+                if (__builtin_expect(__any(live && xw == SENT), 0))
+                    wait_for([&] { return !__any(live && xw == SENT); },
+                             [&] { xw = __builtin_amdgcn_raw_buffer_load_b32(xrs, pj * 4, cbase + bi * (MAXCL * DSLOTB) + 7 * DLAYERB + ((bt - 1) & (DRING - 1)) * XTB, 16 /* sc1 */); },
+                             a.status, dead, 0x520u, bt);
+                xv = __uint_as_float(xw);
+            } else xv = XS[bi * 16 + pj];
+            gir = pr + fmaf(xv, ux_r, cb_r); giz = pz + fmaf(xv, ux_z, cb_z); gin = pn + fmaf(xv, ux_n, cb_n);
+            xin = fmaf(w0o, xv, __uint_as_float(c.xo));             // xi of the owned unit (:208-209)
+        } else {
+            unsigned xw = c.xo;                         // x1 of the owned unit: another wave's quarter of the layer, normally validated long ago
+            if (__builtin_expect(__any(live && xw == SENT), 0))
+                wait_for([&] { return !__any(live && xw == SENT); },
+                         [&] { xw = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, sb + L_P0 * DLAYERB, 16 /* sc1 */); },
+                         a.status, dead, 0x528u, bt);
+            gir = pr + c.c0; giz = pz + c.c1; gin = pn + c.c2;
+            xin = __uint_as_float(xw);
+        }
+        const float hn = gru_update_fast(gir, giz, gin, ghr, ghz, ghn, hprev);
+        HS[bi * 256 + tid] = hn;
+        publish4l(xrs, sb + L_H * DLAYERB + J * 1024, tid, hn, live, loc_h);
+        publish4l(xrs, sb + L_XR * DLAYERB + J * 1024, tid, xin + hn, live, false);        // x1 = xi + h1 (:212) / x2 = x1 + h2 (:216)
+        PHX(cur + 2);
+    };
+    // ---------------- back half of an fc stage: fc1 / fc2 + relu -> publish y1 / y2
+    auto back_relu = [&](const Carry &c) {
+        const float *PB = DPARTOF(c.pp);
+        const int sb = cbase + c.i * (MAXCL * DSLOTB) + (c.t & (DRING - 1)) * XTB;
+        lds_barrier();
+        PHX(cur + 1);
+        publish4l(xrs, sb + L_Y * DLAYERB + J * 1024, tid, fmaxf(get_partial<3>(PB, 0, pu, pj) + c.c0, 0.f), pj < slot_nb(c.i), LA ? false : loc_y);
+        PHX(cur + 2);
     };
 
-    int ring = 0, tc = 0;
-    // A STAGE (phase ph = 0 gates / 2 fc, slot i), one-stage software pipeline as in wrnn_loop.hip: consume the loads issued a
-    // stage ago, run the previous stage's back half, issue the next stage's loads, build the operands, run the MFMA tiles.
-    auto stage = [&](auto PHC, int i) -> bool {
+    // A STAGE (phase ph = 0 gates / 2 fc, slot i), BK = the kind of the pending back half (0 none / 1 gates / 2 relu; compile-time)
+    auto stage = [&](auto PHC, auto BKC, int i) {
         constexpr int ph = decltype(PHC)::value;
-        float *GP = smem + i * DGRP;
+        constexpr int BK = decltype(BKC)::value;
         const int g = cl + ncl * i;
-        const int nb = (int)((nbpack >> (8 * i)) & 255u);
-        float4 c[8];
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-        u32x4 gw = {0u, 0u, 0u, 0u};
+        const int nb = slot_nb(i);
+        const int ring = t & (DRING - 1);
+        const int sbase = cbase + i * (MAXCL * DSLOTB);
+        const int sb = sbase + ring * XTB;
         constexpr bool polled = !(LA && ph == 0);
-        constexpr int xl = ph == 0 ? L_P0 : L_P2;
-        float b[32];
-        bool ready = false;
-        cur = ph == 0 ? 0 : 8;
+        u32x4 x[8];
+        Carry nc;
+        nc.c0 = nc.c1 = nc.c2 = 0.f; nc.gw = u32x4{0u, 0u, 0u, 0u}; nc.xo = nc.xt = 0u;
+        nc.i = i; nc.pp = pp; nc.t = t;
         if (PROF && tid == 0 && plast == 0) plast = __builtin_amdgcn_s_memtime();
-#if DUO_PUBLISH_FIRST
-        // ---------------- the previous stage's back half FIRST: its publication is what the next hop of its slot's chain waits for ----------------
-        if (!run_back()) return false;
-#endif
-        if (polled) {
-            if (DUO_IH_XAHEAD && xa == 1) ready = try_finish(lane, nb, x, b);
-            else issue(xrs, DXL(i, xl, ring) * 4, w, lane, x);
-        } else {
-            if (DUO_IH_XAHEAD && xa == 2) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) c[r] = make_float4(__uint_as_float(x[r].x), __uint_as_float(x[r].y), __uint_as_float(x[r].z), __uint_as_float(x[r].w));
-            } else load_cI(a.cIf + ((size_t)tc * NGR + g) * XT, w, lane, c);
+        if constexpr (PF) {
+            if constexpr (BK == 1) back_gates(cy);
+            if constexpr (BK == 2) back_relu(cy);
         }
-#if DUO_FC_GLB
-        float4 av[8];                                   // the fc tile's A fragments of this wave, in flight under the operand wait
-        if (ph == 2) {
-            const float4 *fp = reinterpret_cast<const float4 *>(a.fc12f + (size_t)((LA ? 0 : LNJ) + J) * XT + frag_off(w, 0, lane));
-#pragma unroll
-            for (int r = 0; r < 8; ++r) av[r] = fp[r * 64];
-        }
-#endif
-        if (ph == 0) {
+        cur = ph == 0 ? 0 : 8;
+        // ---------------- front: this stage's loads ----------------
+        int soff_x;                                     // where the operand fragments come from (for the re-load of a poll)
+        if constexpr (ph == 0) {
             if constexpr (LA) {
-                v0 = a.b_ih1[prow]; v1 = a.b_ih1[H + prow]; v2 = a.b_ih1[2 * H + prow];      // layer 1: b_ih1 (layer 2's b_ih2 is inside c2f)
-                if (t > T0)                             // x_{t-1}, sampled by an hh workgroup (first step of a launch: from the state)
-                    xtw = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, DXL(i, 7, (t + DRING - 1) % DRING) * 4, 16 /* sc1 */);
+                soff_x = ((t - a.cI_t0) * NGR + g) * XTB;                       // conditioning slab cI(t) of the group: plain data
+#pragma unroll
+                for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(crs, voff_frag + r * 1024, soff_x, 0);
+                nc.xo = __builtin_amdgcn_raw_buffer_load_b32(crs, voff_own, soff_x, 0);
+                if (t > T0) nc.xt = __builtin_amdgcn_raw_buffer_load_b32(xrs, pj * 4, sbase + 7 * DLAYERB + ((t - 1) & (DRING - 1)) * XTB, 16 /* sc1 */);
             } else {
-                const int fr = reinterpret_cast<const int *>(GP + D_FR)[SEG * (t & 1) + pj];
-                v0 = a.c2f[(size_t)fr * 3 * H + prow];
-                v1 = a.c2f[(size_t)fr * 3 * H + H + prow];
-                v2 = a.c2f[(size_t)fr * 3 * H + 2 * H + prow];
+                soff_x = sb + L_P0 * DLAYERB;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
+                nc.xo = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, soff_x, 16 /* sc1 */);
+                const int fr = frame_of(SEGT[i * 32 + pj] + t, SEGT[i * 32 + SEG + pj], magic, mshift, a.hop, a.NF);
+                const int vo = (fr * 3 * H + prow) * 4;
+                nc.c0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, 0, 0));
+                nc.c1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, H * 4, 0));
+                nc.c2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, 2 * H * 4, 0));
             }
-            if (t > T0)                                 // gh(t) of this slot: consumed by this stage's back half, one stage from now
-                gw = __builtin_amdgcn_raw_buffer_load_b128(xrs, ghoff, DXL(i, L_GH + (J >> 3), ring) * 4, 16 /* sc1 */);
+            if (t > T0) nc.gw = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, sb + (L_GH + (J >> 3)) * DLAYERB, 16 /* sc1 */);
         } else {
-            const int fr = reinterpret_cast<const int *>(GP + D_FR)[SEG * (t & 1) + pj];
-            v0 = (LA ? a.c3f : a.c4f)[(size_t)fr * H + prow];
+            soff_x = sb + L_P2 * DLAYERB;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
+            const int fr = frame_of(SEGT[i * 32 + pj] + t, SEGT[i * 32 + SEG + pj], magic, mshift, a.hop, a.NF);
+            nc.c0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(frs, (fr * H + prow) * 4, 0, 0));
         }
-        PH(cur + 0);
-#if !DUO_PUBLISH_FIRST
-        // ---------------- the previous stage's back half ----------------
-        if (!run_back()) return false;
-#endif
-        // ---------------- operands -> MFMA tiles -> this wave's partial tiles ----------------
-        if (polled) {
-            unsigned spins = 0;
-            if (!ready) {
-                ok = ok && finish(xrs, DXL(i, xl, ring) * 4, w, lane, nb, x, b, a.status, spins);
-                if (!ok && fcode == 0u) fcode = 0x500u | (LA ? 0u : 8u) | (unsigned)ph;
-            }
-            if (PROF && tid == 0) { PROFL[cur + 6] += 1; PROFL[cur + 7] += !ready; }
+        PHX(cur + 0);
+        if constexpr (!PF) {
+            if constexpr (BK == 1) back_gates(cy);
+            if constexpr (BK == 2) back_relu(cy);
         }
-        PH(cur + 3);
-        if (ph == 2 && i == last_fc) {
-            // ring hygiene, once per step, after the last layer this workgroup polls in the step has arrived (see the header)
+        // ---------------- operands ----------------
+        if constexpr (polled) {
+            const bool live = fi < nb;
+            const bool there = frag_there(x, live);
+            if (PROF && tid == 0) { PROFL[cur + 6] += 1; PROFL[cur + 7] += !there; }
+            if (__builtin_expect(!there, 0))
+                wait_for([&] { return frag_there(x, live); },
+                         [&] {
+#pragma unroll
+                             for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
+                         },
+                         a.status, dead, 0x500u | (LA ? 0u : 8u) | (unsigned)ph, t);
+        }
+        PHX(cur + 3);
+        if (ph == 2 && i == nact - 1) {
+            // ring hygiene, once per step, after the last layer this workgroup polls in the step has arrived (see the header): drain, then
+            // re-arm this wave's own words of entry (t + 4) % 8 in the three layers it publishes, for every slot
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int ringn = (t + DAHEAD) % DRING;
+            const int which = lane >> 4;
+            const int layer = which == 0 ? L_H : (which == 1 ? L_Y : L_XR);
+            const bool lloc = which == 0 ? loc_h : (which == 1 ? (LA ? false : loc_y) : false);
+            const int vo = layer * DLAYERB + J * 1024 + w * 256 + (lane & 15) * 16;
+            const int so = cbase + ((t + DAHEAD) & (DRING - 1)) * XTB;
+            const u32x4 q = {SENT, SENT, SENT, SENT};
+            if (which < 3) {
 #pragma unroll 1
-            for (int i2 = 0; i2 < nact; ++i2) duo_rearm(xrs, (DXL(i2, 0, ringn) + 256 * J + 64 * w) * 4, lane, L_H, L_Y, L_XR, -1);
-        }
-        if (LA && ph == 0) {
-            float xs = GP[D_XS + fi];
-            if (t > T0) {
-                ok = ok && poll_xt(i, (t + DRING - 1) % DRING, nb, xtw);
-                if (!ok && fcode == 0u) fcode = 0x500u | 0x20u;
-                xs = (fi < nb) ? __uint_as_float(xtw) : 0.f;
-            }
-            make_xi(c, WI0, xs, w, lane, b);            // xi(t) (:208-209)
-        }
-        if (ph == 0 && w == (J >> 3)) {
-            // the owned units' slice of this GRU's input (layer 1: xi, layer 2: x1) -> LDS in publish order, for the residual sum
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if (r == (J & 7)) *reinterpret_cast<float4 *>(GP + D_XO + 4 * lane) = make_float4(b[4 * r], b[4 * r + 1], b[4 * r + 2], b[4 * r + 3]);
-        }
-        {   // the next stage's operand fragments, one stage ahead: an exchanged layer (not across a step boundary: nothing of the
-            // next step is published yet) or, for layer 1's gate stages, the conditioning slab (plain data: also across the boundary)
-            int nph = ph, ni = i + 1;
-            if (ni >= nact) { nph = ph + 2; ni = 0; }
-            xa = 0;
-            if (lookahead) {
-                if (nph <= 2) {
-                    if (LA && nph == 0) {
-                        const u32x4 *cp = reinterpret_cast<const u32x4 *>(a.cIf + ((size_t)tc * NGR + cl + ncl * ni) * XT + frag_off(w, 0, lane));
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) x[r] = cp[r * 64];
-                        xa = 2;
-                    } else {
-                        issue(xrs, DXL(ni, nph == 0 ? L_P0 : L_P2, ring) * 4, w, lane, x);
-                        xa = 1;
-                    }
-                } else if (LA && t + 1 < T1) {
-                    const u32x4 *cp = reinterpret_cast<const u32x4 *>(a.cIf + ((size_t)(tc + 1) * NGR + cl) * XT + frag_off(w, 0, lane));
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) x[r] = cp[r * 64];
-                    xa = 2;
+                for (int i2 = 0; i2 < nact; ++i2) {
+                    if (lloc) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, vo, so + i2 * (MAXCL * DSLOTB), 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, vo, so + i2 * (MAXCL * DSLOTB), 16 /* sc1 */);
                 }
             }
         }
-        PH(cur + 4);
+        PHX(cur + 4);
+        float b[32];
+        frag_to_b(x, b);
         float *PW = DPARTOF(pp);
-        if (prio_mfma) __builtin_amdgcn_s_setprio(1);
-        if (ph == 0) {
+        if constexpr (ph == 0) {
             f32x4 o0, o1, o2;
-            DUO_MFMA3(A_ih[0], A_ih[1], A_ih[2], b, o0, o1, o2);
+            mfma3s(A_ih[0], A_ih[1], A_ih[2], b, o0, o1, o2);
             put_partial<3>(PW, w, 0, lane, o0);
             put_partial<3>(PW, w, 1, lane, o1);
             put_partial<3>(PW, w, 2, lane, o2);
-            bk = BK_GATES;
+            if constexpr (LA) {
+                if (t + 1 < T1) {                       // pull the next step's conditioning block of this group (32 KB) into this XCD's L2
+                    asm volatile("" ::"v"(touch));      // (the PREVIOUS touch: never waits for the load it is about to issue)
+                    touch = __builtin_amdgcn_raw_buffer_load_b32(crs, tid * 128, soff_x + NGR * XTB, 0);
+                }
+            }
         } else {
-#if DUO_FC_LDS
-            put_partial<3>(PW, w, 0, lane, mfma1_lds(FC + frag_off(w, 0, lane), b));
-#elif DUO_FC_GLB
-            put_partial<3>(PW, w, 0, lane, mfma1_frag(av, b));
-#else
             put_partial<3>(PW, w, 0, lane, mfma1(A_fc, b));
-#endif
-            bk = BK_RELU;
         }
-        if (prio_mfma) __builtin_amdgcn_s_setprio(0);
-        if (LA && ph == 0 && t + 1 < T1) {     // pull the next step's conditioning block of this group (32 KB) into this XCD's L2
-            asm volatile("" ::"v"(touch));
-            touch = a.cIf[((size_t)(tc + 1) * NGR + g) * XT + 32 * tid];
-        }
-        PH(cur + 5);
-        bi = i; bpp = pp; bt = t; bc0 = v0; bc1 = v1; bc2 = v2; bg = gw;
+        PHX(cur + 5);
+        cy = nc;
         pp ^= 1;
-        return true;
     };
 
-    // Order of a step's stages: the gate stage of slot k, then the fc stage of slot k - lag.  lag = nact is wrnn_loop.hip's order (all
-    // gate stages, then all fc stages); a small lag lets a slot's fc stage run as soon as its operand (two hops behind the slot's
-    // gate stage) can be there instead of behind the gate stages of every other slot -- the slots' chains, which bound a step
-    // with <= 4 groups in flight, get shorter.  wrnn_options.tuning bits 9-11: lag (0 = the default)
-    int lag = (a.tuning >> 9) & 7;
-    if (lag == 0) lag = DUO_FC_LAG;
-    if (lag > nact || DUO_IH_XAHEAD) lag = nact;        // (the ih look-ahead variant assumes the plain order)
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
     for (; t < T1; ++t) {
-        ring = t % DRING;
-        tc = t - a.cI_t0;
+        if (t == T0) stage(I0{}, I0{}, 0);
+        else stage(I0{}, I2{}, 0);
 #pragma unroll 1
-        for (int k = 0; k < nact + lag; ++k) {
-            if (k < nact) {
-                if (!stage(std::integral_constant<int, 0>{}, k)) goto bail;
-            }
-            if (k >= lag && !(split_fc && ((k - lag) & 1))) {
-                if (!stage(std::integral_constant<int, 2>{}, k - lag)) goto bail;
-            }
-        }
+        for (int i = 1; i < nact; ++i) stage(I0{}, I1{}, i);
+        stage(I2{}, I1{}, 0);
+#pragma unroll 1
+        for (int i = 1; i < nact; ++i) stage(I2{}, I2{}, i);
     }
-    if (!run_back()) goto bail;
+    cur = 8;
+    back_relu(cy);
+    asm volatile("" ::"v"(touch));
     // ---- what the next launch of this round needs from the ring: gh(T1) of every slot (published during step T1 - 1) -> the saved
-    //      state in global memory, and, for layer 1, x_{T1-1} -> XS
+    //      state in global memory, and, for rnn1, x_{T1-1}
 #pragma unroll 1
     for (int i = 0; i < nact; ++i) {
-        float *GP = smem + i * DGRP;
-        const int nb = (int)((nbpack >> (8 * i)) & 255u);
-        const int r1 = T1 % DRING;
-        u32x4 gq = __builtin_amdgcn_raw_buffer_load_b128(xrs, ghoff, DXL(i, L_GH + (J >> 3), r1) * 4, 16 /* sc1 */);
-        ok = ok && poll_gh(xrs, ghoff, DXL(i, L_GH + (J >> 3), r1) * 4, pj < nb, (unsigned)T1 + 1u, gq, a.status);
+        const int nb = slot_nb(i);
+        const bool live = pj < nb;
+        const int sbase = cbase + i * (MAXCL * DSLOTB);
+        const int so = sbase + (L_GH + (J >> 3)) * DLAYERB + (T1 & (DRING - 1)) * XTB;
+        u32x4 gq = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, so, 16 /* sc1 */);
+        const unsigned tag = (unsigned)T1 + 1u;
+        wait_for([&] { return !__any(live && gq.w != tag); },
+                 [&] { gq = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, so, 16 /* sc1 */); }, a.status, dead, 0x521u, T1);
         float *sg = a.state + state_wg + (size_t)i * LGRP;
         sg[tid] = __uint_as_float(gq.x); sg[256 + tid] = __uint_as_float(gq.y); sg[512 + tid] = __uint_as_float(gq.z);
+        sg[O_HOWN + tid] = HS[i * 256 + tid];
+        if (tid < 2 * SEG) reinterpret_cast<int *>(sg + O_SP)[tid] = SEGT[i * 32 + tid];
         if constexpr (LA) {
-            unsigned v = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, DXL(i, 7, (T1 + DRING - 1) % DRING) * 4, 16 /* sc1 */);
-            ok = ok && poll_xt(i, (T1 + DRING - 1) % DRING, nb, v);
-            GP[D_XS + fi] = (fi < nb) ? __uint_as_float(v) : 0.f;
+            const int sx = sbase + 7 * DLAYERB + ((T1 - 1) & (DRING - 1)) * XTB;
+            unsigned v = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, sx, 16 /* sc1 */);
+            wait_for([&] { return !__any(fi < nb && v == SENT); },
+                     [&] { v = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, sx, 16 /* sc1 */); }, a.status, dead, 0x522u, T1);
+            if (tid < SEG) sg[O_XS + tid] = (tid < nb) ? __uint_as_float(v) : 0.f;
         }
-    }
-    if (!ok) { if (fcode == 0u) fcode = 0x500u | 0x21u; FAIL[0] = 1; }
-    __syncthreads();
-    if (FAIL[0] != 0) goto bail;
-    asm volatile("" ::"v"(touch));
-    for (int i = 0; i < nact; ++i) {
-        const float4 *GP = reinterpret_cast<const float4 *>(smem + i * DGRP);
-        float4 *dst = reinterpret_cast<float4 *>(a.state + state_wg + (size_t)i * LGRP + 768);
-        for (int q = tid; q < DGRP / 4; q += NT) dst[q] = GP[q];
     }
     if (PROF && tid == 0 && a.prof) {
         for (int k = 0; k < 16; ++k) a.prof[(size_t)(blockIdx.x & 255) * 32 + k] += PROFL[k];
     }
-    return;
-bail:
-    if (fcode != 0u) report_failure(a.status, fcode, blockIdx.x, t, tid);
-#undef PH
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// hh workgroup: gh(t+1) = W_hh . h(t) + b_hh of its 16 units for every slot (off the critical path), and -- for at most one slot --
-// fc3 + mixture-of-logistics sampling (utils/distribution.py:87-123).  Keeps no state between launches.
-// ---------------------------------------------------------------------------------------------------------------------------------
+// hh workgroup: gh(t+1) = W_hh . h(t) + b_hh of its 16 units for every slot (off the critical path), and -- rnn2's workgroup J, for
+// slot J -- fc3 + mixture-of-logistics sampling (utils/distribution.py:87-123).  Keeps no state between launches.
 // PROF: as duo_ih, [gh stages: 0-7, the sampling stage: 8-15]
-template <bool LA, bool PROF>
-__device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, int cl, int J, int ncl)
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <bool LA, bool PF, bool PROF>
+__device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int cl, const int J, const int ncl, const bool loc_h)
 {
     const int G = a.G;
     const DuoLds L = duo_lds(G);
     float *PART = smem + L.off_part, *LOG = smem + L.off_log;
-    int *FAIL = reinterpret_cast<int *>(smem + L.off_misc);
-    int *GEO = FAIL + 16;
+    int *GEO = reinterpret_cast<int *>(smem + L.off_misc);
     u64 *PROFL = reinterpret_cast<u64 *>(smem + L.off_prof);
     u64 plast = 0;
     int cur = 0;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-#define PH(k)                                                                  \
-    do {                                                                       \
-        if (PROF && tid == 0) {                                                \
-            const u64 now_ = __builtin_amdgcn_s_memtime();                     \
-            PROFL[k] += now_ - plast;                                          \
-            plast = now_;                                                      \
-        }                                                                      \
-    } while (0)
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, kq = lane >> 4;
     const int kbase_lane = KCH * w + 4 * kq;
     const int pu = 4 * w + (tid & 3), pj = (tid >> 2) & 15;
     const int prow = LU * J + pu;
     const int T0 = a.t0, T1 = a.t1, C = a.C;
     const int NR = a.Btot, Nall = a.Nall, NGR = a.NG;
-    constexpr int L_H = LA ? 0 : 1, L_GH = LA ? 8 : 12, L_Y = LA ? 2 : 3, L_P2 = LA ? 6 : 2;
+    constexpr int L_H = LA ? 0 : 1, L_GH = LA ? 8 : 12;
 
     float A_hh[3][AF];
 #pragma unroll
     for (int g = 0; g < 3; ++g) load_afrag(A_hh[g], LA ? a.w_hh1 : a.w_hh2, H, g * H + LU * J + fi, true, kbase_lane);
-#if DUO_SPLIT_FC
-    float A_fc[AF];                                      // fc1 / fc2 rows of the unit block: the fc stages of the odd slots (see duo_ih)
-    load_afrag(A_fc, LA ? a.fc1_w : a.fc2_w, H + AUX, LU * J + fi, true, kbase_lane);
-#endif
     const float *bhh = LA ? a.b_hh1 : a.b_hh2;
     const float bh_r = bhh[prow], bh_z = bhh[H + prow], bh_n = bhh[2 * H + prow];
-    const float b3a = a.fc3_b[pu];                                              // logit rows pu and 16 + pu
-    const float b3b = (16 + pu < 30) ? a.fc3_b[16 + pu] : 0.f;
+    float b3a = 0.f, b3b = 0.f;                         // logit rows pu and 16 + pu
+    if constexpr (!LA) {
+        b3a = a.fc3_b[pu];
+        b3b = (16 + pu < 30) ? a.fc3_b[16 + pu] : 0.f;
+    }
 
     for (int q = tid; q < L.total; q += NT) smem[q] = 0.f;
     __syncthreads();
     int nact = 0;
-    for (int i = 0; i < G; ++i)
-        if (cl + ncl * i < NGR) nact = i + 1;
-    u64 nbpack = 0;                                     // segment count of slot i in byte i
-    for (int i = 0; i < nact; ++i) {
+    u64 nbpack = 0;
+    for (int i = 0; i < G; ++i) {
         const int g = cl + ncl * i;
+        if (g >= NGR) break;
+        nact = i + 1;
         const int b0 = (int)(((long)g * NR) / NGR), nb = (int)(((long)(g + 1) * NR) / NGR) - b0;
         if (tid == 0) { GEO[2 * i] = a.rb0 + b0; GEO[2 * i + 1] = nb; }
         nbpack |= (u64)(unsigned)nb << (8 * i);
-        if (tid < SEG) {                                // segment table of the slot (the conditioning frame of its fc stages)
-            int *SP = reinterpret_cast<int *>(smem + i * DGRP + D_SP);
-            const int sc = a.rb0 + b0 + (tid < nb ? tid : nb - 1);
-            SP[tid] = a.seg_pos[sc];
-            SP[SEG + tid] = a.seg_lim[sc];
-        }
     }
     __syncthreads();
-    const bool split_fc = DUO_SPLIT_FC && (a.tuning & 128) == 0 && !DUO_IH_XAHEAD;
-    // the slot this workgroup samples: slot s <-> hh role (s & 1 ? layer 2 : layer 1), unit block s >> 1
-    const int my_slot = (J < LMAXG / 2) ? 2 * J + (LA ? 0 : 1) : -1;
-    const bool sampler = my_slot >= 0 && my_slot < nact;
+    // rnn2's hh workgroup J samples slot J (y2 comes from rnn2's ih workgroups: the same XCD under the placement above)
+    const bool sampler = !LA && J < nact;
+    const int my_slot = J;
 
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.xbuf, (unsigned)(DXBUF_FLOATS * 4));
+    const int voff_frag = frag_off(w, 0, lane) * 4;
+    const int voff_gh = (256 * (J & 7) + tid) * 16;
+    const int cbase = cl * DSLOTB;
+    auto slot_nb = [&](int i) -> int { return (int)((nbpack >> (8 * i)) & 255u); };
+
+    bool dead = false;
     int pp = 0;
-    bool ok = true;
-    unsigned fcode = 0u;
     int t = T0;
-    const bool prio_mfma = (a.tuning & 8) != 0;
-    if (a.tuning & 32) __builtin_amdgcn_s_setprio(1);    // A/B: static priority for the hh workgroups
-    enum { BK_NONE = 0, BK_GH, BK_SAMPLE, BK_RELU };
     u32x4 x[8];
     bool xahead = false;
-    int bk = BK_NONE, bi = 0, bpp = 0, bt = 0;
-    float bc0 = 0.f, bc1 = 0.f;
+    struct Carry { float c0, c1; int i, pp, t; };
+    Carry cy;
+    cy.c0 = cy.c1 = 0.f; cy.i = 0; cy.pp = 0; cy.t = T0;
 
-    auto run_back = [&]() -> bool {
-        if (bk == BK_NONE) return true;
-        const float *PB = DPARTOF(bpp);
-        const int nb = (int)((nbpack >> (8 * bi)) & 255u);
-        if (!ok) FAIL[0] = 1;
+    // ---------------- back half of a gh stage: gh(t+1) of the owned (unit, segment) -> ring entry (t + 1), consumed by the ih workgroup J at step t + 1
+    auto back_gh = [&](const Carry &c) {
+        const float *PB = DPARTOF(c.pp);
         lds_barrier();
-        if (FAIL[0] != 0) return false;
-        PH(cur + 1);
-        if (bk == BK_GH) {                              // gh(t+1) of the owned (unit, segment) -> ring entry (t + 1): consumed by the ih workgroup J at step t + 1
-            const float g0 = get_partial<3>(PB, 0, pu, pj) + bh_r, g1 = get_partial<3>(PB, 1, pu, pj) + bh_z, g2 = get_partial<3>(PB, 2, pu, pj) + bh_n;
-            const int r1 = (bt + 1) % DRING;
-            if (pj < nb) {                              // one 16-byte word {r, z, n, tag} per (unit, segment): no quad gather, one store, one load at the reader
-                const u32x4 q = {__float_as_uint(g0), __float_as_uint(g1), __float_as_uint(g2), (unsigned)bt + 2u};      // tag: consuming step (bt + 1) + 1
-                __builtin_amdgcn_raw_buffer_store_b128(q, xrs, (256 * (J & 7) + tid) * 16, DXL(bi, L_GH + (J >> 3), r1) * 4, 16 /* sc1 */);
-            }
-        } else if (bk == BK_RELU) {                     // fc1 / fc2 + relu of an odd slot -> publish y1 / y2 (as duo_ih)
-            publish4(xrs, (DXL(bi, L_Y, bt % DRING) + 256 * J) * 4, tid, fmaxf(get_partial<3>(PB, 0, pu, pj) + bc0, 0.f), pj < nb);
-        } else {                                        // fc3 logits -> sample x_t (utils/distribution.py:102-121)
-            const int b0 = GEO[2 * bi];
-            {   // 30 logit rows x 16 segments: thread (rows pu and 16 + pu, segment pj) -- the partial tiles' conflict-free reader mapping
-                const int row = pu, sj = pj;
-                const float lg = get_partial<3>(PB, 0, row, sj) + b3a;
-                const float lg2 = get_partial<3>(PB, 1, row, sj) + b3b;
-                LOG[sj * DLOGS + row] = lg;
-                if (a.dbg_logits && sj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + sj) * C + row] = lg;
-                if (row < 14) {
-                    LOG[sj * DLOGS + 16 + row] = lg2;
-                    if (a.dbg_logits && sj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + sj) * C + 16 + row] = lg2;
-                }
-            }
-            lds_barrier();
-            {   // 16-lane row = one segment (su), lane sm = mixture; bc0 / bc1 = this thread's pre-transformed noise
-                const int su = tid >> 4, sm = tid & 15;
-                float best = (sm < 10) ? mol_gumbel_pre(LOG[su * DLOGS + sm], bc0) : -INFINITY;
-                int bidx = sm;
-                argmax_row16(best, bidx);
-                if (sm == 0 && su < nb) {
-                    float xv = mol_sample_pre(LOG[su * DLOGS + 10 + bidx], LOG[su * DLOGS + 20 + bidx], bc1);
-                    a.out[(size_t)(b0 + su) * a.T + bt] = xv;
-                    if (a.force_x) xv = a.force_x[(size_t)(b0 + su) * a.T + bt];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xv), xrs, su * 4, DXL(bi, 7, bt % DRING) * 4, 16 /* sc1 */);
-                }
-            }
+        PHX(cur + 1);
+        const float g0 = get_partial<3>(PB, 0, pu, pj) + bh_r, g1 = get_partial<3>(PB, 1, pu, pj) + bh_z, g2 = get_partial<3>(PB, 2, pu, pj) + bh_n;
+        if (pj < slot_nb(c.i)) {                        // one 16-byte word {r, z, n, tag} per (unit, segment): one store, its own flag (hand-off form R2)
+            const u32x4 q = {__float_as_uint(g0), __float_as_uint(g1), __float_as_uint(g2), (unsigned)c.t + 2u};      // tag: consuming step (t + 1) + 1
+            const int so = cbase + c.i * (MAXCL * DSLOTB) + (L_GH + (J >> 3)) * DLAYERB + ((c.t + 1) & (DRING - 1)) * XTB;
+            if (loc_h) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, voff_gh, so, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, voff_gh, so, 16 /* sc1 */);
         }
-        bk = BK_NONE;
-        PH(cur + 2);
-        return true;
+        PHX(cur + 2);
     };
-
-    int ring = 0;
-    // kind 1: gh stage of slot i (polls h(t)); kind 2: fc stage of an odd slot (polls x2(t) / y1(t)); kind 3: sampling stage of my_slot (polls y2(t))
-    auto stage = [&](auto KC, int i) -> bool {
-        constexpr int kind = decltype(KC)::value;
-        const int nb = (int)((nbpack >> (8 * i)) & 255u);
-        float v0 = 0.f, v1 = 0.f;
-        float b[32];
-        bool ready = false;
-        cur = kind == 1 ? 0 : 8;
-        if (PROF && tid == 0 && plast == 0) plast = __builtin_amdgcn_s_memtime();
-#if DUO_PUBLISH_FIRST
-        if (!run_back()) return false;
-#endif
-        constexpr int xl = kind == 1 ? L_H : (kind == 2 ? L_P2 : 3);
-        if (DUO_HH_XAHEAD && xahead) ready = try_finish(lane, nb, x, b);
-        else issue(xrs, DXL(i, xl, ring) * 4, w, lane, x);
-        if (kind == 2) {                                // conditioning frame of (segment pj, step t): aux columns + bias of fc1 / fc2 as per-frame tables
-            const int *SP = reinterpret_cast<const int *>(smem + i * DGRP + D_SP);
-            const int p0 = SP[pj] + t;
-            const int fr = (p0 < SP[SEG + pj]) ? (p0 / a.hop) : a.NF;
-            v0 = (LA ? a.c3f : a.c4f)[(size_t)fr * H + prow];
+    // ---------------- back half of the sampling stage: fc3 logits -> sample x_t (utils/distribution.py:102-121)
+    auto back_sample = [&](const Carry &c) {
+        const float *PB = DPARTOF(c.pp);
+        const int bi = c.i, bt = c.t;
+        const int nb = slot_nb(bi);
+        const int b0 = GEO[2 * bi];
+        lds_barrier();
+        PHX(cur + 1);
+        {   // 30 logit rows x 16 segments: thread (rows pu and 16 + pu, segment pj) -- the partial tiles' conflict-free reader mapping
+            const float lg = get_partial<3>(PB, 0, pu, pj) + b3a;
+            const float lg2 = get_partial<3>(PB, 1, pu, pj) + b3b;
+            LOG[pj * DLOGS + pu] = lg;
+            if (a.dbg_logits && pj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + pj) * C + pu] = lg;
+            if (pu < 14) {
+                LOG[pj * DLOGS + 16 + pu] = lg2;
+                if (a.dbg_logits && pj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + pj) * C + 16 + pu] = lg2;
+            }
         }
-        if (kind == 3) {
+        lds_barrier();
+        {   // 16-lane row = one segment (su), lane sm = mixture; c0 / c1 = this thread's pre-transformed noise
+            const int su = tid >> 4, sm = tid & 15;
+            float best = (sm < 10) ? mol_gumbel_pre(LOG[su * DLOGS + sm], c.c0) : -INFINITY;
+            int bidx = sm;
+            argmax_row16(best, bidx);
+            if (sm == 0 && su < nb) {
+                float xv = mol_sample_pre(LOG[su * DLOGS + 10 + bidx], LOG[su * DLOGS + 20 + bidx], c.c1);
+                a.out[(size_t)(b0 + su) * a.T + bt] = xv;
+                if (a.force_x) xv = a.force_x[(size_t)(b0 + su) * a.T + bt];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xv), xrs, su * 4, cbase + bi * (MAXCL * DSLOTB) + 7 * DLAYERB + (bt & (DRING - 1)) * XTB, 16 /* sc1 */);
+            }
+        }
+        PHX(cur + 2);
+    };
+    enum { BK_NONE = 0, BK_GH = 1, BK_SAMPLE = 2, BK_ANY = 3 };
+    int pend = BK_NONE;                                 // run-time kind of the pending half, read only where two kinds can meet (BK_ANY sites)
+
+    // kind 1: gh stage of slot i (polls h(t)); kind 3: sampling stage of my_slot (polls y2(t))
+    auto stage = [&](auto KC, auto BKC, int i) {
+        constexpr int kind = decltype(KC)::value;
+        constexpr int BK = decltype(BKC)::value;
+        const int nb = slot_nb(i);
+        const int ring = t & (DRING - 1);
+        const int sbase = cbase + i * (MAXCL * DSLOTB);
+        const int soff_x = sbase + (kind == 1 ? L_H : 3) * DLAYERB + ring * XTB;
+        Carry nc;
+        nc.c0 = nc.c1 = 0.f; nc.i = i; nc.pp = pp; nc.t = t;
+        auto run_back = [&] {
+            if constexpr (BK == BK_GH) back_gh(cy);
+            else if constexpr (BK == BK_SAMPLE) back_sample(cy);
+            else if constexpr (BK == BK_ANY) {
+                if (pend == BK_GH) back_gh(cy);
+                else if (pend == BK_SAMPLE) { if constexpr (!LA) back_sample(cy); }
+            }
+        };
+        if (PROF && tid == 0 && plast == 0) plast = __builtin_amdgcn_s_memtime();
+        if constexpr (PF) run_back();
+        cur = kind == 1 ? 0 : 8;
+        if (!xahead) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
+        }
+        if constexpr (kind == 3) {
             // this step's sampling noise, pre-transformed (wrnn_noise_mol_kernel): thread (segment tid >> 4, mixture tid & 15)
             const int b0 = GEO[2 * i];
             const int su = tid >> 4, sm = tid & 15;
             const float *nrow = a.noise_pre + (size_t)(t - a.noise_t0) * 11 * Nall;
             const int suc = su < nb ? su : nb - 1;
-            v0 = nrow[(size_t)(b0 + suc) * 10 + (sm < 10 ? sm : 9)];
-            v1 = nrow[(size_t)10 * Nall + b0 + suc];
+            nc.c0 = nrow[(size_t)(b0 + suc) * 10 + (sm < 10 ? sm : 9)];
+            nc.c1 = nrow[(size_t)10 * Nall + b0 + suc];
         }
-        PH(cur + 0);
-#if !DUO_PUBLISH_FIRST
-        if (!run_back()) return false;
-#endif
+        PHX(cur + 0);
+        if constexpr (!PF) run_back();
         {
-            unsigned spins = 0;
-            if (!ready) {
-                ok = ok && finish(xrs, DXL(i, xl, ring) * 4, w, lane, nb, x, b, a.status, spins);
-                if (!ok && fcode == 0u) fcode = 0x600u | (LA ? 0u : 8u) | (unsigned)kind;
-            }
-            if (PROF && tid == 0) { PROFL[cur + 6] += 1; PROFL[cur + 7] += !ready; }
+            const bool live = fi < nb;
+            const bool there = frag_there(x, live);
+            if (PROF && tid == 0) { PROFL[cur + 6] += 1; PROFL[cur + 7] += !there; }
+            if (__builtin_expect(!there, 0))
+                wait_for([&] { return frag_there(x, live); },
+                         [&] {
+#pragma unroll
+                             for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
+                         },
+                         a.status, dead, 0x600u | (LA ? 0u : 8u) | (unsigned)kind, t);
         }
-        PH(cur + 3);
+        PHX(cur + 3);
         if (sampler && kind == 3) {
-            // ring hygiene (see the header): drain, then re-arm this wave's words of entry (t + 4) % 8: the x_t words of the slot it
-            // samples (the gh words carry a step tag instead of relying on a sentinel: nothing to re-arm)
+            // ring hygiene (see the header): drain, then re-arm the x_t words of the slot this workgroup samples in entry (t + 4) % 8
+            // (the gh words carry a step tag instead of relying on a sentinel: nothing to re-arm)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int ringn = (t + DAHEAD) % DRING;
-            if (lane == 48) {                // the 4 x_t words this wave publishes (segments 4 w ..)
+            if (lane == 48) {                           // the 4 x_t words of segments 4 w ..
                 const u32x4 q = {SENT, SENT, SENT, SENT};
-                __builtin_amdgcn_raw_buffer_store_b128(q, xrs, 16 * w, DXL(my_slot, 7, ringn) * 4, 16 /* sc1 */);
+                __builtin_amdgcn_raw_buffer_store_b128(q, xrs, 16 * w, sbase + 7 * DLAYERB + ((t + DAHEAD) & (DRING - 1)) * XTB, 16 /* sc1 */);
             }
         }
-        {   // the next stage's polled layer, one stage ahead (not across a step boundary)
+        float b[32];
+        frag_to_b(x, b);
+        {   // the next stage's polled layer, one stage ahead (not across a step boundary: nothing of the next step is published yet)
             xahead = false;
-            if (DUO_HH_XAHEAD && (a.tuning & 1) == 0 && kind != 3) {
-                int nk = 0, ni = 0;                     // the stage that follows in the step: gh of every slot, fc of the odd ones, sampling
-                if (kind == 1 && i + 1 < nact) { nk = 1; ni = i + 1; }
-                else if (kind == 1 && split_fc && nact >= 2) { nk = 2; ni = 1; }
-                else if (kind == 2 && i + 2 < nact) { nk = 2; ni = i + 2; }
-                else if (sampler) { nk = 3; ni = my_slot; }
-                if (nk != 0) {
+            if (kind == 1) {
+                int so = -1;
+                if (i + 1 < nact) so = sbase + MAXCL * DSLOTB + L_H * DLAYERB + ring * XTB;
+                else if (sampler) so = cbase + my_slot * (MAXCL * DSLOTB) + 3 * DLAYERB + ring * XTB;
+                if (so >= 0) {
                     xahead = true;
-                    issue(xrs, DXL(ni, nk == 1 ? L_H : (nk == 2 ? L_P2 : 3), ring) * 4, w, lane, x);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, so, 16 /* sc1 */);
                 }
             }
         }
-        PH(cur + 4);
+        PHX(cur + 4);
         float *PW = DPARTOF(pp);
-        if (prio_mfma) __builtin_amdgcn_s_setprio(1);
-        if (kind == 1) {
+        if constexpr (kind == 1) {
             f32x4 o0, o1, o2;
-            mfma3(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
+            mfma3s(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
             put_partial<3>(PW, w, 0, lane, o0);
             put_partial<3>(PW, w, 1, lane, o1);
             put_partial<3>(PW, w, 2, lane, o2);
-            bk = BK_GH;
-        } else if (kind == 2) {
-#if DUO_SPLIT_FC
-            put_partial<3>(PW, w, 0, lane, mfma1(A_fc, b));
-#endif
-            bk = BK_RELU;
+            pend = BK_GH;
         } else {
             put_partial<3>(PW, w, 0, lane, mfma1_glb(a.fc3f + frag_off(w, 0, lane), b));
             put_partial<3>(PW, w, 1, lane, mfma1_glb(a.fc3f + XT + frag_off(w, 0, lane), b));
-            bk = BK_SAMPLE;
+            pend = BK_SAMPLE;
         }
-        if (prio_mfma) __builtin_amdgcn_s_setprio(0);
-        PH(cur + 5);
-        bi = i; bpp = pp; bt = t; bc0 = v0; bc1 = v1;
+        PHX(cur + 5);
+        cy = nc;
         pp ^= 1;
-        return true;
     };
 
+    using K1 = std::integral_constant<int, 1>;
+    using K3 = std::integral_constant<int, 3>;
+    using BGH = std::integral_constant<int, BK_GH>;
+    using BANY = std::integral_constant<int, BK_ANY>;
     for (; t < T1; ++t) {
-        ring = t % DRING;
+        stage(K1{}, BANY{}, 0);
 #pragma unroll 1
-        for (int i = 0; i < nact; ++i)
-            if (!stage(std::integral_constant<int, 1>{}, i)) goto bail;
-        if (split_fc) {
-#pragma unroll 1
-            for (int i = 1; i < nact; i += 2)
-                if (!stage(std::integral_constant<int, 2>{}, i)) goto bail;
-        }
-        if (sampler) {
-            if (!stage(std::integral_constant<int, 3>{}, my_slot)) goto bail;
+        for (int i = 1; i < nact; ++i) stage(K1{}, BGH{}, i);
+        if constexpr (!LA) {
+            if (sampler) stage(K3{}, BGH{}, my_slot);
         }
     }
-    if (!run_back()) goto bail;
+    cur = 0;
+    if (pend == BK_GH) back_gh(cy);
+    else if (pend == BK_SAMPLE) { if constexpr (!LA) back_sample(cy); }
     if (PROF && tid == 0 && a.prof) {
         for (int k = 0; k < 16; ++k) a.prof[(size_t)(blockIdx.x & 255) * 32 + 16 + k] += PROFL[k];
     }
-    return;
-bail:
-    if (fcode != 0u) report_failure(a.status, fcode, blockIdx.x, t, tid);
-#undef PH
 }
-#undef DXL
 #undef DPARTOF
+#undef PHX
 
-// Grid = clusters x 128 workgroups of 256 threads (two per CU), cooperative launch.  Workgroup wg of a cluster: role wg & 3, unit
-// block wg >> 2.  Whole XCDs per cluster (speed only: nothing depends on the placement).
-template <bool PROF>
+// Grid = clusters x 128 workgroups of 256 threads (two per CU), cooperative launch.  Whole XCDs per cluster (speed only: nothing
+// depends on the placement; what the placement is, is looked at below).
+template <bool PF, bool PROF>
 __global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int cl, wg;
     const int ncl = gridDim.x / DNWGC;
+    check_kind(a);
     {
         const int b = blockIdx.x, nblk = gridDim.x;
         if (nblk % 8 == 0 && ncl >= 1 && 8 % ncl == 0) {
@@ -868,26 +757,53 @@ __global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
             wg = b % DNWGC;
         }
     }
-    // role / unit block of workgroup wg.  Speed only: blocks are observed to be dealt round-robin over the CUs of an XCD, i.e. (with
-    // 64 blocks per XCD on 32 CUs) local blocks q and q + 32 share a CU.  The pairing below puts an ih workgroup (128 MFMAs per
-    // group-step and wave) next to the hh workgroup of the same layer and unit block (96): every SIMD then carries 224 MFMAs per
-    // group-step, and one wave's tiles can run under the other's pointwise / load / barrier time.  (wg & 3 as the role would
-    // pair two workgroups of the SAME role on every CU.)
-    int role, J;
+    // role / unit block of workgroup wg.  Speed only: block b is observed to run on XCD b % 8 and the blocks of an XCD to be dealt
+    // round-robin over its 32 CUs, i.e. (with 64 blocks per XCD) local blocks q and q + 32 share a CU.  First half of a cluster's
+    // blocks (one XCD when a cluster spans two): rnn1, second half: rnn2; within a half q < 32: the ih workgroup of unit block q,
+    // q >= 32: the hh workgroup of unit block q - 32 -- so a CU carries the ih (128 MFMAs per group-step and wave) and the hh
+    // workgroup (96) of the same units, and h / gh / (rnn2) y2 never leave the XCD.
+    const int layer = wg / (DNWGC / 2), q = wg % (DNWGC / 2);
+    const int hh = q >> 5, J = q & 31;
+    // ---- placement handshake: every workgroup records its XCC id; a layer whose producers and consumers all sit on one XCD is
+    //      exchanged through that XCD's L2 with plain stores.  Every workgroup of a cluster reads the same 128 words -> the same verdict.
+    bool loc_a = false, loc_b = false;
     {
-        const int half = DNWGC / 2;                     // 64: the workgroups of one XCD when a cluster spans two
-        const int q = wg % half, xh = wg / half;
-        role = ((q >> 5) << 1) | (q & 1);               // second half of an XCD's blocks: hh; odd: layer 2
-        J = xh * (LNJ / 2) + ((q & 31) >> 1);
+        int *TAB = reinterpret_cast<int *>(smem) + 2 * LMAXG;         // scratch (the roles clear their LDS afterwards)
+        const int tid = threadIdx.x;
+        unsigned *tab = a.xcc_tab + cl * DNWGC;
+        if (tid == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;          // HW_REG_XCC_ID
+            __hip_atomic_store(tab + wg, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!PROF && a.prof && blockIdx.x < 2048 && (a.tuning & 64)) {                   // placement read-out (test / profiling hook)
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                a.prof[blockIdx.x] = ((u64)xcc << 32) | hw | ((u64)(unsigned)((layer | (hh << 1)) | (J << 2) | (cl << 8)) << 40);
+            }
+        }
+        unsigned v = 1u;
+        if (tid < DNWGC) {
+            unsigned spins = 0;
+            v = ld_agent32(tab + tid);
+            while (v == 0u && ++spins < 200000u) {
+                __builtin_amdgcn_s_sleep(2);
+                v = ld_agent32(tab + tid);
+            }
+            TAB[tid] = (int)v;
+        }
+        __syncthreads();
+        const int ok_a = (tid < DNWGC / 2) ? (v != 0u && (int)v == TAB[0]) : 1;
+        const int ok_b = (tid >= DNWGC / 2 && tid < DNWGC) ? (v != 0u && (int)v == TAB[DNWGC / 2]) : 1;
+        loc_a = __syncthreads_and(ok_a) != 0;
+        loc_b = __syncthreads_and(ok_b) != 0;
+        if (a.tuning & 256) { loc_a = false; loc_b = false; }        // A/B: everything written through, as round 3
+        __syncthreads();
     }
-    if (!PROF && a.prof && threadIdx.x == 0 && blockIdx.x < 2048) {   // placement read-out (test / profiling hook): HW_ID and XCC_ID of the block
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        a.prof[blockIdx.x] = ((u64)xcc << 32) | hw | ((u64)(unsigned)(role | (J << 2) | (cl << 8)) << 40);
+    if (layer == 0) {
+        if (hh == 0) duo_ih<true, PF, PROF>(a, smem, cl, J, ncl, loc_a, false);
+        else duo_hh<true, PF, PROF>(a, smem, cl, J, ncl, loc_a);
+    } else {
+        if (hh == 0) duo_ih<false, PF, PROF>(a, smem, cl, J, ncl, loc_b, loc_b);
+        else duo_hh<false, PF, PROF>(a, smem, cl, J, ncl, loc_b);
     }
-    if (role == 0) duo_ih<true, PROF>(a, smem, cl, J, ncl);
-    else if (role == 1) duo_ih<false, PROF>(a, smem, cl, J, ncl);
-    else if (role == 2) duo_hh<true, PROF>(a, smem, cl, J, ncl);
-    else duo_hh<false, PROF>(a, smem, cl, J, ncl);
 }
 
 size_t duo_lds_bytes(int G) { return (size_t)duo_lds(G).total * sizeof(float); }
@@ -904,12 +820,18 @@ int duo_clusters(int n_cus)
     return ncl;
 }
 
+// publish_first: < 0 = by depth (DUO_PUBFIRST_DEPTH), 0 / 1 = forced
+constexpr int DUO_PUBFIRST_DEPTH = 4;
 hipError_t launch_duo(const LoopArgs &args, int ncl, hipStream_t stream)
 {
-    if (ncl < 1 || args.G < 1 || args.G > LMAXG || !args.fc3f) return hipErrorInvalidValue;
+    if (ncl < 1 || args.G < 1 || args.G > LMAXG || !args.fc3f || !args.u1 || !args.xcc_tab) return hipErrorInvalidValue;
     const size_t lds = duo_lds_bytes(args.G);
+    // stage order: tuning bit 0 = loads first, bit 1 = publish first (default: publish first up to DUO_PUBFIRST_DEPTH groups in flight)
+    const bool pf = (args.tuning & 2) ? true : ((args.tuning & 1) ? false : args.G <= DUO_PUBFIRST_DEPTH);
     // phase clocks (wrnn_options.phase_clocks) unless tuning bit 6 asks for the placement read-out through the same buffer
-    const void *fn = (args.prof && !(args.tuning & 64)) ? (const void *)wrnn_duo_kernel<true> : (const void *)wrnn_duo_kernel<false>;
+    const bool prof = args.prof && !(args.tuning & 64);
+    const void *fn = pf ? (prof ? (const void *)wrnn_duo_kernel<true, true> : (const void *)wrnn_duo_kernel<true, false>)
+                        : (prof ? (const void *)wrnn_duo_kernel<false, true> : (const void *)wrnn_duo_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     LoopArgs a = args;

@@ -711,6 +711,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_loop_kernel(const LoopArgs a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int cl, wg;                                         // cluster, workgroup-in-cluster: whole XCDs per cluster (speed only)
     const int ncl = gridDim.x / LNWGC;
+    check_kind(a);
     {
         const int b = blockIdx.x, nblk = gridDim.x;
         if (nblk % 8 == 0 && ncl >= 1 && 8 % ncl == 0) {

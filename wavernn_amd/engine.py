@@ -32,6 +32,7 @@ class LoopEngine:
                                  'there is no CPU fallback')
         self.lib = _lib.lib()
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.mode = mode
         host = {k: _as_host_f32(state_dict[v]) for k, v in LOOP_KEYS.items()}
         w = _lib.Weights()
@@ -48,16 +49,18 @@ class LoopEngine:
         self.n_classes = int(w.n_classes)
         self.feat_dims, self.aux_dims = int(w.feat_dims), int(w.aux_dims)
         pack = ctypes.c_void_p()
-        _lib.check(self.lib.wrnn_pack_create(ctypes.byref(w), self.device.index or 0, ctypes.byref(pack)), 'wrnn_pack_create')
+        _lib.check(self.lib.wrnn_pack_create(ctypes.byref(w), self._dev_index, ctypes.byref(pack)), 'wrnn_pack_create')
         self._pack = pack
         self._ws = None
-        self.n_cus = self.lib.wrnn_device_cus(self.device.index or 0)
+        self.n_cus = self.lib.wrnn_device_cus(self._dev_index)
         timer = ctypes.c_void_p()
-        _lib.check(self.lib.wrnn_timer_create(self.device.index or 0, ctypes.byref(timer)), 'wrnn_timer_create')
+        _lib.check(self.lib.wrnn_timer_create(self._dev_index, ctypes.byref(timer)), 'wrnn_timer_create')
         self._timer = timer
         self._info = _lib.RunInfo()
         self._last_opts = None
         self._launches = 0
+        self._slice_algo = None
+        self._progress_keep = []          # ctypes thunks of progress callbacks whose host functions may still be queued on the stream
 
     def __del__(self):
         try:
@@ -132,6 +135,10 @@ class LoopEngine:
         if mels_up.shape[1] != self.feat_dims or aux.shape[1] != 4 * self.aux_dims:
             raise ValueError('conditioning shape mismatch')
         t0, t1 = (0, T) if t_range is None else (int(t_range[0]), int(t_range[1]))
+        if t0 > 0 and algo == 'auto' and self._slice_algo is not None:
+            # a continuation runs on the kernel its first slice settled on (`auto` may have fallen back from two workgroups per CU to
+            # one on that slice only; the two kernels keep different state / ring layouts -- the library also checks: status word 8)
+            algo = self._slice_algo
         need = (t1 - t0) * 11 * B if self.mode == 'MOL' else (t1 - t0) * B * self.n_classes
         if noise.numel() != need:
             raise ValueError(f'noise has {noise.numel()} elements, expected {need}')
@@ -157,9 +164,10 @@ class LoopEngine:
             o.logits = logits.data_ptr()
         if phase_clocks is not None:      # profiling hook: int64 CUDA tensor [256, 32], zeroed by the caller
             o.phase_clocks = phase_clocks.data_ptr()
-        if progress is not None:          # keep the ctypes thunk alive until the stream has drained (released on the next call)
-            self._progress_keep = _lib.PROGRESS_FN(lambda done, T_, n_, user: progress(int(done), int(T_), int(n_)))
-            o.progress = ctypes.cast(self._progress_keep, ctypes.c_void_p)
+        if progress is not None:          # the thunk must outlive the host functions queued behind the slabs: released after a synchronisation
+            thunk = _lib.PROGRESS_FN(lambda done, T_, n_, user: progress(int(done), int(T_), int(n_)))
+            self._progress_keep.append(thunk)
+            o.progress = ctypes.cast(thunk, ctypes.c_void_p)
         o.timer = self._timer
         o.info = ctypes.pointer(self._info)
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -179,15 +187,21 @@ class LoopEngine:
             raise _lib.ResidencyError('cooperative launch refused (' + self.lib.wrnn_last_error().decode() + ')')
         _lib.check(rc, 'wrnn_generate_segments')
         self._launches = (self._launches if t0 > 0 else 0) + int(self._info.launches)
+        if t0 == 0:
+            self._slice_algo = {'wrnn_loop_kernel': 'loop', 'wrnn_duo_kernel': 'duo'}.get((self._info.kernel or b'').decode())
         self._last_opts = (B, T, n_frames, self.options(algo, depth, clusters, slab_steps, cond_valu, None))
         if check:
-            _lib.check(self.lib.wrnn_status(self._ws.data_ptr(), stream), 'loop kernel')
+            rc = self.lib.wrnn_status(self._ws.data_ptr(), stream)      # synchronises the stream: every queued progress call has run
+            del self._progress_keep[:]
+            _lib.check(rc, 'loop kernel')
         return (out, logits) if want_logits else out
 
     def status(self):
         """Synchronise the current stream and raise if a loop kernel of the last call gave up (for `check=False` calls)."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self.lib.wrnn_status(self._ws.data_ptr(), stream), 'loop kernel')
+        rc = self.lib.wrnn_status(self._ws.data_ptr(), stream)
+        del self._progress_keep[:]
+        _lib.check(rc, 'loop kernel')
 
     def read_exchange(self, cluster, slot, layer, ring):
         """Test hook: one exchanged layer (0 h1, 1 h2, 2 y1, 3 y2, 4 RAW logits) of the last loop-kernel call as a host

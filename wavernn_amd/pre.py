@@ -48,7 +48,7 @@ class PreEngine:
             setattr(w, name, arr.ctypes.data)
         self.feat_dims, self.res_out_dims = int(feat), int(conv_out_w.shape[0])
         pre = ctypes.c_void_p()
-        rc = self.lib.wrnn_pre_create(ctypes.byref(w), self.device.index or 0, ctypes.byref(pre))
+        rc = self.lib.wrnn_pre_create(ctypes.byref(w), (self.device.index if self.device.index is not None else torch.cuda.current_device()), ctypes.byref(pre))
         if rc != 0:
             raise _lib.WrnnError(f'wrnn_pre_create failed (rc={rc}): {self.lib.wrnn_pre_last_error().decode()}')
         self._pre = pre

@@ -115,7 +115,7 @@ class TacotronInference:
         c.gi_fwd, c.gi_rev, c.w_hh_fwd, c.w_hh_rev = gi_f.data_ptr(), gi_r.data_ptr(), w_hh.data_ptr(), w_hh_r.data_ptr()
         c.b_hh_fwd, c.b_hh_rev, c.out = b_hh.data_ptr(), b_hh_r.data_ptr(), out.data_ptr()
         c.stream = torch.cuda.current_stream(x.device).cuda_stream
-        rc = L.wrnn_bigru(x.device.index or 0, ctypes.byref(c))
+        rc = L.wrnn_bigru((x.device.index if x.device.index is not None else torch.cuda.current_device()), ctypes.byref(c))
         if rc != _lib.WRNN_OK:
             raise _lib.WrnnError(f'wrnn_bigru failed (rc={rc}): {L.wrnn_taco_last_error().decode()}')
         return out
@@ -200,7 +200,7 @@ class TacotronInference:
         c.steps_done, c.workspace, c.workspace_bytes = done.data_ptr(), ws.data_ptr(), ws.numel()
         c.stream = torch.cuda.current_stream(dev).cuda_stream
         c.variant = int(variant)
-        rc = L.wrnn_taco_decode(dev.index or 0, ctypes.byref(w), ctypes.byref(c))
+        rc = L.wrnn_taco_decode((dev.index if dev.index is not None else torch.cuda.current_device()), ctypes.byref(w), ctypes.byref(c))
         if rc != _lib.WRNN_OK:
             raise _lib.WrnnError(f'wrnn_taco_decode failed (rc={rc}): {L.wrnn_taco_last_error().decode()}')
         st4 = (ctypes.c_uint32 * 4)()
