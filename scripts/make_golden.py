@@ -160,11 +160,45 @@ def tacotron_shapes():
     print('tacotron shapes written:', len(table), 'tensors')
 
 
+def tacotron_decoder_golden(steps=200, wseed=3):
+    """What the reference's own `Tacotron.generate` (models/tacotron.py:370-430) returns for the weights the GPU tests use:
+    `random_tacotron_state_dict(3, shapes)` loaded into the REFERENCE class, first line of sentences.txt, `steps` decoder steps.
+    tests/test_gpu_config3.py compares both decoder kernels and the CBHG GRU kernel's post-net to these arrays on the GPU box
+    (SURVEY.md section 8 row f3); tests/test_oracle_golden.py compares the CPU mirror to them here."""
+    import json
+    un = types.ModuleType('unidecode'); un.unidecode = lambda s: s
+    sys.modules.setdefault('unidecode', un)
+    inf = types.ModuleType('inflect'); inf.engine = lambda: types.SimpleNamespace(number_to_words=lambda *a, **k: 'number')
+    sys.modules.setdefault('inflect', inf)
+    from models.tacotron import Tacotron
+    from utils.text.symbols import symbols
+    from utils.text import text_to_sequence
+    from wavernn_amd.synthetic import random_tacotron_state_dict
+    tts = Tacotron(embed_dims=hp.tts_embed_dims, num_chars=len(symbols), encoder_dims=hp.tts_encoder_dims,
+                   decoder_dims=hp.tts_decoder_dims, n_mels=hp.num_mels, fft_bins=hp.num_mels, postnet_dims=hp.tts_postnet_dims,
+                   encoder_K=hp.tts_encoder_K, lstm_dims=hp.tts_lstm_dims, postnet_K=hp.tts_postnet_K,
+                   num_highways=hp.tts_num_highways, dropout=hp.tts_dropout, stop_threshold=hp.tts_stop_threshold)
+    shapes = json.load(open(os.path.join(OUT, 'tacotron_shapes.json')))
+    sd = {k: torch.as_tensor(np.array(v)) for k, v in random_tacotron_state_dict(wseed, shapes).items()}
+    tts.load_state_dict(sd, strict=True)
+    with open(os.path.join(REF, 'sentences.txt')) as f:
+        ids = text_to_sequence(f.readline().strip(), hp.tts_cleaner_names)
+    with torch.no_grad():
+        mel, lin, attn = tts.generate(ids, steps=steps)
+    mel, lin, attn = np.asarray(mel, np.float32), np.asarray(lin, np.float32), np.asarray(attn, np.float32)
+    assert mel.shape == (80, steps) and lin.shape == (80, steps) and attn.shape == (steps, len(ids)), (mel.shape, lin.shape, attn.shape)
+    np.savez_compressed(os.path.join(OUT, f'tacotron_decoder_{steps}f.npz'), mel=mel, linear=lin, attention=attn, ids=np.array(ids, np.int32),
+                        config=np.array(repr(dict(wseed=wseed, steps=steps, source='reference models/tacotron.py Tacotron.generate, CPU'))))
+    print('tacotron decoder golden:', mel.shape, lin.shape, attn.shape, 'mel absmax', float(np.abs(mel).max()))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     rng_kats()
     tacotron_shapes()
     only = sys.argv[1:]
+    if not only or 'tacotron_decoder_200f' in only:
+        tacotron_decoder_golden()
     for c in CASES:
         if only and c['name'] not in only:
             continue

@@ -71,19 +71,31 @@ def _tts(dev, seed=3, **override):
 IDS_TEXT = 'Scientists at the CERN laboratory say they have discovered a new particle.'
 
 
+#: decoder-kernel tolerance against the REFERENCE's own output over all 200 frames (mel |x| <= 0.016, attention rows sum to 1): the kernels
+#: were measured at <= 7.5e-9 (profiles/r03ad_taco_profile.json); 1e-6 leaves room for another summation order, not for a wrong term
+TACO_TOL = 1e-6
+
+
+def _decoder_golden():
+    g = np.load(os.path.join(HERE, 'golden', 'tacotron_decoder_200f.npz'))
+    return g['mel'], g['linear'], g['attention'], [int(i) for i in g['ids']]
+
+
 @pytest.mark.parametrize('variant', [2, 1], ids=['resident', 'flag-barrier'])
-def test_tacotron_decoder_kernel_matches_the_cpu_mirror(variant):
+def test_tacotron_decoder_kernel_matches_the_reference(variant):
     """the decoder loop as ONE persistent kernel (csrc/wrnn_taco.hip, `wrnn_taco_decode`; both forms: the
-    register-resident kernel with the tagged exchange that `auto` picks on a >= 128-CU device, and the flag-barrier kernel) against (a) the same
-    `TacotronInference` run on the CPU -- which tests/test_tacotron_mirror.py pins bit-exactly to the reference's `Tacotron.generate`
-    (models/tacotron.py:370-430) -- and (b) its eager PyTorch-ROCm loop on the device.  The kernel sums K in another order and 200
-    recurrent steps amplify rounding: 1e-4 on the first 32 frames, the same trajectory (5e-2) on the rest; attention rows are
-    probability vectors."""
+    register-resident kernel with the tagged exchange that `auto` picks on a >= 128-CU device, and the flag-barrier kernel) against
+    what the REFERENCE's `Tacotron.generate` (models/tacotron.py:370-430) itself returned for these weights and this sentence --
+    tests/golden/tacotron_decoder_200f.npz, written by scripts/make_golden.py from /root/reference in the build container: decoder
+    mel and attention of all 200 frames within TACO_TOL, and the post-net output (encoder / post-net CBHG with `wrnn_bigru`)
+    within the same bound.  Also against the CPU mirror and the eager PyTorch-ROCm loop on this box."""
     from wavernn_amd.tacotron import text_to_ids
     dev = torch.device('cuda', 0)
+    ref_mel, ref_lin, ref_attn, ref_ids = _decoder_golden()
     ids = text_to_ids(IDS_TEXT)
-    steps = 200
-    mel_c, lin_c, attn_c = _tts('cpu').generate(ids, steps=steps)                 # the mirror of the reference, on the host
+    assert ids == ref_ids
+    steps = ref_mel.shape[1]
+    mel_c, lin_c, attn_c = _tts('cpu').generate(ids, steps=steps)                 # the mirror of the reference, on this host
     tts = _tts(dev)
     mel_e, lin_e, attn_e = tts.generate(ids, steps=steps)
     tts.generate(ids, steps=8, kernel=True, kernel_variant=variant)                # warm-up (module load, workspace)
@@ -92,15 +104,18 @@ def test_tacotron_decoder_kernel_matches_the_cpu_mirror(variant):
     mel_k, lin_k, attn_k = tts.generate(ids, steps=steps, kernel=True, kernel_variant=variant)
     torch.cuda.synchronize()
     t_k = time.perf_counter() - t0
-    assert mel_k.shape == mel_c.shape == (80, steps) and attn_k.shape == attn_c.shape
-    d = np.abs(mel_c - mel_k).max(axis=0)
-    de = np.abs(mel_e - mel_k).max(axis=0)
-    print(f'decoder kernel (variant {variant}): {steps} frames in {t_k * 1e3:.1f} ms incl. encoder + post-net; max |d mel| per frame vs the CPU mirror', d[:4], '...', d[-4:],
-          'vs eager on the device', de[:4], '...', de[-4:])
-    assert d[:32].max() <= 1e-4, d[:32]
-    assert d.max() <= 5e-2 and np.abs(attn_c - attn_k).max() <= 5e-2
-    assert de[:32].max() <= 1e-4 and de.max() <= 5e-2
-    assert np.abs(lin_c - lin_k)[:, :32].max() <= 1e-3
+    assert mel_k.shape == ref_mel.shape == (80, steps) and attn_k.shape == ref_attn.shape
+    d = np.abs(ref_mel - mel_k).max(axis=0)
+    da = np.abs(ref_attn - attn_k).max()
+    dl = np.abs(ref_lin - lin_k).max()
+    print(f'decoder kernel (variant {variant}): {steps} frames in {t_k * 1e3:.1f} ms incl. encoder + post-net; vs the reference: max |d mel| per frame',
+          d[:3], '...', d[-3:], f'attention {da:.2e} post-net {dl:.2e}; CPU mirror on this host vs the reference {np.abs(ref_mel - mel_c).max():.2e}')
+    assert d.max() <= TACO_TOL, d.max()
+    assert da <= TACO_TOL, da
+    assert dl <= TACO_TOL, dl
+    # the mirror on this host and the eager loop on the device follow the same trajectory
+    assert np.abs(ref_mel - mel_c).max() <= TACO_TOL and np.abs(ref_attn - attn_c).max() <= TACO_TOL
+    assert np.abs(mel_e - mel_k).max() <= 1e-5 and np.abs(attn_e - attn_k).max() <= 1e-5
     np.testing.assert_allclose(attn_k.sum(axis=1), 1.0, atol=1e-5)
 
 
@@ -118,21 +133,21 @@ def test_tacotron_decoder_kernel_stop_test_and_r(variant):
     mel_e, _, _ = tts.generate(ids, steps=100)
     mel_k, _, attn_k = tts.generate(ids, steps=100, kernel=True, kernel_variant=variant)
     assert mel_c.shape == mel_e.shape == mel_k.shape == (80, 12), (mel_c.shape, mel_e.shape, mel_k.shape)      # t = 0 .. 11: the first t > 10
-    assert np.abs(mel_c - mel_k).max() <= 1e-4 and attn_k.shape == attn_c.shape
+    assert np.abs(mel_c - mel_k).max() <= TACO_TOL and attn_k.shape == attn_c.shape
     r2 = dict(r=torch.tensor(2))
     if 'decoder.r' in _tts('cpu').p:
         r2 = {'decoder.r': torch.tensor(2)}
     mel_c, _, attn_c = _tts('cpu', **r2).generate(ids, steps=40)
     mel_k, _, attn_k = _tts(dev, **r2).generate(ids, steps=40, kernel=True, kernel_variant=variant)
     assert mel_c.shape == mel_k.shape == (80, 40) and attn_c.shape == attn_k.shape == (20, len(ids))
-    assert np.abs(mel_c - mel_k)[:, :16].max() <= 1e-4 and np.abs(mel_c - mel_k).max() <= 5e-2
+    assert np.abs(mel_c - mel_k).max() <= TACO_TOL and np.abs(attn_c - attn_k).max() <= TACO_TOL
     # more encoder positions than waves (n > 512: the second position of a wave, 16-deep context sums)
     long_ids = text_to_ids(' '.join([IDS_TEXT] * 9))
     assert 512 < len(long_ids) <= 1024
     mel_c, _, attn_c = _tts('cpu').generate(long_ids, steps=12)
     mel_k, _, attn_k = _tts(dev).generate(long_ids, steps=12, kernel=True, kernel_variant=variant)
     assert mel_c.shape == mel_k.shape and attn_c.shape == attn_k.shape == (12, len(long_ids))
-    assert np.abs(mel_c - mel_k).max() <= 1e-4 and np.abs(attn_c - attn_k).max() <= 1e-5
+    assert np.abs(mel_c - mel_k).max() <= TACO_TOL and np.abs(attn_c - attn_k).max() <= TACO_TOL
 
 
 @pytest.mark.parametrize('T', [1, 74, 800])

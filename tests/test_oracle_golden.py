@@ -124,3 +124,22 @@ def test_torch_eager_restatement_matches_reference_golden(name):
         assert np.array_equal(out, g['raw'])
     else:
         assert np.abs(out - g['raw']).max() <= 1e-6
+
+
+def test_tacotron_mirror_reproduces_the_reference_decoder_fixture():
+    """tests/golden/tacotron_decoder_200f.npz holds what the REFERENCE's `Tacotron.generate` (models/tacotron.py:370-430) returned
+    for `random_tacotron_state_dict(3, shapes)` and the first line of sentences.txt (scripts/make_golden.py, build container).  The
+    functional mirror the GPU kernels are also compared with reproduces it on this host's CPU: decoder mel, post-net output and
+    attention of all 200 frames (<= 1e-6; bit-identical in the build container, where tests/test_tacotron_mirror.py runs both)."""
+    import json, os
+    import numpy as np
+    from helpers import GOLDEN
+    from wavernn_amd.synthetic import random_tacotron_state_dict
+    from wavernn_amd.tacotron import TacotronInference, text_to_ids
+    g = np.load(os.path.join(GOLDEN, 'tacotron_decoder_200f.npz'))
+    shapes = json.load(open(os.path.join(GOLDEN, 'tacotron_shapes.json')))
+    ids = text_to_ids('Scientists at the CERN laboratory say they have discovered a new particle.')
+    assert ids == [int(i) for i in g['ids']]
+    mel, lin, attn = TacotronInference(random_tacotron_state_dict(3, shapes)).generate(ids, steps=g['mel'].shape[1])
+    assert mel.shape == g['mel'].shape and attn.shape == g['attention'].shape
+    assert np.abs(mel - g['mel']).max() <= 1e-6 and np.abs(lin - g['linear']).max() <= 1e-6 and np.abs(attn - g['attention']).max() <= 1e-6

@@ -372,8 +372,8 @@ int enqueue_progress(const wrnn_options *o, int done, int T, int n, hipStream_t 
 }
 
 enum Kind { K_STREAM, K_LOOP, K_SPARSE, K_DUO, K_GENERIC };
-constexpr bool DUO_AUTO = true;      // `auto` picks wrnn_duo_kernel from DUO_MIN_DEPTH groups in flight per cluster on: measured (profiles/r03p_probe_min_depth.json)
-constexpr int DUO_MIN_DEPTH = 3;     // 1.15x wrnn_loop_kernel at depth 3 and 4, 1.29x at depth 8; 0.94x at depth 2 (its slot chain is one hop longer)
+constexpr bool DUO_AUTO = true;      // `auto` runs MoL on wrnn_duo_kernel at every depth (round 4, profiles/r04a_probe_new.json: 13.5 vs 16.6 us per step
+constexpr int DUO_MIN_DEPTH = 1;     // with one group in flight, 17.9 vs 21.7 with two, 26.2 vs 36 with four; round 3's kernel paid off from depth 3 on)
 
 // what a call will run: kernel, split, rounds, slab length
 struct Plan {
@@ -446,7 +446,11 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
         }
         if (shape_ok && ncl >= 1) {
             if (o->clusters == 1 || o->clusters == 2 || o->clusters == 4) ncl = o->clusters < ncl ? o->clusters : ncl;
-            else if (groups < ncl) { int c2 = 1; while (c2 < groups) c2 *= 2; if (c2 < ncl) ncl = c2; }   // no more clusters than groups (rounded up to 1, 2, 4)
+            else if (groups < ncl && !(p->mode == WRNN_MODE_MOL && DUO_AUTO && algo != WRNN_ALGO_LOOP && ncl == MAXCL)) {
+                // no more clusters than groups (rounded up to 1, 2, 4).  Not for the duo kernel: its grid is always 4 clusters (a cluster
+                // without a group leaves at once), so that a small batch sits on whole XCDs exactly as a large one does
+                int c2 = 1; while (c2 < groups) c2 *= 2; if (c2 < ncl) ncl = c2;
+            }
             const int gmax = loop_max_depth(p->mode);
             int g = o->depth;
             if (g < 1 || g > gmax) {

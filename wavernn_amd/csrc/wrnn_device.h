@@ -84,6 +84,7 @@ struct LoopArgs {
     unsigned hop_magic;                 // p / hop == __umulhi(p, hop_magic) >> hop_shift for 0 <= p < 2^31 (0: divide)
     int hop_shift;
     unsigned *xcc_tab;                  // [MAXCL * 128] zeroed before every launch: XCC id + 1 of every workgroup (placement handshake)
+    int place;                          // wrnn_duo.hip: 0 = a layer per XCD (rnn1 | rnn2), 1 = a slot's chain per XCD (ih workgroups | hh workgroups)
     int kind_tag;                       // 1 wrnn_loop_kernel, 2 wrnn_duo_kernel: recorded in status[8] by the launch that starts a call at step 0,
                                         // checked by every continuing launch (the two kernels keep different state / ring layouts)
 };

@@ -94,12 +94,9 @@ __device__ __forceinline__ void mfma3s(const float (&a0)[AF], const float (&a1)[
     o0 = c0; o1 = c1; o2 = c2;
 }
 
-// one fc3 tile with the A fragments read from global memory (L2-resident, fragment order), B in registers; mfma_tile's order
-__device__ __forceinline__ f32x4 mfma1_glb(const float *a_lane /* tile + frag_off(w, 0, lane) */, const float (&b)[32])
+// one fc3 tile with the A fragments already loaded (fragment order), B in registers; mfma_tile's order
+__device__ __forceinline__ f32x4 mfma1_frag(const float4 (&av)[8], const float (&b)[32])
 {
-    float4 av[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) av[r] = *reinterpret_cast<const float4 *>(a_lane + 256 * r);
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
 #pragma unroll
     for (int r = 0; r < 8; r += 2) {
@@ -200,7 +197,7 @@ struct DuoGeo {
 // wait / poll, 4 ring hygiene, 5 MFMA tiles + partial writes, 6 stages, 7 stages whose operand was not there at the first look
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <bool LA, bool PF, bool PROF>
-__device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int cl, const int J, const int ncl, const bool loc_h, const bool loc_y)
+__device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int cl, const int J, const int ncl, const bool loc_h, const bool loc_x, const bool loc_y)
 {
     const int G = a.G;
     const DuoLds L = duo_lds(G);
@@ -216,6 +213,13 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
     const int prow = LU * J + pu;
     const int T0 = a.t0, T1 = a.t1;
     const int NR = a.Btot, NGR = a.NG;
+    // (everything the stage lambdas need of the launch arguments as local values: they must not hold a reference to the argument
+    // struct -- with one the compiler was seen to copy the whole struct to scratch and read every field from there)
+    unsigned *const status = a.status;
+    float *const state = a.state;
+    u64 *const profp = a.prof;
+    const float *const bhhp = LA ? a.b_hh1 : a.b_hh2;
+    const int resume = a.resume, hop = a.hop, NF = a.NF, cI_t0 = a.cI_t0;
     constexpr int L_H = LA ? 0 : 1, L_XR = LA ? 5 : 6, L_Y = LA ? 2 : 3, L_GH = LA ? 8 : 12;       // layers this role publishes / reads gh from
     constexpr int L_P0 = 5, L_P2 = LA ? 6 : 2;                                                     // layers its stages poll (rnn1's gates: the slab)
 
@@ -269,6 +273,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
     const unsigned magic = a.hop_magic;
     const int mshift = a.hop_shift;
 
+    const int locbits = (loc_h ? 1 : 0) | (loc_y ? 2 : 0) | (loc_x ? 4 : 0);       // by re-arm lane group: h | y | residual sum
     bool dead = false;
     int pp = 0;
     int t = T0;
@@ -305,14 +310,13 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             if (__builtin_expect(__any(live && g.w != tag), 0))
                 wait_for([&] { return !__any(live && g.w != tag); },
                          [&] { g = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, sb + (L_GH + (J >> 3)) * DLAYERB, 16 /* sc1 */); },
-                         a.status, dead, 0x500u | (LA ? 0u : 8u) | 6u, bt);
+                         status, dead, 0x500u | (LA ? 0u : 8u) | 6u, bt);
             ghr = __uint_as_float(g.x); ghz = __uint_as_float(g.y); ghn = __uint_as_float(g.z);
-        } else if (a.resume) {                          // first step of a continuing launch: gh(t0), saved by the launch that ended there
-            const float *sg = a.state + state_wg + (size_t)bi * LGRP;
+        } else if (resume) {                          // first step of a continuing launch: gh(t0), saved by the launch that ended there
+            const float *sg = state + state_wg + (size_t)bi * LGRP;
             ghr = sg[tid]; ghz = sg[256 + tid]; ghn = sg[512 + tid];
         } else {                                        // t = 0: gh = W_hh . 0 + b_hh = b_hh
-            const float *bhh = LA ? a.b_hh1 : a.b_hh2;
-            ghr = bhh[prow]; ghz = bhh[H + prow]; ghn = bhh[2 * H + prow];
+            ghr = bhhp[prow]; ghz = bhhp[H + prow]; ghn = bhhp[2 * H + prow];
         }
         float gir, giz, gin, xin;
         if constexpr (LA) {
@@ -322,7 +326,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
                 if (__builtin_expect(__any(live && xw == SENT), 0))
                     wait_for([&] { return !__any(live && xw == SENT); },
                              [&] { xw = __builtin_amdgcn_raw_buffer_load_b32(xrs, pj * 4, cbase + bi * (MAXCL * DSLOTB) + 7 * DLAYERB + ((bt - 1) & (DRING - 1)) * XTB, 16 /* sc1 */); },
-                             a.status, dead, 0x520u, bt);
+                             status, dead, 0x520u, bt);
                 xv = __uint_as_float(xw);
             } else xv = XS[bi * 16 + pj];
             gir = pr + fmaf(xv, ux_r, cb_r); giz = pz + fmaf(xv, ux_z, cb_z); gin = pn + fmaf(xv, ux_n, cb_n);
@@ -332,14 +336,14 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             if (__builtin_expect(__any(live && xw == SENT), 0))
                 wait_for([&] { return !__any(live && xw == SENT); },
                          [&] { xw = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, sb + L_P0 * DLAYERB, 16 /* sc1 */); },
-                         a.status, dead, 0x528u, bt);
+                         status, dead, 0x528u, bt);
             gir = pr + c.c0; giz = pz + c.c1; gin = pn + c.c2;
             xin = __uint_as_float(xw);
         }
         const float hn = gru_update_fast(gir, giz, gin, ghr, ghz, ghn, hprev);
         HS[bi * 256 + tid] = hn;
         publish4l(xrs, sb + L_H * DLAYERB + J * 1024, tid, hn, live, loc_h);
-        publish4l(xrs, sb + L_XR * DLAYERB + J * 1024, tid, xin + hn, live, false);        // x1 = xi + h1 (:212) / x2 = x1 + h2 (:216)
+        publish4l(xrs, sb + L_XR * DLAYERB + J * 1024, tid, xin + hn, live, loc_x);        // x1 = xi + h1 (:212) / x2 = x1 + h2 (:216)
         PHX(cur + 2);
     };
     // ---------------- back half of an fc stage: fc1 / fc2 + relu -> publish y1 / y2
@@ -348,7 +352,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         const int sb = cbase + c.i * (MAXCL * DSLOTB) + (c.t & (DRING - 1)) * XTB;
         lds_barrier();
         PHX(cur + 1);
-        publish4l(xrs, sb + L_Y * DLAYERB + J * 1024, tid, fmaxf(get_partial<3>(PB, 0, pu, pj) + c.c0, 0.f), pj < slot_nb(c.i), LA ? false : loc_y);
+        publish4l(xrs, sb + L_Y * DLAYERB + J * 1024, tid, fmaxf(get_partial<3>(PB, 0, pu, pj) + c.c0, 0.f), pj < slot_nb(c.i), loc_y);
         PHX(cur + 2);
     };
 
@@ -376,7 +380,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         int soff_x;                                     // where the operand fragments come from (for the re-load of a poll)
         if constexpr (ph == 0) {
             if constexpr (LA) {
-                soff_x = ((t - a.cI_t0) * NGR + g) * XTB;                       // conditioning slab cI(t) of the group: plain data
+                soff_x = ((t - cI_t0) * NGR + g) * XTB;                       // conditioning slab cI(t) of the group: plain data
 #pragma unroll
                 for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(crs, voff_frag + r * 1024, soff_x, 0);
                 nc.xo = __builtin_amdgcn_raw_buffer_load_b32(crs, voff_own, soff_x, 0);
@@ -386,7 +390,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
 #pragma unroll
                 for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
                 nc.xo = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, soff_x, 16 /* sc1 */);
-                const int fr = frame_of(SEGT[i * 32 + pj] + t, SEGT[i * 32 + SEG + pj], magic, mshift, a.hop, a.NF);
+                const int fr = frame_of(SEGT[i * 32 + pj] + t, SEGT[i * 32 + SEG + pj], magic, mshift, hop, NF);
                 const int vo = (fr * 3 * H + prow) * 4;
                 nc.c0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, 0, 0));
                 nc.c1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, H * 4, 0));
@@ -397,7 +401,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             soff_x = sb + L_P2 * DLAYERB;
 #pragma unroll
             for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
-            const int fr = frame_of(SEGT[i * 32 + pj] + t, SEGT[i * 32 + SEG + pj], magic, mshift, a.hop, a.NF);
+            const int fr = frame_of(SEGT[i * 32 + pj] + t, SEGT[i * 32 + SEG + pj], magic, mshift, hop, NF);
             nc.c0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(frs, (fr * H + prow) * 4, 0, 0));
         }
         PHX(cur + 0);
@@ -416,7 +420,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
 #pragma unroll
                              for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
                          },
-                         a.status, dead, 0x500u | (LA ? 0u : 8u) | (unsigned)ph, t);
+                         status, dead, 0x500u | (LA ? 0u : 8u) | (unsigned)ph, t);
         }
         PHX(cur + 3);
         if (ph == 2 && i == nact - 1) {
@@ -425,7 +429,8 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int which = lane >> 4;
             const int layer = which == 0 ? L_H : (which == 1 ? L_Y : L_XR);
-            const bool lloc = which == 0 ? loc_h : (which == 1 ? (LA ? false : loc_y) : false);
+            const bool lloc = ((locbits >> which) & 1) != 0;          // (NOT a select between the captured flags: a select of pointers to
+                                                                      // captured locals keeps the whole closure -- every local -- in scratch)
             const int vo = layer * DLAYERB + J * 1024 + w * 256 + (lane & 15) * 16;
             const int so = cbase + ((t + DAHEAD) & (DRING - 1)) * XTB;
             const u32x4 q = {SENT, SENT, SENT, SENT};
@@ -487,8 +492,8 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         u32x4 gq = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, so, 16 /* sc1 */);
         const unsigned tag = (unsigned)T1 + 1u;
         wait_for([&] { return !__any(live && gq.w != tag); },
-                 [&] { gq = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, so, 16 /* sc1 */); }, a.status, dead, 0x521u, T1);
-        float *sg = a.state + state_wg + (size_t)i * LGRP;
+                 [&] { gq = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, so, 16 /* sc1 */); }, status, dead, 0x521u, T1);
+        float *sg = state + state_wg + (size_t)i * LGRP;
         sg[tid] = __uint_as_float(gq.x); sg[256 + tid] = __uint_as_float(gq.y); sg[512 + tid] = __uint_as_float(gq.z);
         sg[O_HOWN + tid] = HS[i * 256 + tid];
         if (tid < 2 * SEG) reinterpret_cast<int *>(sg + O_SP)[tid] = SEGT[i * 32 + tid];
@@ -496,12 +501,12 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             const int sx = sbase + 7 * DLAYERB + ((T1 - 1) & (DRING - 1)) * XTB;
             unsigned v = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, sx, 16 /* sc1 */);
             wait_for([&] { return !__any(fi < nb && v == SENT); },
-                     [&] { v = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, sx, 16 /* sc1 */); }, a.status, dead, 0x522u, T1);
+                     [&] { v = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, sx, 16 /* sc1 */); }, status, dead, 0x522u, T1);
             if (tid < SEG) sg[O_XS + tid] = (tid < nb) ? __uint_as_float(v) : 0.f;
         }
     }
-    if (PROF && tid == 0 && a.prof) {
-        for (int k = 0; k < 16; ++k) a.prof[(size_t)(blockIdx.x & 255) * 32 + k] += PROFL[k];
+    if (PROF && tid == 0 && profp) {
+        for (int k = 0; k < 16; ++k) profp[(size_t)(blockIdx.x & 255) * 32 + k] += PROFL[k];
     }
 }
 
@@ -527,6 +532,11 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     const int prow = LU * J + pu;
     const int T0 = a.t0, T1 = a.t1, C = a.C;
     const int NR = a.Btot, Nall = a.Nall, NGR = a.NG;
+    unsigned *const status = a.status;                  // (local values for the stage lambdas: see duo_ih)
+    u64 *const profp = a.prof;
+    float *const outp = a.out, *const dbgl = a.dbg_logits;
+    const float *const forcex = a.force_x, *const noise_pre = a.noise_pre, *const fc3f = a.fc3f;
+    const int Tall = a.T, noise_t0 = a.noise_t0;
     constexpr int L_H = LA ? 0 : 1, L_GH = LA ? 8 : 12;
 
     float A_hh[3][AF];
@@ -598,10 +608,10 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             const float lg = get_partial<3>(PB, 0, pu, pj) + b3a;
             const float lg2 = get_partial<3>(PB, 1, pu, pj) + b3b;
             LOG[pj * DLOGS + pu] = lg;
-            if (a.dbg_logits && pj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + pj) * C + pu] = lg;
+            if (dbgl && pj < nb) dbgl[((size_t)bt * Nall + b0 + pj) * C + pu] = lg;
             if (pu < 14) {
                 LOG[pj * DLOGS + 16 + pu] = lg2;
-                if (a.dbg_logits && pj < nb) a.dbg_logits[((size_t)bt * Nall + b0 + pj) * C + 16 + pu] = lg2;
+                if (dbgl && pj < nb) dbgl[((size_t)bt * Nall + b0 + pj) * C + 16 + pu] = lg2;
             }
         }
         lds_barrier();
@@ -612,8 +622,8 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             argmax_row16(best, bidx);
             if (sm == 0 && su < nb) {
                 float xv = mol_sample_pre(LOG[su * DLOGS + 10 + bidx], LOG[su * DLOGS + 20 + bidx], c.c1);
-                a.out[(size_t)(b0 + su) * a.T + bt] = xv;
-                if (a.force_x) xv = a.force_x[(size_t)(b0 + su) * a.T + bt];
+                outp[(size_t)(b0 + su) * Tall + bt] = xv;
+                if (forcex) xv = forcex[(size_t)(b0 + su) * Tall + bt];
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xv), xrs, su * 4, cbase + bi * (MAXCL * DSLOTB) + 7 * DLAYERB + (bt & (DRING - 1)) * XTB, 16 /* sc1 */);
             }
         }
@@ -651,13 +661,19 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             // this step's sampling noise, pre-transformed (wrnn_noise_mol_kernel): thread (segment tid >> 4, mixture tid & 15)
             const int b0 = GEO[2 * i];
             const int su = tid >> 4, sm = tid & 15;
-            const float *nrow = a.noise_pre + (size_t)(t - a.noise_t0) * 11 * Nall;
+            const float *nrow = noise_pre + (size_t)(t - noise_t0) * 11 * Nall;
             const int suc = su < nb ? su : nb - 1;
             nc.c0 = nrow[(size_t)(b0 + suc) * 10 + (sm < 10 ? sm : 9)];
             nc.c1 = nrow[(size_t)10 * Nall + b0 + suc];
         }
         PHX(cur + 0);
         if constexpr (!PF) run_back();
+        float4 av0[8] = {};                             // fc3 A fragments (L2-resident), tile 0: requested now, under the wait for y2
+        if constexpr (kind == 3) {
+            const float4 *fp = reinterpret_cast<const float4 *>(fc3f + frag_off(w, 0, lane));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) av0[r] = fp[64 * r];
+        }
         {
             const bool live = fi < nb;
             const bool there = frag_there(x, live);
@@ -668,7 +684,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
 #pragma unroll
                              for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
                          },
-                         a.status, dead, 0x600u | (LA ? 0u : 8u) | (unsigned)kind, t);
+                         status, dead, 0x600u | (LA ? 0u : 8u) | (unsigned)kind, t);
         }
         PHX(cur + 3);
         if (sampler && kind == 3) {
@@ -705,8 +721,16 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             put_partial<3>(PW, w, 2, lane, o2);
             pend = BK_GH;
         } else {
-            put_partial<3>(PW, w, 0, lane, mfma1_glb(a.fc3f + frag_off(w, 0, lane), b));
-            put_partial<3>(PW, w, 1, lane, mfma1_glb(a.fc3f + XT + frag_off(w, 0, lane), b));
+            {   // tile 1: in flight under tile 0's MFMAs, in the registers of the (now idle) look-ahead fragments
+                const u32x4 *fp = reinterpret_cast<const u32x4 *>(fc3f + XT + frag_off(w, 0, lane));
+#pragma unroll
+                for (int r = 0; r < 8; ++r) x[r] = fp[64 * r];
+            }
+            put_partial<3>(PW, w, 0, lane, mfma1_frag(av0, b));
+            float4 av1[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) av1[r] = make_float4(__uint_as_float(x[r].x), __uint_as_float(x[r].y), __uint_as_float(x[r].z), __uint_as_float(x[r].w));
+            put_partial<3>(PW, w, 1, lane, mfma1_frag(av1, b));
             pend = BK_SAMPLE;
         }
         PHX(cur + 5);
@@ -729,8 +753,8 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     cur = 0;
     if (pend == BK_GH) back_gh(cy);
     else if (pend == BK_SAMPLE) { if constexpr (!LA) back_sample(cy); }
-    if (PROF && tid == 0 && a.prof) {
-        for (int k = 0; k < 16; ++k) a.prof[(size_t)(blockIdx.x & 255) * 32 + 16 + k] += PROFL[k];
+    if (PROF && tid == 0 && profp) {
+        for (int k = 0; k < 16; ++k) profp[(size_t)(blockIdx.x & 255) * 32 + 16 + k] += PROFL[k];
     }
 }
 #undef DPARTOF
@@ -757,13 +781,22 @@ __global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
             wg = b % DNWGC;
         }
     }
+    if (cl >= a.NG) return;                             // a cluster without a group of this round (the grid is always 4 clusters: see launch_duo)
     // role / unit block of workgroup wg.  Speed only: block b is observed to run on XCD b % 8 and the blocks of an XCD to be dealt
-    // round-robin over its 32 CUs, i.e. (with 64 blocks per XCD) local blocks q and q + 32 share a CU.  First half of a cluster's
-    // blocks (one XCD when a cluster spans two): rnn1, second half: rnn2; within a half q < 32: the ih workgroup of unit block q,
-    // q >= 32: the hh workgroup of unit block q - 32 -- so a CU carries the ih (128 MFMAs per group-step and wave) and the hh
-    // workgroup (96) of the same units, and h / gh / (rnn2) y2 never leave the XCD.
-    const int layer = wg / (DNWGC / 2), q = wg % (DNWGC / 2);
-    const int hh = q >> 5, J = q & 31;
+    // round-robin over its 32 CUs, i.e. (with 64 blocks per XCD) local blocks q and q + 32 share a CU; with 4 clusters a cluster is two
+    // XCDs = the two halves of its 128 blocks.  Two placements (LoopArgs.place):
+    //   0 "layer per XCD" (deep pipelines): first half rnn1, second half rnn2; within a half q < 32: the ih workgroup of unit block q,
+    //     q >= 32: the hh workgroup of unit block q - 32.  A CU carries the ih (128 MFMAs per group-step and wave) and the hh workgroup
+    //     (96) of the same units; h, gh and (rnn2) y2 never leave the XCD: least fabric traffic, best MFMA balance.
+    //   1 "chain per XCD" (shallow pipelines, where the latency of a slot's chain bounds a step): first half all 64 ih workgroups (q < 32:
+    //     rnn1's, q >= 32: rnn2's), second half all hh workgroups.  Three of the five hops of a slot's chain (x1, x2, y1) stay in one L2.
+    int layer, hh, J;
+    {
+        const int half = wg / (DNWGC / 2), q = wg % (DNWGC / 2);
+        if (a.place == 0) { layer = half; hh = q >> 5; }
+        else { hh = half; layer = q >> 5; }
+        J = q & 31;
+    }
     // ---- placement handshake: every workgroup records its XCC id; a layer whose producers and consumers all sit on one XCD is
     //      exchanged through that XCD's L2 with plain stores.  Every workgroup of a cluster reads the same 128 words -> the same verdict.
     bool loc_a = false, loc_b = false;
@@ -797,12 +830,17 @@ __global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
         if (a.tuning & 256) { loc_a = false; loc_b = false; }        // A/B: everything written through, as round 3
         __syncthreads();
     }
+    // which layers stay inside one XCD (loc_a / loc_b: every workgroup of the first / second half of the cluster was seen on one XCC)
+    const bool p0 = a.place == 0;
+    const bool loc_h1 = p0 && loc_a, loc_h2 = p0 && loc_b;           // h, gh: ih <-> hh workgroups of a layer
+    const bool loc_x = !p0 && loc_a;                                 // x1, x2, y1: among the ih workgroups
+    const bool loc_y2 = p0 && loc_b;                                 // y2: rnn2's ih workgroups -> the sampling (rnn2 hh) workgroups
     if (layer == 0) {
-        if (hh == 0) duo_ih<true, PF, PROF>(a, smem, cl, J, ncl, loc_a, false);
-        else duo_hh<true, PF, PROF>(a, smem, cl, J, ncl, loc_a);
+        if (hh == 0) duo_ih<true, PF, PROF>(a, smem, cl, J, ncl, loc_h1, loc_x, loc_x);
+        else duo_hh<true, PF, PROF>(a, smem, cl, J, ncl, loc_h1);
     } else {
-        if (hh == 0) duo_ih<false, PF, PROF>(a, smem, cl, J, ncl, loc_b, loc_b);
-        else duo_hh<false, PF, PROF>(a, smem, cl, J, ncl, loc_b);
+        if (hh == 0) duo_ih<false, PF, PROF>(a, smem, cl, J, ncl, loc_h2, loc_x, loc_y2);
+        else duo_hh<false, PF, PROF>(a, smem, cl, J, ncl, loc_h2);
     }
 }
 
@@ -820,21 +858,24 @@ int duo_clusters(int n_cus)
     return ncl;
 }
 
-// publish_first: < 0 = by depth (DUO_PUBFIRST_DEPTH), 0 / 1 = forced
-constexpr int DUO_PUBFIRST_DEPTH = 4;
+// Measured defaults (profiles/r04a_probe_new.json, r04b_*): loads-first stage order up to 7 groups in flight, publish-first at 8;
+// the chain-per-XCD placement up to DUO_CHAIN_DEPTH groups in flight, a layer per XCD above.
+constexpr int DUO_PUBFIRST_DEPTH = 8;
+constexpr int DUO_CHAIN_DEPTH = 2;
 hipError_t launch_duo(const LoopArgs &args, int ncl, hipStream_t stream)
 {
     if (ncl < 1 || args.G < 1 || args.G > LMAXG || !args.fc3f || !args.u1 || !args.xcc_tab) return hipErrorInvalidValue;
     const size_t lds = duo_lds_bytes(args.G);
-    // stage order: tuning bit 0 = loads first, bit 1 = publish first (default: publish first up to DUO_PUBFIRST_DEPTH groups in flight)
-    const bool pf = (args.tuning & 2) ? true : ((args.tuning & 1) ? false : args.G <= DUO_PUBFIRST_DEPTH);
-    // phase clocks (wrnn_options.phase_clocks) unless tuning bit 6 asks for the placement read-out through the same buffer
+    // wrnn_options.tuning (A/B switches): bit 0 = loads first, bit 1 = publish first; bit 3 = a layer per XCD, bit 4 = a chain per XCD;
+    // bit 8 = every layer written through (no XCD-local plain stores); bit 6 = placement read-out through the phase-clock buffer
+    const bool pf = (args.tuning & 2) ? true : ((args.tuning & 1) ? false : args.G >= DUO_PUBFIRST_DEPTH);
+    LoopArgs a = args;
+    a.place = (args.tuning & 16) ? 1 : ((args.tuning & 8) ? 0 : (args.G <= DUO_CHAIN_DEPTH ? 1 : 0));
     const bool prof = args.prof && !(args.tuning & 64);
     const void *fn = pf ? (prof ? (const void *)wrnn_duo_kernel<true, true> : (const void *)wrnn_duo_kernel<true, false>)
                         : (prof ? (const void *)wrnn_duo_kernel<false, true> : (const void *)wrnn_duo_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    LoopArgs a = args;
     void *params[] = {(void *)&a};
     return hipLaunchCooperativeKernel(fn, dim3(ncl * DNWGC), dim3(NT), params, (unsigned)lds, stream);
 }
