@@ -668,12 +668,6 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         }
         PHX(cur + 0);
         if constexpr (!PF) run_back();
-        float4 av0[8] = {};                             // fc3 A fragments (L2-resident), tile 0: requested now, under the wait for y2
-        if constexpr (kind == 3) {
-            const float4 *fp = reinterpret_cast<const float4 *>(fc3f + frag_off(w, 0, lane));
-#pragma unroll
-            for (int r = 0; r < 8; ++r) av0[r] = fp[64 * r];
-        }
         {
             const bool live = fi < nb;
             const bool there = frag_there(x, live);
@@ -721,6 +715,14 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             put_partial<3>(PW, w, 2, lane, o2);
             pend = BK_GH;
         } else {
+            // fc3 A fragments (L2-resident, fragment order).  (Requesting tile 0 before the wait for y2 would take its L2 latency off the
+            // slot's chain, but costs 5 VGPR spills in this role: not done.)
+            float4 av0[8];
+            {
+                const float4 *fp0 = reinterpret_cast<const float4 *>(fc3f + frag_off(w, 0, lane));
+#pragma unroll
+                for (int r = 0; r < 8; ++r) av0[r] = fp0[64 * r];
+            }
             {   // tile 1: in flight under tile 0's MFMAs, in the registers of the (now idle) look-ahead fragments
                 const u32x4 *fp = reinterpret_cast<const u32x4 *>(fc3f + XT + frag_off(w, 0, lane));
 #pragma unroll
