@@ -81,6 +81,12 @@ VARIANTS = {
     'duo-g2-slabs': dict(algo='duo', depth=2, slab_steps=97),
     'duo-c1-g3': dict(algo='duo', clusters=1, depth=3, slab_steps=160),
     'duo-c2-g2': dict(algo='duo', clusters=2, depth=2),
+    # round 4: both placements (tuning bit 3: a layer per XCD, bit 4: a slot's chain per XCD) x both stage orders (bit 0: loads first,
+    # bit 1: publish first), and every layer written through (bit 8) -- speed switches, results must not depend on them
+    'duo-g2-p0-pf': dict(algo='duo', depth=2, tuning=8 | 2),
+    'duo-g2-p1-lf': dict(algo='duo', depth=2, tuning=16 | 1),
+    'duo-g3-p1-pf-slabs': dict(algo='duo', depth=3, tuning=16 | 2, slab_steps=131),
+    'duo-g1-p0-wt': dict(algo='duo', depth=1, tuning=8 | 256),
 }
 KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'loop': 'wrnn_loop_kernel', 'sparse': 'wrnn_sparse_kernel', 'duo': 'wrnn_duo_kernel'}
 
@@ -159,6 +165,30 @@ def test_step_ranges_continue_bit_exactly(gpu, mode, algo):
     assert np.array_equal(out.cpu().numpy(), whole)
     with pytest.raises(Exception):
         eng.run(mu, au, B, T, stride, nz[:10].contiguous(), 275, algo='stream', t_range=(0, 10))
+
+
+def test_continuation_on_the_other_loop_kernel_fails_loudly(gpu):
+    """Round-3 advisor: `auto` may fall back from wrnn_duo_kernel to wrnn_loop_kernel on ONE slice of a step-sliced run (cooperative
+    launch refused); the two kernels keep different state / ring layouts, so a continuation planned onto the other kernel must not
+    resume from foreign state.  The launch that starts a call records its kernel in status word 8; a continuing launch of the other
+    kernel raises the abort flag (code 0x7F0 | kind) and `wrnn_status` reports it.  Forced here by switching `algo` between slices;
+    `LoopEngine` itself pins `auto` continuations to the first slice's kernel (second half of the test)."""
+    from wavernn_amd import _lib
+    from wavernn_amd.engine import LoopEngine
+    cfg = dict(mode='MOL', wseed=38, mseed=138, frames=60, batched=True, target=550, overlap=55, seed=98)
+    sd, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
+    eng = LoopEngine(sd, 'MOL', device=gpu)
+    mu, au, nz = torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), torch.from_numpy(flat).to(gpu)
+    whole = eng.run(mu, au, B, T, stride, nz, 275, algo='duo').cpu().numpy()          # (also sizes the workspace for the larger layout)
+    out = eng.run(mu, au, B, T, stride, nz[:100].contiguous(), 275, algo='loop', t_range=(0, 100))
+    with pytest.raises(_lib.WrnnError, match='0x7f2'):
+        eng.run(mu, au, B, T, stride, nz[100:].contiguous(), 275, algo='duo', t_range=(100, T), out=out)
+    # `auto`: the continuation is pinned to the kernel the first slice ran on, whatever a fresh plan would pick
+    out = eng.run(mu, au, B, T, stride, nz[:100].contiguous(), 275, algo='auto', t_range=(0, 100))
+    first = eng.last_loop_kernel()
+    out = eng.run(mu, au, B, T, stride, nz[100:].contiguous(), 275, algo='auto', t_range=(100, T), out=out)
+    assert eng.last_loop_kernel() == first == 'wrnn_duo_kernel'
+    assert np.array_equal(out.cpu().numpy(), whole)
 
 
 def test_workspace_does_not_grow_with_steps(gpu):
@@ -323,7 +353,7 @@ def test_generate_end_to_end(gpu, name, pre, tmp_path):
 
 
 @pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'loop-c2-g2', 'loop-c1-g3-nofuse', 'duo', 'duo-g1', 'duo-g2-slabs',
-                                     'duo-c1-g3', 'duo-c2-g2'])
+                                     'duo-c1-g3', 'duo-c2-g2', 'duo-g2-p0-pf', 'duo-g2-p1-lf', 'duo-g3-p1-pf-slabs', 'duo-g1-p0-wt'])
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_many_segments_all_clusters(gpu, mode, variant):
     """46 folded segments (the last one zero-padded) = 3 groups: one per cluster, all three in flight on one cluster, two
