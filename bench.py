@@ -282,6 +282,10 @@ def main():
     par = (f'{world_seen} rank(s) in the process group ({"gloo, DRY RUN on the host" if dry else "nccl = RCCL" if group is not None else "no group"}): '
            f'1 process per GPU, contiguous block of the segment table, ONE all-gather of the finished audio')
     if dry:
+        # order check of the launch path: the gathered [n_segments, T] table, weighted by row, against what ONE rank computes
+        segs, _ = generate_corpus(model, mels, target, overlap, True, seeds, group=group, noise_source=noise_source, loop_fn=loop_fn,
+                                  return_segments=True)
+        checksum = float((segs[:, 0] * (1.0 + np.arange(segs.shape[0]))).sum())
         if rank == 0:
             print(json.dumps({
                 'metric': 'audio samples/sec (real-time factor @22.05 kHz), MoL WaveRNN batched generate', 'value': None,
@@ -291,7 +295,9 @@ def main():
                 'data': 'synthetic', 'dry_host': True,
                 'config': {'workload': f'DRY RUN of the launch path on the host, NOT a measurement: {n_utt} utterances -> '
                                        f'{plan.n_segments} segments x T={plan.T}, loop stand-in {args.dry_host}',
-                           'segments_rank0': hi0 - lo0, 'host_samples_per_s': round(args.steps * wave_total / dt, 1),
+                           'segments_rank0': hi0 - lo0, 'segments_per_rank': [h - l for l, h in shard_bounds(plan.n_segments, world)],
+                           'gathered_rows': int(segs.shape[0]), 'gathered_checksum': checksum,
+                           'host_samples_per_s': round(args.steps * wave_total / dt, 1),
                            'parallelism': par}}), flush=True)
         if group is not None:
             dist.destroy_process_group()

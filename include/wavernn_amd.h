@@ -52,7 +52,8 @@ enum {
                                tag-free activation exchange in MFMA-fragment order (csrc/wrnn_loop.hip) */
     WRNN_ALGO_DUO = 6,      /* the loop kernel cut for TWO workgroups per CU (MOL): four roles -- rnn1 / rnn2 x {W_ih + fc, W_hh [+ fc3 and
                                sampling]} -- of <= 128 weight registers, 128 workgroups per 64-CU cluster, so that one wave's MFMAs overlap
-                               the other's loads, pointwise math and barrier waits (csrc/wrnn_duo.hip); for >= 2 groups in flight */
+                               the other's loads, pointwise math and barrier waits (csrc/wrnn_duo.hip).  Round 4: what `auto` runs for
+                               MOL at every depth */
     WRNN_ALGO_SPARSE = 5    /* block-sparse GRU kernel (MOL; BASELINE config 5): needs GRU matrices whose 16x1 block rows
                                keep <= 64 columns (wrnn_pack_sparse_blocks); 8 XCD-local clusters x 2 groups in flight */
 };
@@ -64,11 +65,11 @@ enum {
  * All pointers are HOST pointers to contiguous row-major float32.
  */
 typedef struct wrnn_weights {
-    int32_t rnn_dims;    /* H: must be 512 in this build */
-    int32_t fc_dims;     /* F: must be 512 in this build */
-    int32_t feat_dims;   /* M: 80 */
-    int32_t aux_dims;    /* A: 32 */
-    int32_t n_classes;   /* C: 30 (MOL) or 2**bits (RAW); RAW needs C <= 512 and C % 64 == 0 */
+    int32_t rnn_dims;    /* H: 512 for the MFMA kernels (loop / duo / sparse / stream); any other value <= 2048 runs on wrnn_generic_kernel */
+    int32_t fc_dims;     /* F: 512 for the MFMA kernels; <= 2048 otherwise */
+    int32_t feat_dims;   /* M: 80 for the MFMA kernels; feat + aux <= 1024 otherwise */
+    int32_t aux_dims;    /* A: 32 for the MFMA kernels */
+    int32_t n_classes;   /* C: 30 (MOL) or 2**bits (RAW); shipped dims: RAW 2..512 classes (the loop kernel needs 512, others stream) */
     int32_t mode;        /* WRNN_MODE_* */
     const float *I_w, *I_b;                          /* I.weight (H,1+M+A), I.bias (H) */
     const float *w_ih1, *w_hh1, *b_ih1, *b_hh1;      /* rnn1.weight_ih_l0 (3H,H), weight_hh_l0 (3H,H), biases (3H) */
@@ -102,7 +103,7 @@ typedef struct wrnn_timer wrnn_timer;
 
 /* What a wrnn_generate* call decided (filled synchronously, before the call returns). */
 typedef struct wrnn_run_info {
-    const char *kernel;      /* "wrnn_duo_kernel" / "wrnn_loop_kernel" / "wrnn_sparse_kernel" / "wrnn_stream_kernel" */
+    const char *kernel;      /* "wrnn_duo_kernel" / "wrnn_loop_kernel" / "wrnn_sparse_kernel" / "wrnn_stream_kernel" / "wrnn_generic_kernel" */
     int32_t units_per_wg;    /* hidden units per workgroup (16; stream: 0) */
     int32_t clusters;        /* independent CU clusters, each holding one copy of the weights */
     int32_t depth;           /* groups of <= 16 segments in flight per cluster */
@@ -125,11 +126,15 @@ typedef struct wrnn_options {
     int32_t t_begin, t_end;  /* run steps [t_begin, t_end) of the T; 0,0 = all.  t_begin > 0 CONTINUES the call that ended at
                                 t_begin on the same workspace (loop kernel only); `noise` then covers [t_begin, t_end) only,
                                 `out` / force_x / logits always the whole [.., T] tensors */
-    int32_t tuning;          /* loop kernel A/B switches for measurements: bit 0 = no one-stage look-ahead of the exchange loads,
-                                bit 1 = full __syncthreads() fences at the stage barriers (default 0 = the fast forms); bit 2 (duo
-                                kernel) = re-fill the exchange ring with the sentinel before EVERY launch, not only where a round starts;
-                                loop kernel: bit 5 / bit 6 = never / always start a stage with the pending back half (default: up to 2
-                                groups in flight), bit 7 = library exp / tanh in the MoL gate math (default: hardware exp / rcp) */
+    int32_t tuning;          /* A/B switches for measurements, PER KERNEL (0 = the measured defaults; results never depend on them):
+                                wrnn_loop_kernel: bit 0 = no one-stage look-ahead of the exchange loads, bit 1 = full __syncthreads() fences
+                                  at the stage barriers, bit 2 = no fused stages, bit 3 = RAW sampled by role A alone, bit 4 = RAW: one
+                                  sampling workgroup per slot, bit 5 / bit 6 = never / always start a stage with the pending back half
+                                  (default: up to 2 groups in flight), bit 7 = library exp / tanh in the MoL gate math;
+                                wrnn_duo_kernel: bit 0 = stage order loads-first, bit 1 = publish-first (default: by depth), bit 2 = re-fill the
+                                  exchange ring with the sentinel before EVERY launch, bit 6 = placement read-out through phase_clocks (test
+                                  hook), bit 8 = every layer written through (no XCD-local plain stores).
+                                The `auto` fallback from wrnn_duo_kernel to wrnn_loop_kernel (cooperative grid refused) clears the field. */
     const float *force_x;    /* test hook, device [n,T]: value fed back as x_t instead of the sample (teacher forcing) */
     float *logits;           /* test hook, device [T,n,C]: fc3 output of every step (:223) */
     unsigned long long *phase_clocks; /* profiling hook, device [256 workgroups][32] zeroed by the caller: the loop kernel (MOL) adds
@@ -271,8 +276,8 @@ int wrnn_post_unfold(const float *segments, int32_t T, int32_t n_utt, const int3
 const char *wrnn_post_last_error(void);
 
 /*
- * DRAFT (never run on a GPU) -- BASELINE config 3's caller: the Tacotron decoder loop as one persistent kernel (SURVEY.md
- * section 8 row f3).  Replaces the per-frame loop of `Tacotron.generate()` (reference models/tacotron.py:396-414) around
+ * BASELINE config 3's caller: the Tacotron decoder loop as one persistent kernel (on hardware since round 3:
+ * tests/test_gpu_config3.py compares it with the reference's own output, tests/golden/tacotron_decoder_200f.npz).  Replaces the per-frame loop of `Tacotron.generate()` (reference models/tacotron.py:396-414) around
  * `Decoder.forward` (:218-279) for one sentence; the encoder (:24-39, once per sentence) and the post-net stay with the caller.
  * All pointers are DEVICE pointers to contiguous float32 tensors in the reference's state-dict layouts (`decoder.*`).
  */

@@ -47,9 +47,7 @@ VARS = {'auto': dict(algo='auto'), 'stream': dict(algo='stream'), 'g1': dict(alg
         'd6lf': dict(algo='duo', depth=6, tuning=1), 'd8lf': dict(algo='duo', depth=8, tuning=1),
         'd2pf': dict(algo='duo', depth=2, tuning=2), 'd4pf': dict(algo='duo', depth=4, tuning=2), 'd6pf': dict(algo='duo', depth=6, tuning=2),
         'd8pf': dict(algo='duo', depth=8, tuning=2),
-        # placement: tuning bit 3 = a layer per XCD (p0), bit 4 = a slot's chain per XCD (p1); combined with the stage order
-        **{f'd{d}p{pl}{o}': dict(algo='duo', depth=d, tuning=(8 if pl == 0 else 16) | {'': 0, 'lf': 1, 'pf': 2}[o])
-           for d in (1, 2, 3, 4, 6, 8) for pl in (0, 1) for o in ('', 'lf', 'pf')},
+        **{f'd{d}{o}': dict(algo='duo', depth=d, tuning={'lf': 1, 'pf': 2}[o]) for d in (1, 2, 3, 4, 5, 6, 8) for o in ('lf', 'pf')},
         'd4wt': dict(algo='duo', depth=4, tuning=256), 'd8wt': dict(algo='duo', depth=8, tuning=256), 'd4lfwt': dict(algo='duo', depth=4, tuning=257),
         'd8lfwt': dict(algo='duo', depth=8, tuning=257), 'd1wt': dict(algo='duo', depth=1, tuning=256),
         'g2ns': dict(algo='loop', depth=2, tuning=16), 'g4ns': dict(algo='loop', depth=4, tuning=16), 'g8ns': dict(algo='loop', depth=8, tuning=16),

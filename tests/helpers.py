@@ -55,3 +55,14 @@ def zero_loop_fn(sd, mode):
     def fn(mels_up, aux, seg_pos, seg_lim, T, noise, hop):
         return torch.zeros(len(seg_pos), T)
     return fn
+
+
+def probe_loop_fn(sd, mode):
+    """Loop stand-in whose output identifies the segment -- TEST ONLY: row b is filled with the first up-sampled mel value of segment
+    b's conditioning (distinct per segment for random mels), so a test can tell whether sharded, gathered rows arrive in table order."""
+    import torch
+
+    def fn(mels_up, aux, seg_pos, seg_lim, T, noise, hop):
+        first = mels_up[torch.as_tensor(np.asarray(seg_pos, dtype=np.int64)), 0].cpu()
+        return first[:, None].expand(len(seg_pos), T).contiguous()
+    return fn

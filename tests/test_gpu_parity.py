@@ -81,12 +81,11 @@ VARIANTS = {
     'duo-g2-slabs': dict(algo='duo', depth=2, slab_steps=97),
     'duo-c1-g3': dict(algo='duo', clusters=1, depth=3, slab_steps=160),
     'duo-c2-g2': dict(algo='duo', clusters=2, depth=2),
-    # round 4: both placements (tuning bit 3: a layer per XCD, bit 4: a slot's chain per XCD) x both stage orders (bit 0: loads first,
-    # bit 1: publish first), and every layer written through (bit 8) -- speed switches, results must not depend on them
-    'duo-g2-p0-pf': dict(algo='duo', depth=2, tuning=8 | 2),
-    'duo-g2-p1-lf': dict(algo='duo', depth=2, tuning=16 | 1),
-    'duo-g3-p1-pf-slabs': dict(algo='duo', depth=3, tuning=16 | 2, slab_steps=131),
-    'duo-g1-p0-wt': dict(algo='duo', depth=1, tuning=8 | 256),
+    # round 4: both stage orders (tuning bit 0: loads first, bit 1: publish first) and every layer written through (bit 8) -- speed
+    # switches, results must not depend on them
+    'duo-g2-pf': dict(algo='duo', depth=2, tuning=2),
+    'duo-g3-lf-slabs': dict(algo='duo', depth=3, tuning=1, slab_steps=131),
+    'duo-g1-wt': dict(algo='duo', depth=1, tuning=256),
 }
 KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'loop': 'wrnn_loop_kernel', 'sparse': 'wrnn_sparse_kernel', 'duo': 'wrnn_duo_kernel'}
 
@@ -353,7 +352,7 @@ def test_generate_end_to_end(gpu, name, pre, tmp_path):
 
 
 @pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'loop-c2-g2', 'loop-c1-g3-nofuse', 'duo', 'duo-g1', 'duo-g2-slabs',
-                                     'duo-c1-g3', 'duo-c2-g2', 'duo-g2-p0-pf', 'duo-g2-p1-lf', 'duo-g3-p1-pf-slabs', 'duo-g1-p0-wt'])
+                                     'duo-c1-g3', 'duo-c2-g2', 'duo-g2-pf', 'duo-g3-lf-slabs', 'duo-g1-wt'])
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_many_segments_all_clusters(gpu, mode, variant):
     """46 folded segments (the last one zero-padded) = 3 groups: one per cluster, all three in flight on one cluster, two

@@ -316,6 +316,29 @@ def test_bench_self_launches_two_ranks_dry_host(tmp_path):
     assert line['scaling'] == 'strong' and line['n_gpus'] == 1 and '3 utterances' in line['config']['workload']
 
 
+def test_bench_eight_ranks_share_config4_dry_host():
+    """BASELINE config 4 as the driver launches it at N = 8 (`bench.py --gpus 8 --corpus config4`: the fixed 64-utterance corpus,
+    strong scaling), on the host under gloo with a loop stand-in that tags every segment: 942 segments go to the 8 ranks in contiguous
+    blocks of 117 / 118, and the all-gathered table arrives in segment order (row-weighted checksum == the single-process one)."""
+    import json, subprocess, sys
+    from helpers import ROOT
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, 'tests'), ROOT, os.environ.get('PYTHONPATH', '')]), OMP_NUM_THREADS='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--corpus', 'config4', '--dry-host', 'helpers:probe_loop_fn']
+    r8 = subprocess.run(base + ['--gpus', '8'], env=env, capture_output=True, text=True, timeout=1500)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    l8 = json.loads(r8.stdout.strip().splitlines()[-1])
+    assert l8['n_gpus'] == 8 and l8['scaling'] == 'strong' and l8['dry_host'] is True
+    per = l8['config']['segments_per_rank']
+    assert len(per) == 8 and sum(per) == 942 and set(per) == {117, 118} and l8['config']['gathered_rows'] == 942
+    r1 = subprocess.run(base + ['--gpus', '1'], env=dict(env, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1'), capture_output=True, text=True, timeout=1500)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    l1 = json.loads(r1.stdout.strip().splitlines()[-1])
+    assert l1['config']['segments_per_rank'] == [942]
+    assert abs(l8['config']['gathered_checksum'] - l1['config']['gathered_checksum']) <= 1e-6 * abs(l1['config']['gathered_checksum'])
+
+
 def test_sliced_generate_degrades_to_stream_when_the_grid_is_refused(tmp_path, monkeypatch):
     """Round-2 advisor: `auto` -> stream on WRNN_ERR_RESIDENCY only fired for unsliced runs.  A step-sliced generate() (batched
     RAW always is) whose first slice is refused must redo the WHOLE call on the stream kernel from the same point of the

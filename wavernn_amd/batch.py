@@ -225,38 +225,57 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
                 eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo=model.loop_algo, check=check, out=out_view)
             else:
                 out_view[:] = loop_fn(mels_up, aux, seg_pos, seg_lim, T, nz, hop)
+    # ---- the ONE collective of the path: an all-gather of the finished audio, asynchronous so that the utterances lying entirely in
+    #      this rank's block are unfolded (post-loop stage) while the other ranks' segments are still on their way over xGMI
+    n_utt = len(frames)
+    work, gathered = None, None
     if group is not None:
         gathered = [torch.empty_like(out_local) for _ in range(world)]
-        dist.all_gather(gathered, out_local, group=group)    # the ONE collective of the path: finished audio only
-        parts = [gathered[r][:h - l] for r, (l, h) in enumerate(shard_bounds(plan.n_segments, world))]
-        segs = torch.cat(parts)
-    else:
-        segs = out_local[:plan.n_segments]
+        work = dist.all_gather(gathered, out_local, group=group, async_op=True)
+
+    def gathered_segments():
+        nonlocal work
+        if group is None:
+            return out_local[:plan.n_segments]
+        if work is not None:
+            work.wait()
+            work = None
+        return torch.cat([gathered[r][:h - l] for r, (l, h) in enumerate(shard_bounds(plan.n_segments, world))])
+
     if was_training:
         model.train()
     if return_segments:
-        return segs.cpu().numpy().astype(np.float64), plan
-    if loop_fn is None and getattr(model, 'post_algo', 'numpy') == 'native' and segs.is_cuda:
-        # post-loop on the device (float64, reference order): one launch for every utterance this rank finishes
-        from .post import unfold_on_device
-        mine_u = [u for u in range(len(frames)) if finish != 'own' or (lo <= plan.first[u] < hi)]
-        outs = [None] * len(frames)
-        if mine_u:
-            wav, sl = unfold_on_device(segs, [int(plan.first[u]) for u in mine_u], [int(plan.folds[u]) for u in mine_u],
-                                       [(frames[u] - 1) * hop for u in mine_u], overlap, hop, model.n_classes, mu_law, True)
+        return gathered_segments().cpu().numpy().astype(np.float64), plan
+    mine_u = [u for u in range(n_utt) if finish != 'own' or (lo <= plan.first[u] < hi)]
+    local_u = [u for u in mine_u if lo <= plan.first[u] and plan.first[u] + plan.folds[u] <= hi]      # no segment on another rank
+    local_set = set(local_u)
+    rest_u = [u for u in mine_u if u not in local_set]
+    outs = [None] * n_utt
+    native_post = loop_fn is None and getattr(model, 'post_algo', 'numpy') == 'native' and out_local.is_cuda
+
+    def unfold(segs, first_of, us):
+        """Post-loop stage (reference :245-260, :342-405) of utterances `us`, whose first segment is row first_of(u) of `segs`."""
+        if not us:
+            return
+        if native_post:       # on the device (float64, reference order): one launch for all of them
+            from .post import unfold_on_device
+            wav, sl = unfold_on_device(segs, [first_of(u) for u in us], [int(plan.folds[u]) for u in us],
+                                       [(frames[u] - 1) * hop for u in us], overlap, hop, model.n_classes, mu_law, True)
             wav = wav.cpu().numpy()
-            for (a, b), u in zip(sl, mine_u):
+            for (a, b), u in zip(sl, us):
                 outs[u] = wav[a:b]
-        return outs
-    segs = segs.cpu().numpy().astype(np.float64)
-    outs = []
-    for u, n in enumerate(frames):
-        if finish == 'own' and not (lo <= plan.first[u] < hi):
-            outs.append(None)
-            continue
-        y = segs[plan.first[u]:plan.first[u] + plan.folds[u]].copy()
-        if mu_law:
-            y = _fold.decode_mu_law(y, model.n_classes, False)
-        y = _fold.xfade_and_unfold(y, target, overlap)
-        outs.append(_fold.finish_waveform(y, (n - 1) * hop, hop))
+            return
+        host = segs.cpu().numpy().astype(np.float64)
+        for u in us:
+            y = host[first_of(u):first_of(u) + int(plan.folds[u])].copy()
+            if mu_law:
+                y = _fold.decode_mu_law(y, model.n_classes, False)
+            y = _fold.xfade_and_unfold(y, target, overlap)
+            outs[u] = _fold.finish_waveform(y, (frames[u] - 1) * hop, hop)
+
+    unfold(out_local, lambda u: int(plan.first[u]) - lo, local_u)          # under the all-gather
+    if rest_u:
+        unfold(gathered_segments(), lambda u: int(plan.first[u]), rest_u)
+    elif work is not None:
+        work.wait()
     return outs

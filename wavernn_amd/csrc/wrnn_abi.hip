@@ -133,7 +133,8 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
         if (!ptrs[i]) { set_err("NULL weight pointer #%d", i); return WRNN_ERR_ARG; }
     const int cus = wrnn_device_cus(device);
     if (cus < 0) return cus;
-    HIPCHK(hipSetDevice(device));
+    DeviceGuard dg(device);
+    HIPCHK(dg.err);
 
     if (!shipped) {
         // ---- generic pack: k-major copies of the eight matrices + the biases (wrnn_generic.hip reads nothing else)
@@ -629,7 +630,8 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     if (workspace_bytes < l.total) { set_err("workspace %zu < required %zu", workspace_bytes, l.total); return WRNN_ERR_WORKSPACE; }
     if (((uintptr_t)workspace & 255) != 0) { set_err("workspace must be 256-byte aligned"); return WRNN_ERR_ARG; }
     hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(hipSetDevice(p->device));
+    DeviceGuard dg(p->device);
+    HIPCHK(dg.err);
     char *ws = (char *)workspace;
     wrnn_timer *timer = o->timer;
     if (timer && pl.t0 == 0) timer->used = 0;            // a continuing call (t_begin > 0) adds its launches to the same total
@@ -734,6 +736,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                     (void)hipGetLastError();
                     wrnn_options o2 = *o;
                     o2.algo = WRNN_ALGO_LOOP;
+                    o2.tuning = 0;                       // (the bits mean other things to the other kernel)
                     return wrnn_generate_segments(p, B, T, seg_pos, seg_lim, L, hop, n_frames, mels_up, aux, noise, out, workspace,
                                                   workspace_bytes, &o2, stream_);
                 }
@@ -844,7 +847,8 @@ extern "C" int wrnn_selftest(int device, int which)
 {
     const int cus = wrnn_device_cus(device);
     if (cus < 0) return cus;
-    HIPCHK(hipSetDevice(device));
+    DeviceGuard dg(device);
+    HIPCHK(dg.err);
     char msg[400] = "";
     int rc;
     if (which == 1) rc = selftest_mfma(msg, sizeof msg);

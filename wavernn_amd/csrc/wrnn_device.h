@@ -8,6 +8,21 @@
 
 namespace wrnn {
 
+// Host side: the entry points run on the device of the pack / call, and leave the calling thread's current device as they found it
+// (a caller such as PyTorch tracks its own current device: switching it behind its back sends its next launch to the wrong GPU).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        err = (prev == device) ? hipSuccess : hipSetDevice(device);
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
@@ -84,7 +99,6 @@ struct LoopArgs {
     unsigned hop_magic;                 // p / hop == __umulhi(p, hop_magic) >> hop_shift for 0 <= p < 2^31 (0: divide)
     int hop_shift;
     unsigned *xcc_tab;                  // [MAXCL * 128] zeroed before every launch: XCC id + 1 of every workgroup (placement handshake)
-    int place;                          // wrnn_duo.hip: 0 = a layer per XCD (rnn1 | rnn2), 1 = a slot's chain per XCD (ih workgroups | hh workgroups)
     int kind_tag;                       // 1 wrnn_loop_kernel, 2 wrnn_duo_kernel: recorded in status[8] by the launch that starts a call at step 0,
                                         // checked by every continuing launch (the two kernels keep different state / ring layouts)
 };

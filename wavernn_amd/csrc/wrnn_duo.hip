@@ -197,7 +197,7 @@ struct DuoGeo {
 // wait / poll, 4 ring hygiene, 5 MFMA tiles + partial writes, 6 stages, 7 stages whose operand was not there at the first look
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <bool LA, bool PF, bool PROF>
-__device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int cl, const int J, const int ncl, const bool loc_h, const bool loc_x, const bool loc_y)
+__device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int cl, const int J, const int ncl, const bool loc_h, const bool loc_y)
 {
     const int G = a.G;
     const DuoLds L = duo_lds(G);
@@ -273,7 +273,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
     const unsigned magic = a.hop_magic;
     const int mshift = a.hop_shift;
 
-    const int locbits = (loc_h ? 1 : 0) | (loc_y ? 2 : 0) | (loc_x ? 4 : 0);       // by re-arm lane group: h | y | residual sum
+    const int locbits = (loc_h ? 1 : 0) | (loc_y ? 2 : 0);                          // by re-arm lane group: h | y | residual sum (never local)
     bool dead = false;
     int pp = 0;
     int t = T0;
@@ -343,7 +343,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         const float hn = gru_update_fast(gir, giz, gin, ghr, ghz, ghn, hprev);
         HS[bi * 256 + tid] = hn;
         publish4l(xrs, sb + L_H * DLAYERB + J * 1024, tid, hn, live, loc_h);
-        publish4l(xrs, sb + L_XR * DLAYERB + J * 1024, tid, xin + hn, live, loc_x);        // x1 = xi + h1 (:212) / x2 = x1 + h2 (:216)
+        publish4l(xrs, sb + L_XR * DLAYERB + J * 1024, tid, xin + hn, live, false);        // x1 = xi + h1 (:212) / x2 = x1 + h2 (:216): to the other XCD, written through
         PHX(cur + 2);
     };
     // ---------------- back half of an fc stage: fc1 / fc2 + relu -> publish y1 / y2
@@ -786,19 +786,14 @@ __global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
     if (cl >= a.NG) return;                             // a cluster without a group of this round (the grid is always 4 clusters: see launch_duo)
     // role / unit block of workgroup wg.  Speed only: block b is observed to run on XCD b % 8 and the blocks of an XCD to be dealt
     // round-robin over its 32 CUs, i.e. (with 64 blocks per XCD) local blocks q and q + 32 share a CU; with 4 clusters a cluster is two
-    // XCDs = the two halves of its 128 blocks.  Two placements (LoopArgs.place):
-    //   0 "layer per XCD" (deep pipelines): first half rnn1, second half rnn2; within a half q < 32: the ih workgroup of unit block q,
-    //     q >= 32: the hh workgroup of unit block q - 32.  A CU carries the ih (128 MFMAs per group-step and wave) and the hh workgroup
-    //     (96) of the same units; h, gh and (rnn2) y2 never leave the XCD: least fabric traffic, best MFMA balance.
-    //   1 "chain per XCD" (shallow pipelines, where the latency of a slot's chain bounds a step): first half all 64 ih workgroups (q < 32:
-    //     rnn1's, q >= 32: rnn2's), second half all hh workgroups.  Three of the five hops of a slot's chain (x1, x2, y1) stay in one L2.
-    int layer, hh, J;
-    {
-        const int half = wg / (DNWGC / 2), q = wg % (DNWGC / 2);
-        if (a.place == 0) { layer = half; hh = q >> 5; }
-        else { hh = half; layer = q >> 5; }
-        J = q & 31;
-    }
+    // XCDs = the two halves of its 128 blocks.  First half: rnn1, second half: rnn2; within a half q < 32: the ih workgroup of unit block
+    // q, q >= 32: the hh workgroup of unit block q - 32.  A CU carries the ih (128 MFMAs per group-step and wave) and the hh workgroup (96)
+    // of the same units; h, gh and (rnn2) y2 never leave the XCD.  (Measured and dropped, profiles/r04b_probe.json: all ih workgroups
+    // of a cluster on one XCD -- x1, x2, y1 through one L2 -- is 1.0 us per step SLOWER at depth 1 and 3-8 % slower at depth 4-8: a plain
+    // store is not visible in its L2 sooner than a write-through store is visible across the fabric, and two ih workgroups per CU
+    // share the matrix pipe badly.)
+    const int layer = wg / (DNWGC / 2), q = wg % (DNWGC / 2);
+    const int hh = q >> 5, J = q & 31;
     // ---- placement handshake: every workgroup records its XCC id; a layer whose producers and consumers all sit on one XCD is
     //      exchanged through that XCD's L2 with plain stores.  Every workgroup of a cluster reads the same 128 words -> the same verdict.
     bool loc_a = false, loc_b = false;
@@ -832,17 +827,14 @@ __global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
         if (a.tuning & 256) { loc_a = false; loc_b = false; }        // A/B: everything written through, as round 3
         __syncthreads();
     }
-    // which layers stay inside one XCD (loc_a / loc_b: every workgroup of the first / second half of the cluster was seen on one XCC)
-    const bool p0 = a.place == 0;
-    const bool loc_h1 = p0 && loc_a, loc_h2 = p0 && loc_b;           // h, gh: ih <-> hh workgroups of a layer
-    const bool loc_x = !p0 && loc_a;                                 // x1, x2, y1: among the ih workgroups
-    const bool loc_y2 = p0 && loc_b;                                 // y2: rnn2's ih workgroups -> the sampling (rnn2 hh) workgroups
+    // loc_a / loc_b: every workgroup of the first / second half of the cluster was seen on one XCC -> h, gh (ih <-> hh workgroups of a
+    // layer) and y2 (rnn2's ih workgroups -> the sampling workgroups) stay in that XCD's L2
     if (layer == 0) {
-        if (hh == 0) duo_ih<true, PF, PROF>(a, smem, cl, J, ncl, loc_h1, loc_x, loc_x);
-        else duo_hh<true, PF, PROF>(a, smem, cl, J, ncl, loc_h1);
+        if (hh == 0) duo_ih<true, PF, PROF>(a, smem, cl, J, ncl, loc_a, false);
+        else duo_hh<true, PF, PROF>(a, smem, cl, J, ncl, loc_a);
     } else {
-        if (hh == 0) duo_ih<false, PF, PROF>(a, smem, cl, J, ncl, loc_h2, loc_x, loc_y2);
-        else duo_hh<false, PF, PROF>(a, smem, cl, J, ncl, loc_h2);
+        if (hh == 0) duo_ih<false, PF, PROF>(a, smem, cl, J, ncl, loc_b, loc_b);
+        else duo_hh<false, PF, PROF>(a, smem, cl, J, ncl, loc_b);
     }
 }
 
@@ -860,24 +852,22 @@ int duo_clusters(int n_cus)
     return ncl;
 }
 
-// Measured defaults (profiles/r04a_probe_new.json, r04b_*): loads-first stage order up to 7 groups in flight, publish-first at 8;
-// the chain-per-XCD placement up to DUO_CHAIN_DEPTH groups in flight, a layer per XCD above.
-constexpr int DUO_PUBFIRST_DEPTH = 8;
-constexpr int DUO_CHAIN_DEPTH = 2;
+// Stage order, measured (profiles/r04a_probe_new.json, r04b_probe.json): loads first with 1-2 groups in flight (17.8 vs 18.3 us per step at
+// depth 2), publish first from 3 on (25.8 vs 26.1 at depth 4; equal at depth 8).
+constexpr int DUO_PUBFIRST_DEPTH = 3;
 hipError_t launch_duo(const LoopArgs &args, int ncl, hipStream_t stream)
 {
     if (ncl < 1 || args.G < 1 || args.G > LMAXG || !args.fc3f || !args.u1 || !args.xcc_tab) return hipErrorInvalidValue;
     const size_t lds = duo_lds_bytes(args.G);
-    // wrnn_options.tuning (A/B switches): bit 0 = loads first, bit 1 = publish first; bit 3 = a layer per XCD, bit 4 = a chain per XCD;
-    // bit 8 = every layer written through (no XCD-local plain stores); bit 6 = placement read-out through the phase-clock buffer
+    // wrnn_options.tuning (A/B switches): bit 0 = loads first, bit 1 = publish first; bit 8 = every layer written through (no XCD-local
+    // plain stores); bit 6 = placement read-out through the phase-clock buffer
     const bool pf = (args.tuning & 2) ? true : ((args.tuning & 1) ? false : args.G >= DUO_PUBFIRST_DEPTH);
-    LoopArgs a = args;
-    a.place = (args.tuning & 16) ? 1 : ((args.tuning & 8) ? 0 : (args.G <= DUO_CHAIN_DEPTH ? 1 : 0));
     const bool prof = args.prof && !(args.tuning & 64);
     const void *fn = pf ? (prof ? (const void *)wrnn_duo_kernel<true, true> : (const void *)wrnn_duo_kernel<true, false>)
                         : (prof ? (const void *)wrnn_duo_kernel<false, true> : (const void *)wrnn_duo_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    LoopArgs a = args;
     void *params[] = {(void *)&a};
     return hipLaunchCooperativeKernel(fn, dim3(ncl * DNWGC), dim3(NT), params, (unsigned)lds, stream);
 }

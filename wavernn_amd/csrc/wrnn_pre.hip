@@ -250,7 +250,8 @@ extern "C" int wrnn_pre_create(const wrnn_pre_weights *w, int device, wrnn_pre *
         PRE_FAIL(WRNN_ERR_ARG, "NULL weight pointer");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) PRE_FAIL(WRNN_ERR_NO_DEVICE, "no HIP device %d (count %d)", device, n);
-    PRE_HIP(hipSetDevice(device));
+    DeviceGuard dg(device);
+    PRE_HIP(dg.err);
     const int B = w->res_blocks;
     const double eps = 1e-5;                                    // nn.BatchNorm1d default
     std::vector<float> h;
@@ -311,7 +312,8 @@ extern "C" int wrnn_pre_upsample(const wrnn_pre *p, const float *mel, int32_t n_
     if (workspace_bytes < wrnn_pre_workspace_bytes(p, n_frames)) PRE_FAIL(WRNN_ERR_WORKSPACE, "workspace too small");
     if (((uintptr_t)workspace & 255) != 0) PRE_FAIL(WRNN_ERR_ARG, "workspace must be 256-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
-    PRE_HIP(hipSetDevice(p->device));
+    DeviceGuard dg(p->device);
+    PRE_HIP(dg.err);
     PreArgs a;
     a.mel = mel; a.conv_in_w = p->conv_in_w; a.bn_in = p->bn_in; a.res_w = p->res_w; a.res_bn = p->res_bn;
     a.conv_out_w = p->conv_out_w; a.conv_out_b = p->conv_out_b; a.aux = aux; a.N = n_frames; a.blocks = p->blocks;

@@ -844,7 +844,8 @@ extern "C" int wrnn_taco_decode(int device, const wrnn_taco_weights *w, const wr
         taco_err("unsupported decoder geometry (the kernel is built for the reference's hparams: 80 / 256 / 128 / 256 / 512 / 32 x 31)");
         return WRNN_ERR_ARG;
     }
-    hipError_t e = hipSetDevice(device);
+    DeviceGuard dg(device);
+    hipError_t e = dg.err;
     if (e != hipSuccess) { taco_err("hipSetDevice: %s", hipGetErrorString(e)); return WRNN_ERR_HIP; }
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, device);
@@ -900,7 +901,8 @@ extern "C" int wrnn_bigru(int device, const wrnn_bigru_call *c)
         taco_err("bad call: hidden=%d (this build: %d) T=%d or a null buffer", c->hidden, GR_H, c->T);
         return WRNN_ERR_ARG;
     }
-    hipError_t e = hipSetDevice(device);
+    DeviceGuard dg(device);
+    hipError_t e = dg.err;
     if (e != hipSuccess) { taco_err("hipSetDevice: %s", hipGetErrorString(e)); return WRNN_ERR_HIP; }
     BigruArgs a;
     a.gi[0] = c->gi_fwd; a.gi[1] = c->gi_rev; a.w_hh[0] = c->w_hh_fwd; a.w_hh[1] = c->w_hh_rev; a.b_hh[0] = c->b_hh_fwd; a.b_hh[1] = c->b_hh_rev;

@@ -5,9 +5,10 @@ This is NOT the hot path and not a kernel: it is the reference's `Tacotron.gener
 a FUNCTIONAL forward over a reference state dict (`tts_model.state_dict()` / `latest_weights.pyt`), on whatever device the
 tensors live on -- PyTorch-ROCm on an MI355X.  No module tree, no training code, eval semantics only (dropout and zoneout
 are identities in `generate()`, which calls `self.eval()` first, :371).  On the CPU it reproduces the reference bit for bit
-(tests/test_tacotron_mirror.py, build container); on the GPU the decoder loop -- ~40 small launches per mel frame, one
-sentence = one serial chain -- can be captured ONCE as a HIP graph and replayed per frame (`graph=True`).  The decoder loop
-as a second persistent kernel (f3) is the follow-up; this gives config 3 an end-to-end path and a number to beat.
+(tests/test_tacotron_mirror.py, build container; tests/golden/tacotron_decoder_200f.npz holds the reference's own output for the
+GPU tests' weights); on the GPU the decoder loop -- one sentence = one serial chain of ~40 small ops per mel frame -- runs as ONE
+persistent kernel (`generate(..., kernel=True)`: `wrnn_taco_decode`, csrc/wrnn_taco.hip) and the CBHGs'
+bidirectional GRUs as `wrnn_bigru`; the eager loop stays as the any-device form.
 
     tts = TacotronInference(state_dict, device='cuda')
     _, m, attn = tts.generate(ids, steps=800)                 # same returns as the reference: (80, N), (fft, N), (N, chars); the
@@ -130,7 +131,7 @@ class TacotronInference:
 
     def _decoder_step(self, seq, seq_proj, prenet_in, st):
         """Decoder.forward (:218-279) in eval mode with the LSA attention (:181-207); `st` holds the recurrent tensors and is
-        updated IN PLACE (static addresses: the step can be captured as a HIP graph)."""
+        updated IN PLACE."""
         p = self.p
         q = 'decoder.'
         pre = self._prenet(prenet_in, q + 'prenet')
@@ -213,13 +214,13 @@ class TacotronInference:
         return mel, scores[:k]
 
     @torch.no_grad()
-    def generate(self, ids, steps=2000, graph=False, stop_check_every=1, kernel=False, kernel_variant=0):
+    def generate(self, ids, steps=2000, kernel=False, kernel_variant=0):
         """`Tacotron.generate(x, steps)` (:370-430).  Returns numpy (mel (n_mels, N), linear (fft, N), attention (N, n_chars)).
 
-        graph=True (CUDA/HIP device): one decoder step is captured as a HIP graph and replayed; the stop test of :411 (`all
-        frames < stop_threshold and t > 10`) is then evaluated from per-step flags every `stop_check_every` frames and the
-        output truncated at the first step that met it -- the same result as the eager loop, without a host round trip
-        per frame."""
+        kernel=True (HIP device): the decoder loop runs as ONE persistent kernel (`wrnn_taco_decode`, csrc/wrnn_taco.hip; the stop
+        test of :411 is evaluated inside it) and the CBHGs' bidirectional GRUs as `wrnn_bigru`.  kernel=False: the eager loop (any
+        device; the CPU form is the mirror tests/test_tacotron_mirror.py pins bit-exactly to the reference).  (Round 2's HIP-graph
+        replay of one decoder step -- 555 us per step against the kernel's 27.6 -- is gone; its numbers are in profiles/r03*.)"""
         dev = self.device
         self._bigru_kernel = bool(kernel) and dev.type == 'cuda'                   # the CBHGs' GRUs as persistent kernels too
         seq, seq_proj = self.encode(ids)
@@ -232,38 +233,6 @@ class TacotronInference:
         if kernel:
             mel, scores_all = self._decode_kernel(seq, seq_proj, steps, kernel_variant)
             frames = [mel]
-        elif graph and dev.type == 'cuda':
-            out_m, out_s = z(1, self.n_mels, self.r), z(1, n)
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):                                          # warm-up outside capture, then restore the state
-                saved = {k: v.clone() for k, v in st.items()}
-                self._decoder_step(seq, seq_proj, prenet_in, st)
-                for k, v in saved.items():
-                    st[k].copy_(v)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                m_, s_ = self._decoder_step(seq, seq_proj, prenet_in, st)
-                out_m.copy_(m_)
-                out_s.copy_(s_)
-                prenet_in.copy_(m_[:, :, -1])
-            for k, v in saved.items():                                             # capture does not execute: state is still pristine,
-                st[k].copy_(v)                                                     # but be explicit
-            prenet_in.zero_()
-            flags, last = [], 0
-            for t in range(0, steps, self.r):
-                g.replay()
-                frames.append(out_m.clone())
-                scores_all.append(out_s.clone())
-                flags.append((out_m < self.stop_threshold).all())
-                if (len(flags) - last) >= stop_check_every or t + self.r >= steps:
-                    f = torch.stack(flags).cpu().numpy()
-                    hit = [i for i in range(len(f)) if f[i] and i * self.r > 10]
-                    if hit:
-                        frames, scores_all = frames[:hit[0] + 1], scores_all[:hit[0] + 1]
-                        break
-                    last = len(flags)
         else:
             for t in range(0, steps, self.r):
                 m_, s_ = self._decoder_step(seq, seq_proj, prenet_in, st)
