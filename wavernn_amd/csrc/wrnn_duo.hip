@@ -46,6 +46,17 @@
 
 namespace wrnn {
 
+// A/B build switches (measured: profiles/r04c_*)
+#ifndef DUO_POLL_SLEEP
+#define DUO_POLL_SLEEP 1                     // s_sleep(n) between two polls of a layer; 0 = none
+#endif
+#ifndef DUO_FC3_EARLY
+#define DUO_FC3_EARLY 0                      // 1 = the sampler requests fc3's first tile before it waits for y2 (5 VGPR spills in that role)
+#endif
+#ifndef DUO_XR_FIRST
+#define DUO_XR_FIRST 1                       // 1 = the residual sum (on a slot's chain) is published before h (read a step later)
+#endif
+
 constexpr int DNX = 16;                      // layers: 0 h1  1 h2  2 y1  3 y2  4 -  5 x1  6 x2  7 x_t  8-11 gh1  12-15 gh2 ([32 unit blocks][256 threads][r, z, n, tag])
 constexpr int DRING = 8;
 constexpr int DAHEAD = 4;                    // re-arm distance (steps)
@@ -144,7 +155,7 @@ __device__ __forceinline__ void wait_for(There there, Reload reload, unsigned *s
             if (ld_agent32(status) != 0u) { dead = true; break; }
             if (spins > SPIN_LIMIT) { report_failure(status, code, blockIdx.x, step, threadIdx.x); dead = true; break; }
         }
-        __builtin_amdgcn_s_sleep(1);
+        if (DUO_POLL_SLEEP) __builtin_amdgcn_s_sleep(DUO_POLL_SLEEP);
         reload();
     }
 }
@@ -342,8 +353,9 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         }
         const float hn = gru_update_fast(gir, giz, gin, ghr, ghz, ghn, hprev);
         HS[bi * 256 + tid] = hn;
+        if (DUO_XR_FIRST) publish4l(xrs, sb + L_XR * DLAYERB + J * 1024, tid, xin + hn, live, false);    // x1 = xi + h1 (:212) / x2 = x1 + h2 (:216): to the other XCD, written through
         publish4l(xrs, sb + L_H * DLAYERB + J * 1024, tid, hn, live, loc_h);
-        publish4l(xrs, sb + L_XR * DLAYERB + J * 1024, tid, xin + hn, live, false);        // x1 = xi + h1 (:212) / x2 = x1 + h2 (:216): to the other XCD, written through
+        if (!DUO_XR_FIRST) publish4l(xrs, sb + L_XR * DLAYERB + J * 1024, tid, xin + hn, live, false);
         PHX(cur + 2);
     };
     // ---------------- back half of an fc stage: fc1 / fc2 + relu -> publish y1 / y2
@@ -668,6 +680,14 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         }
         PHX(cur + 0);
         if constexpr (!PF) run_back();
+#if DUO_FC3_EARLY
+        float4 av0[8] = {};
+        if constexpr (kind == 3) {
+            const float4 *fp0 = reinterpret_cast<const float4 *>(fc3f + frag_off(w, 0, lane));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) av0[r] = fp0[64 * r];
+        }
+#endif
         {
             const bool live = fi < nb;
             const bool there = frag_there(x, live);
@@ -717,12 +737,14 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         } else {
             // fc3 A fragments (L2-resident, fragment order).  (Requesting tile 0 before the wait for y2 would take its L2 latency off the
             // slot's chain, but costs 5 VGPR spills in this role: not done.)
+#if !DUO_FC3_EARLY
             float4 av0[8];
             {
                 const float4 *fp0 = reinterpret_cast<const float4 *>(fc3f + frag_off(w, 0, lane));
 #pragma unroll
                 for (int r = 0; r < 8; ++r) av0[r] = fp0[64 * r];
             }
+#endif
             {   // tile 1: in flight under tile 0's MFMAs, in the registers of the (now idle) look-ahead fragments
                 const u32x4 *fp = reinterpret_cast<const u32x4 *>(fc3f + XT + frag_off(w, 0, lane));
 #pragma unroll
