@@ -474,15 +474,15 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
             if (pl->ngr_max > ncl * g) { pl->rounds += 1; pl->per_round = (B + pl->rounds - 1) / pl->rounds; pl->ngr_max = (pl->per_round + SEG - 1) / SEG; }
             int slab = o->slab_steps;
             if (slab < 1) {
-                slab = (int)((96u << 20) / ((size_t)pl->ngr_max * SEG * H * sizeof(float)));
+                // what a slab holds: wrnn_loop_kernel -- the hoisted conditioning cI (2 KB per segment-step) + the derived MoL noise;
+                // wrnn_duo_kernel forms cI in the loop: only the derived noise (44 B per segment-step)
+                if (pl->kind == K_DUO) slab = (int)((64u << 20) / ((size_t)pl->per_round * 11 * sizeof(float) * pl->rounds));
+                else slab = (int)((96u << 20) / ((size_t)pl->ngr_max * SEG * H * sizeof(float)));
                 if (slab < 16) slab = 16;
-                if (slab > 1024) slab = 1024;
+                if (slab > (pl->kind == K_DUO ? 4096 : 1024)) slab = pl->kind == K_DUO ? 4096 : 1024;
             }
             if (slab > T) slab = T;
-            {   // the conditioning slab is addressed with 32-bit buffer offsets (wrnn_duo.hip)
-                const size_t per_step = (size_t)pl->ngr_max * SEG * H * sizeof(float);
-                if ((size_t)slab * per_step > 0x7FF00000u) slab = (int)(0x7FF00000u / per_step);
-            }
+
             pl->slab = slab;
         } else if (algo == WRNN_ALGO_LOOP) {
             set_err("the loop kernel needs >= 64 CUs and (MOL or RAW with 512 classes); device has %d CUs, C=%d", p->n_cus, p->C);
@@ -512,7 +512,7 @@ WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frame
     if (pl.kind == K_LOOP || pl.kind == K_DUO) {
         l.xbuf = o;  o = al(o + (pl.kind == K_DUO ? duo_xbuf_bytes_max() : XBUF_FLOATS * sizeof(float)));
         l.state = o; o = al(o + (size_t)pl.rounds * loop_state_floats(pl.G) * sizeof(float));
-        l.cIf = o;   o = al(o + (size_t)pl.slab * pl.ngr_max * SEG * H * sizeof(float));
+        l.cIf = o;   if (pl.kind == K_LOOP) o = al(o + (size_t)pl.slab * pl.ngr_max * SEG * H * sizeof(float));      // (the duo kernel forms cI in the loop)
         l.npre = o;  if (mol) o = al(o + (size_t)pl.slab * 11 * B * sizeof(float));      // derived MOL noise of one slab
     } else {
         l.gran = o;  o = al(o + GRAN_BYTES);
@@ -688,6 +688,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     a.NG = (B + SEG - 1) / SEG;
     a.Nall = B;
     a.xcc_tab = (unsigned *)(ws + l.xcc);
+    a.mels_up = mels_up; a.aux_fr = aux; a.I_cT = p->I_cT; a.I_b = p->I_b;
     hop_magic(hop, &a.hop_magic, &a.hop_shift);
 
     wrnn_run_info info;
@@ -718,7 +719,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                 if (nr < 1) continue;
                 const int ngr = (nr + SEG - 1) / SEG;
                 c.t0 = s0; c.t1 = s1; c.rb0 = rb0; c.B = nr; c.NG = ngr;
-                HIPCHK(launch_cond_frag(c, p->n_cus, stream));
+                if (!duo) HIPCHK(launch_cond_frag(c, p->n_cus, stream));
                 // every word of the exchange ring = the sentinel.  The duo kernel leaves its ring consistent at the end of a launch
                 // (every step re-arms the entries four steps ahead), so it needs the fill only where a round starts: the first
                 // launch of a call that starts at step 0, or any launch when several rounds share the buffer

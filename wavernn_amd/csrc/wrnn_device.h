@@ -98,6 +98,8 @@ struct LoopArgs {
     const float *u1;                    // [3H] rnn1.weight_ih . I.weight[:,0]: the x_{t-1} term of rnn1's gi, applied in the gates' pointwise half
     unsigned hop_magic;                 // p / hop == __umulhi(p, hop_magic) >> hop_shift for 0 <= p < 2^31 (0: divide)
     int hop_shift;
+    const float *mels_up, *aux_fr;      // [L][MEL], [NF][4 AUX]: the conditioning itself (wrnn_duo.hip forms cI(t) in the loop: SURVEY.md 8 row f1)
+    const float *I_cT, *I_b;            // [KCOND][H] transposed I.weight[:, 1:], [H] I.bias
     unsigned *xcc_tab;                  // [MAXCL * 128] zeroed before every launch: XCC id + 1 of every workgroup (placement handshake)
     int kind_tag;                       // 1 wrnn_loop_kernel, 2 wrnn_duo_kernel: recorded in status[8] by the launch that starts a call at step 0,
                                         // checked by every continuing launch (the two kernels keep different state / ring layouts)

@@ -57,7 +57,7 @@ namespace wrnn {
 #define DUO_XR_FIRST 1                       // 1 = the residual sum (on a slot's chain) is published before h (read a step later)
 #endif
 
-constexpr int DNX = 16;                      // layers: 0 h1  1 h2  2 y1  3 y2  4 -  5 x1  6 x2  7 x_t  8-11 gh1  12-15 gh2 ([32 unit blocks][256 threads][r, z, n, tag])
+constexpr int DNX = 16;                      // layers: 0 h1  1 h2  2 y1  3 y2  4 cI  5 x1  6 x2  7 x_t  8-11 gh1  12-15 gh2 ([32 unit blocks][256 threads][r, z, n, tag])
 constexpr int DRING = 8;
 constexpr int DAHEAD = 4;                    // re-arm distance (steps)
 constexpr int DNWGC = 4 * LNJ;               // workgroups per cluster (128)
@@ -230,9 +230,9 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
     float *const state = a.state;
     u64 *const profp = a.prof;
     const float *const bhhp = LA ? a.b_hh1 : a.b_hh2;
-    const int resume = a.resume, hop = a.hop, NF = a.NF, cI_t0 = a.cI_t0;
+    const int resume = a.resume, hop = a.hop, NF = a.NF;
     constexpr int L_H = LA ? 0 : 1, L_XR = LA ? 5 : 6, L_Y = LA ? 2 : 3, L_GH = LA ? 8 : 12;       // layers this role publishes / reads gh from
-    constexpr int L_P0 = 5, L_P2 = LA ? 6 : 2;                                                     // layers its stages poll (rnn1's gates: the slab)
+    constexpr int L_P0 = LA ? 4 : 5, L_P2 = LA ? 6 : 2;                                            // layers its stages poll (rnn1's gates: cI, formed in the loop by rnn1's hh workgroups)
 
     float A_ih[3][AF], A_fc[AF];
 #pragma unroll
@@ -275,7 +275,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
     const u64 nbpack = geo.nbpack;
 
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.xbuf, (unsigned)(DXBUF_FLOATS * 4));
-    const __amdgpu_buffer_rsrc_t crs = make_rsrc(LA ? a.cIf : a.c2f, 0x7FFFF000u);                 // rnn1: the conditioning slab; rnn2: its per-frame table
+    const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.c2f, 0x7FFFF000u);                              // rnn2: per-frame table of its aux columns + b_ih2
     const __amdgpu_buffer_rsrc_t frs = make_rsrc(LA ? a.c3f : a.c4f, 0x7FFFF000u);                 // per-frame table of fc1 / fc2
     const int voff_frag = frag_off(w, 0, lane) * 4;     // this lane's first fragment of a layer (bytes)
     const int voff_own = (((J * 64) + 16 * w + pj) * 4 + (tid & 3)) * 4;      // the layer word of (owned unit pu, segment pj) = its publish position
@@ -289,7 +289,6 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
     int pp = 0;
     int t = T0;
     int cur = 0;
-    unsigned touch = 0u;
 
     // what a stage's front leaves for its back half, one stage later
     struct Carry {
@@ -330,24 +329,24 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             ghr = bhhp[prow]; ghz = bhhp[H + prow]; ghn = bhhp[2 * H + prow];
         }
         float gir, giz, gin, xin;
+        unsigned xw = c.xo;                             // the GRU input of the owned unit (cI / x1): another wave's quarter of the layer, normally validated long ago
+        if (__builtin_expect(__any(live && xw == SENT), 0))
+            wait_for([&] { return !__any(live && xw == SENT); },
+                     [&] { xw = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, sb + L_P0 * DLAYERB, 16 /* sc1 */); },
+                     status, dead, 0x528u, bt);
         if constexpr (LA) {
             float xv;
             if (bt > T0) {                              // x_{t-1}, sampled by a B-hh workgroup
-                unsigned xw = c.xt;
-                if (__builtin_expect(__any(live && xw == SENT), 0))
-                    wait_for([&] { return !__any(live && xw == SENT); },
-                             [&] { xw = __builtin_amdgcn_raw_buffer_load_b32(xrs, pj * 4, cbase + bi * (MAXCL * DSLOTB) + 7 * DLAYERB + ((bt - 1) & (DRING - 1)) * XTB, 16 /* sc1 */); },
+                unsigned xt = c.xt;
+                if (__builtin_expect(__any(live && xt == SENT), 0))
+                    wait_for([&] { return !__any(live && xt == SENT); },
+                             [&] { xt = __builtin_amdgcn_raw_buffer_load_b32(xrs, pj * 4, cbase + bi * (MAXCL * DSLOTB) + 7 * DLAYERB + ((bt - 1) & (DRING - 1)) * XTB, 16 /* sc1 */); },
                              status, dead, 0x520u, bt);
-                xv = __uint_as_float(xw);
+                xv = __uint_as_float(xt);
             } else xv = XS[bi * 16 + pj];
             gir = pr + fmaf(xv, ux_r, cb_r); giz = pz + fmaf(xv, ux_z, cb_z); gin = pn + fmaf(xv, ux_n, cb_n);
-            xin = fmaf(w0o, xv, __uint_as_float(c.xo));             // xi of the owned unit (:208-209)
+            xin = fmaf(w0o, xv, __uint_as_float(xw));               // xi of the owned unit (:208-209)
         } else {
-            unsigned xw = c.xo;                         // x1 of the owned unit: another wave's quarter of the layer, normally validated long ago
-            if (__builtin_expect(__any(live && xw == SENT), 0))
-                wait_for([&] { return !__any(live && xw == SENT); },
-                         [&] { xw = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, sb + L_P0 * DLAYERB, 16 /* sc1 */); },
-                         status, dead, 0x528u, bt);
             gir = pr + c.c0; giz = pz + c.c1; gin = pn + c.c2;
             xin = __uint_as_float(xw);
         }
@@ -372,12 +371,10 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
     auto stage = [&](auto PHC, auto BKC, int i) {
         constexpr int ph = decltype(PHC)::value;
         constexpr int BK = decltype(BKC)::value;
-        const int g = cl + ncl * i;
         const int nb = slot_nb(i);
         const int ring = t & (DRING - 1);
         const int sbase = cbase + i * (MAXCL * DSLOTB);
         const int sb = sbase + ring * XTB;
-        constexpr bool polled = !(LA && ph == 0);
         u32x4 x[8];
         Carry nc;
         nc.c0 = nc.c1 = nc.c2 = 0.f; nc.gw = u32x4{0u, 0u, 0u, 0u}; nc.xo = nc.xt = 0u;
@@ -391,17 +388,13 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         // ---------------- front: this stage's loads ----------------
         int soff_x;                                     // where the operand fragments come from (for the re-load of a poll)
         if constexpr (ph == 0) {
-            if constexpr (LA) {
-                soff_x = ((t - cI_t0) * NGR + g) * XTB;                       // conditioning slab cI(t) of the group: plain data
+            soff_x = sb + L_P0 * DLAYERB;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(crs, voff_frag + r * 1024, soff_x, 0);
-                nc.xo = __builtin_amdgcn_raw_buffer_load_b32(crs, voff_own, soff_x, 0);
+            for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
+            nc.xo = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, soff_x, 16 /* sc1 */);
+            if constexpr (LA) {
                 if (t > T0) nc.xt = __builtin_amdgcn_raw_buffer_load_b32(xrs, pj * 4, sbase + 7 * DLAYERB + ((t - 1) & (DRING - 1)) * XTB, 16 /* sc1 */);
             } else {
-                soff_x = sb + L_P0 * DLAYERB;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
-                nc.xo = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, soff_x, 16 /* sc1 */);
                 const int fr = frame_of(SEGT[i * 32 + pj] + t, SEGT[i * 32 + SEG + pj], magic, mshift, hop, NF);
                 const int vo = (fr * 3 * H + prow) * 4;
                 nc.c0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, 0, 0));
@@ -422,7 +415,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             if constexpr (BK == 2) back_relu(cy);
         }
         // ---------------- operands ----------------
-        if constexpr (polled) {
+        {
             const bool live = fi < nb;
             const bool there = frag_there(x, live);
             if (PROF && tid == 0) { PROFL[cur + 6] += 1; PROFL[cur + 7] += !there; }
@@ -464,12 +457,6 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             put_partial<3>(PW, w, 0, lane, o0);
             put_partial<3>(PW, w, 1, lane, o1);
             put_partial<3>(PW, w, 2, lane, o2);
-            if constexpr (LA) {
-                if (t + 1 < T1) {                       // pull the next step's conditioning block of this group (32 KB) into this XCD's L2
-                    asm volatile("" ::"v"(touch));      // (the PREVIOUS touch: never waits for the load it is about to issue)
-                    touch = __builtin_amdgcn_raw_buffer_load_b32(crs, tid * 128, soff_x + NGR * XTB, 0);
-                }
-            }
         } else {
             put_partial<3>(PW, w, 0, lane, mfma1(A_fc, b));
         }
@@ -492,7 +479,6 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
     }
     cur = 8;
     back_relu(cy);
-    asm volatile("" ::"v"(touch));
     // ---- what the next launch of this round needs from the ring: gh(T1) of every slot (published during step T1 - 1) -> the saved
     //      state in global memory, and, for rnn1, x_{T1-1}
 #pragma unroll 1
@@ -523,8 +509,10 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// hh workgroup: gh(t+1) = W_hh . h(t) + b_hh of its 16 units for every slot (off the critical path), and -- rnn2's workgroup J, for
-// slot J -- fc3 + mixture-of-logistics sampling (utils/distribution.py:87-123).  Keeps no state between launches.
+// hh workgroup: gh(t+1) = W_hh . h(t) + b_hh of its 16 units for every slot (off the critical path); rnn2's workgroup J, for slot J:
+// fc3 + mixture-of-logistics sampling (utils/distribution.py:87-123); rnn1's workgroups: the I-layer conditioning cI(t+1) of their 16
+// rows for every slot, formed here from the up-sampled mel and the frame's aux (cond_tile: one wave, 28 MFMAs) and published through
+// ring layer 4 one step ahead -- nothing of the conditioning is materialised per call.  Keeps no state between launches.
 // PROF: as duo_ih, [gh stages: 0-7, the sampling stage: 8-15]
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <bool LA, bool PF, bool PROF>
@@ -533,6 +521,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     const int G = a.G;
     const DuoLds L = duo_lds(G);
     float *PART = smem + L.off_part, *LOG = smem + L.off_log;
+    int *SEGT = reinterpret_cast<int *>(smem + L.off_seg);
     int *GEO = reinterpret_cast<int *>(smem + L.off_misc);
     u64 *PROFL = reinterpret_cast<u64 *>(smem + L.off_prof);
     u64 plast = 0;
@@ -549,6 +538,12 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     float *const outp = a.out, *const dbgl = a.dbg_logits;
     const float *const forcex = a.force_x, *const noise_pre = a.noise_pre, *const fc3f = a.fc3f;
     const int Tall = a.T, noise_t0 = a.noise_t0;
+    const float *const mels_up = a.mels_up, *const aux_fr = a.aux_fr;
+    const int hop = a.hop;
+    const unsigned magic = a.hop_magic;
+    const int mshift = a.hop_shift;
+    CondTile ct;
+    if constexpr (LA) cond_tile_init(ct, a.I_cT, a.I_b, J, lane);
     constexpr int L_H = LA ? 0 : 1, L_GH = LA ? 8 : 12;
 
     float A_hh[3][AF];
@@ -573,6 +568,11 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         const int b0 = (int)(((long)g * NR) / NGR), nb = (int)(((long)(g + 1) * NR) / NGR) - b0;
         if (tid == 0) { GEO[2 * i] = a.rb0 + b0; GEO[2 * i + 1] = nb; }
         nbpack |= (u64)(unsigned)nb << (8 * i);
+        if (LA && tid < SEG) {                          // segment table of the slot (the conditioning it forms)
+            const int sc = a.rb0 + b0 + (tid < nb ? tid : nb - 1);
+            SEGT[i * 32 + tid] = a.seg_pos[sc];
+            SEGT[i * 32 + SEG + tid] = a.seg_lim[sc];
+        }
     }
     __syncthreads();
     // rnn2's hh workgroup J samples slot J (y2 comes from rnn2's ih workgroups: the same XCD under the placement above)
@@ -640,6 +640,35 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             }
         }
         PHX(cur + 2);
+    };
+    // ---------------- rnn1: cI(tt) of the owned 16 rows, slots w, w + 4 by wave w (no barrier: a wave forms, publishes and later re-arms its own slots)
+    auto cond_step = [&](int tt) {
+        if constexpr (LA) {
+#pragma unroll 1
+            for (int i = w; i < nact; i += NW) {
+                const int p = SEGT[i * 32 + fi] + tt;
+                const bool valid = fi < slot_nb(i) && p < SEGT[i * 32 + SEG + fi];
+                const int fr = magic ? (int)(__umulhi((unsigned)p, magic) >> mshift) : p / hop;
+                const f32x4 v = cond_tile(ct, mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane);
+                const u32x4 q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                const int so = cbase + i * (MAXCL * DSLOTB) + 4 * DLAYERB + (tt & (DRING - 1)) * XTB;
+                if (loc_h) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 16 /* sc1 */);
+            }
+        }
+    };
+    // ring hygiene of layer 4 (see the header), once per step and wave: drain, then re-arm this wave's slots' blocks of entry (t + 4) % 8
+    auto cond_rearm = [&](int tt) {
+        if constexpr (LA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const u32x4 q = {SENT, SENT, SENT, SENT};
+#pragma unroll 1
+            for (int i = w; i < nact; i += NW) {
+                const int so = cbase + i * (MAXCL * DSLOTB) + 4 * DLAYERB + ((tt + DAHEAD) & (DRING - 1)) * XTB;
+                if (loc_h) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 16 /* sc1 */);
+            }
+        }
     };
     enum { BK_NONE = 0, BK_GH = 1, BK_SAMPLE = 2, BK_ANY = 3 };
     int pend = BK_NONE;                                 // run-time kind of the pending half, read only where two kinds can meet (BK_ANY sites)
@@ -766,13 +795,16 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     using K3 = std::integral_constant<int, 3>;
     using BGH = std::integral_constant<int, BK_GH>;
     using BANY = std::integral_constant<int, BK_ANY>;
+    cond_step(T0);                                      // (the step a launch starts with; every later one is formed a step ahead)
     for (; t < T1; ++t) {
+        if (t + 1 < T1) cond_step(t + 1);
         stage(K1{}, BANY{}, 0);
 #pragma unroll 1
         for (int i = 1; i < nact; ++i) stage(K1{}, BGH{}, i);
         if constexpr (!LA) {
             if (sampler) stage(K3{}, BGH{}, my_slot);
         }
+        cond_rearm(t);
     }
     cur = 0;
     if (pend == BK_GH) back_gh(cy);

@@ -226,6 +226,49 @@ __device__ __forceinline__ void make_xi(const float4 (&c)[8], const float *WI0, 
     }
 }
 
+// ---- in-loop conditioning: cI(t) = b_I + W_I[:, 1:] . [m_t ; a1_t] (fatchord_version.py:203-209 without the x_{t-1}
+// column) for the 16 rows of unit block J and the 16 segments of a group, as ONE wave's 28 MFMAs (K = 112, no split, no LDS, no barrier)
+// straight from the up-sampled mel row and the frame's aux row.  K is ordered so that lane (row / segment fi, k-quad kq) owns the 28
+// CONSECUTIVE inputs [28 kq, 28 kq + 28): seven 16-byte loads per lane.  The accumulator layout (rows 4 (lane >> 4) + i, segment
+// lane & 15) IS the consumers' fragment order of the block: one 16-byte store per lane at block + 16 lane.
+constexpr int CK = KCOND / 4;                // inputs per lane (28)
+struct CondTile {
+    float w[CK];                             // A fragments: W_I[16 J + fi][1 + 28 kq + kk]
+    float bias[4];                           // b_I[16 J + 4 (lane >> 4) + i]
+};
+__device__ __forceinline__ void cond_tile_init(CondTile &c, const float *I_cT /* [KCOND][H] */, const float *I_b, int J, int lane)
+{
+    const int fi = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < CK; ++kk) c.w[kk] = I_cT[(size_t)(CK * kq + kk) * H + LU * J + fi];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.bias[i] = I_b[LU * J + 4 * kq + i];
+}
+// mel_row = &mels_up[p][0] (80 floats), aux_row = &aux[frame][0] (a1 = its first 32 floats) of THIS lane's segment; valid == false (the
+// fold's zero padding, an absent segment): zero conditioning -> b_I
+__device__ __forceinline__ f32x4 cond_tile(const CondTile &c, const float *mel_row, const float *aux_row, bool valid, int lane)
+{
+    const int kq = lane >> 4;
+    // inputs 28 kq + 4 j .. + 3:  kq 0, 1: mel;  kq 2: mel 56..79 (j < 6), aux 0..3 (j = 6);  kq 3: aux 4..31
+    const float *lo = (kq == 3) ? aux_row + 4 : mel_row + CK * kq;
+    const float *hi = (kq == 2) ? aux_row : lo + 24;
+    float4 v[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) v[j] = *reinterpret_cast<const float4 *>(j < 6 ? lo + 4 * j : hi);
+    }
+    f32x4 a0 = {c.bias[0], c.bias[1], c.bias[2], c.bias[3]}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w[4 * j + 0], v[j].x, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w[4 * j + 1], v[j].y, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w[4 * j + 2], v[j].z, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w[4 * j + 3], v[j].w, a1, 0, 0, 0);
+    }
+    return a0 + a1;
+}
+
 // GRU pointwise math with the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each) instead of the library's expf, tanhf
 // and IEEE divisions: ~25 VALU instead of ~120 on the critical back half of every gate stage.  Same algebra as gru_update
 // (wrnn_device.h); absolute error ~1e-7 per value, the size of the fp32 rounding already present (MoL tolerance 1e-5: tests).
