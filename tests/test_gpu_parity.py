@@ -605,7 +605,7 @@ def test_full_size_loop_kernel_vs_stream(gpu):
     noise = torch.empty(T, 11 * B).uniform_(1e-5, 1 - 1e-5, generator=torch.Generator().manual_seed(6)).to(gpu)
     eng = LoopEngine(sd, 'MOL', device=gpu)
     a = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='auto').cpu().numpy()
-    assert eng.last_loop_kernel() == 'wrnn_loop_kernel' and eng.last_loop_split() == (16, 4, 2)
+    assert eng.last_loop_kernel() == 'wrnn_duo_kernel' and eng.last_loop_split() == (16, 4, 2)      # round 4: `auto` runs MoL on the duo kernel at every depth
     ms = eng.last_loop_ms()
     print(eng.last_run_info())
     b = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='auto').cpu().numpy()
@@ -613,6 +613,8 @@ def test_full_size_loop_kernel_vs_stream(gpu):
     print(f'loop kernel {ms:.1f} ms for {B}x{T} segment-steps ({B * T / ms / 1e3:.2f} M/s); stream {eng.last_loop_ms():.1f} ms')
     assert np.array_equal(a, b), 'loop kernel is not deterministic'
     assert np.abs(a).max() <= 1.0 and np.abs(a - s).max() <= MOL_TOL, np.abs(a - s).max()
+    l = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='loop').cpu().numpy()                  # ... and the one-workgroup-per-CU kernel (the fallback)
+    assert eng.last_loop_kernel() == 'wrnn_loop_kernel' and np.abs(l - s).max() <= MOL_TOL
 
 
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])

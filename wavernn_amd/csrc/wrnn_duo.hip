@@ -50,9 +50,6 @@ namespace wrnn {
 #ifndef DUO_POLL_SLEEP
 #define DUO_POLL_SLEEP 1                     // s_sleep(n) between two polls of a layer; 0 = none
 #endif
-#ifndef DUO_FC3_EARLY
-#define DUO_FC3_EARLY 0                      // 1 = the sampler requests fc3's first tile before it waits for y2 (5 VGPR spills in that role)
-#endif
 #ifndef DUO_XR_FIRST
 #define DUO_XR_FIRST 1                       // 1 = the residual sum (on a slot's chain) is published before h (read a step later)
 #endif
@@ -73,7 +70,7 @@ static_assert((size_t)LMAXG * MAXCL * DSLOTB < 0x7FFFFFFFull, "32-bit buffer off
 static_assert(O_HOWN == 768 && O_XS == 1024 && O_SP == 1040, "saved state layout");
 
 struct DuoLds {
-    int off_h, off_seg, off_xs, off_part, off_log, off_misc, off_prof, total;
+    int off_h, off_seg, off_xs, off_part, off_log, off_misc, off_prof, off_f3, total;
 };
 __host__ __device__ inline DuoLds duo_lds(int G)
 {
@@ -86,6 +83,8 @@ __host__ __device__ inline DuoLds duo_lds(int G)
     l.off_log = o;  o += SEG * DLOGS;
     l.off_misc = o; o += 2 * LMAXG + 2 * DNWGC;      // [2 i], [2 i + 1]: first segment / count of slot i; then the placement table (ints)
     l.off_prof = o; o += 2 * 16;             // [16] u64 phase clocks (profiling builds)
+    o = (o + 3) & ~3;
+    l.off_f3 = o;   o += XT;                 // sampling workgroups: fc3's first tile in A-fragment order (its L2 latency off the slot's chain)
     l.total = o;
     return l;
 }
@@ -520,7 +519,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
 {
     const int G = a.G;
     const DuoLds L = duo_lds(G);
-    float *PART = smem + L.off_part, *LOG = smem + L.off_log;
+    float *PART = smem + L.off_part, *LOG = smem + L.off_log, *F3 = smem + L.off_f3;
     int *SEGT = reinterpret_cast<int *>(smem + L.off_seg);
     int *GEO = reinterpret_cast<int *>(smem + L.off_misc);
     u64 *PROFL = reinterpret_cast<u64 *>(smem + L.off_prof);
@@ -578,6 +577,10 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     // rnn2's hh workgroup J samples slot J (y2 comes from rnn2's ih workgroups: the same XCD under the placement above)
     const bool sampler = !LA && J < nact;
     const int my_slot = J;
+    if (sampler) {                                      // fc3's first tile -> LDS (fragment order as in the pack)
+        for (int q = tid; q < XT / 4; q += NT) reinterpret_cast<float4 *>(F3)[q] = reinterpret_cast<const float4 *>(a.fc3f)[q];
+    }
+    __syncthreads();
 
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.xbuf, (unsigned)(DXBUF_FLOATS * 4));
     const int voff_frag = frag_off(w, 0, lane) * 4;
@@ -709,14 +712,6 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         }
         PHX(cur + 0);
         if constexpr (!PF) run_back();
-#if DUO_FC3_EARLY
-        float4 av0[8] = {};
-        if constexpr (kind == 3) {
-            const float4 *fp0 = reinterpret_cast<const float4 *>(fc3f + frag_off(w, 0, lane));
-#pragma unroll
-            for (int r = 0; r < 8; ++r) av0[r] = fp0[64 * r];
-        }
-#endif
         {
             const bool live = fi < nb;
             const bool there = frag_there(x, live);
@@ -764,22 +759,16 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             put_partial<3>(PW, w, 2, lane, o2);
             pend = BK_GH;
         } else {
-            // fc3 A fragments (L2-resident, fragment order).  (Requesting tile 0 before the wait for y2 would take its L2 latency off the
-            // slot's chain, but costs 5 VGPR spills in this role: not done.)
-#if !DUO_FC3_EARLY
-            float4 av0[8];
+            // fc3 (30 x 512: two 16-row tiles in A-fragment order).  Tile 0 sits in LDS (copied once per launch): requesting it from L2
+            // here costs ~0.8 us per step on a slot's chain (25.35 vs 24.59 us per step at depth 4 with the request moved ahead of the
+            // wait for y2, which in turn cost 5 VGPR spills: profiles/r04c_probe_*.json); tile 1 comes from L2 under tile 0's MFMAs,
+            // into the registers of the (now idle) look-ahead fragments
             {
-                const float4 *fp0 = reinterpret_cast<const float4 *>(fc3f + frag_off(w, 0, lane));
-#pragma unroll
-                for (int r = 0; r < 8; ++r) av0[r] = fp0[64 * r];
-            }
-#endif
-            {   // tile 1: in flight under tile 0's MFMAs, in the registers of the (now idle) look-ahead fragments
                 const u32x4 *fp = reinterpret_cast<const u32x4 *>(fc3f + XT + frag_off(w, 0, lane));
 #pragma unroll
                 for (int r = 0; r < 8; ++r) x[r] = fp[64 * r];
             }
-            put_partial<3>(PW, w, 0, lane, mfma1_frag(av0, b));
+            put_partial<3>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
             float4 av1[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) av1[r] = make_float4(__uint_as_float(x[r].x), __uint_as_float(x[r].y), __uint_as_float(x[r].z), __uint_as_float(x[r].w));
