@@ -134,7 +134,8 @@ typedef struct wrnn_options {
                                 wrnn_duo_kernel: bit 0 = stage order loads-first, bit 1 = publish-first (default: by depth), bit 2 = re-fill the
                                   exchange ring with the sentinel before EVERY launch, bit 6 = placement read-out through phase_clocks (test
                                   hook), bit 8 = every layer written through (no XCD-local plain stores).
-                                The `auto` fallback from wrnn_duo_kernel to wrnn_loop_kernel (cooperative grid refused) clears the field. */
+                                When the two-workgroups-per-CU grid of wrnn_duo_kernel is refused the call returns WRNN_ERR_RESIDENCY; the
+                                caller may run it again with WRNN_ALGO_LOOP (another workspace layout: query its size) or _STREAM. */
     const float *force_x;    /* test hook, device [n,T]: value fed back as x_t instead of the sample (teacher forcing) */
     float *logits;           /* test hook, device [T,n,C]: fc3 output of every step (:223) */
     unsigned long long *phase_clocks; /* profiling hook, device [256 workgroups][32] zeroed by the caller: the loop kernel (MOL) adds

@@ -14,6 +14,7 @@
 namespace wrnn {
 hipError_t launch_cond(const CondArgs &a, int n_cus, bool valu, hipStream_t stream);
 hipError_t launch_cond_frames(const CondArgs &a, hipStream_t stream);
+hipError_t launch_cond_frames_slab(const CondArgs &a, hipStream_t stream);
 hipError_t launch_cond_frag(const CondArgs &a, int n_cus, hipStream_t stream);
 hipError_t launch_noise_mol(const float *in, float *out, long n, int B, int n_cus, hipStream_t stream);
 hipError_t launch_stream(const LoopArgs &args, int mode, hipStream_t stream);
@@ -373,6 +374,7 @@ int enqueue_progress(const wrnn_options *o, int done, int T, int n, hipStream_t 
 }
 
 enum Kind { K_STREAM, K_LOOP, K_SPARSE, K_DUO, K_GENERIC };
+constexpr int DUO_TAB_FPS = 8;       // wrnn_duo_kernel: rows per segment of the per-slab aux tables: a slab covers at most (DUO_TAB_FPS - 2) hops + 1 steps
 constexpr bool DUO_AUTO = true;      // `auto` runs MoL on wrnn_duo_kernel at every depth (round 4, profiles/r04a_probe_new.json: 13.5 vs 16.6 us per step
 constexpr int DUO_MIN_DEPTH = 1;     // with one group in flight, 17.9 vs 21.7 with two, 26.2 vs 36 with four; round 3's kernel paid off from depth 3 on)
 
@@ -380,6 +382,7 @@ constexpr int DUO_MIN_DEPTH = 1;     // with one group in flight, 17.9 vs 21.7 w
 struct Plan {
     Kind kind;
     int ncl, G, rounds, per_round, slab, ngr_max;
+    int tab_fps;                        // K_DUO: rows per segment of the per-slab aux tables
     int t0, t1;
 };
 
@@ -476,14 +479,14 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
             if (slab < 1) {
                 // what a slab holds: wrnn_loop_kernel -- the hoisted conditioning cI (2 KB per segment-step) + the derived MoL noise;
                 // wrnn_duo_kernel forms cI in the loop: only the derived noise (44 B per segment-step)
-                if (pl->kind == K_DUO) slab = (int)((64u << 20) / ((size_t)pl->per_round * 11 * sizeof(float) * pl->rounds));
+                if (pl->kind == K_DUO) slab = (int)((32u << 20) / ((size_t)pl->per_round * 11 * sizeof(float) * pl->rounds));
                 else slab = (int)((96u << 20) / ((size_t)pl->ngr_max * SEG * H * sizeof(float)));
                 if (slab < 16) slab = 16;
                 if (slab > (pl->kind == K_DUO ? 4096 : 1024)) slab = pl->kind == K_DUO ? 4096 : 1024;
             }
             if (slab > T) slab = T;
-
             pl->slab = slab;
+            pl->tab_fps = DUO_TAB_FPS;
         } else if (algo == WRNN_ALGO_LOOP) {
             set_err("the loop kernel needs >= 64 CUs and (MOL or RAW with 512 classes); device has %d CUs, C=%d", p->n_cus, p->C);
             return WRNN_ERR_RESIDENCY;
@@ -505,9 +508,12 @@ WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frame
     l.xcc = o;    o = al(o + XCC_WORDS * sizeof(unsigned));
     l.segs = o;   o = al(o + (size_t)2 * B * sizeof(int));
     if (pl.kind == K_GENERIC) { l.total = o; return l; }
-    l.c2f = o;    o = al(o + (size_t)(n_frames + 1) * 3 * H * sizeof(float));
-    l.c3f = o;    o = al(o + (size_t)(n_frames + 1) * H * sizeof(float));
-    l.c4f = o;    o = al(o + (size_t)(n_frames + 1) * H * sizeof(float));
+    // per-frame aux tables: one row per frame of the call's conditioning (+ the zero row) -- or, for wrnn_duo_kernel, per SEGMENT and
+    // slab: (slab - 1) / hop + 2 rows per segment (+ the zero row), refilled for every slab: independent of the corpus' length
+    const size_t tab_rows = pl.kind == K_DUO ? (size_t)B * pl.tab_fps + 1 : (size_t)n_frames + 1;
+    l.c2f = o;    o = al(o + tab_rows * 3 * H * sizeof(float));
+    l.c3f = o;    o = al(o + tab_rows * H * sizeof(float));
+    l.c4f = o;    o = al(o + tab_rows * H * sizeof(float));
     const bool mol = p->mode == WRNN_MODE_MOL;
     if (pl.kind == K_LOOP || pl.kind == K_DUO) {
         l.xbuf = o;  o = al(o + (pl.kind == K_DUO ? duo_xbuf_bytes_max() : XBUF_FLOATS * sizeof(float)));
@@ -669,7 +675,11 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     c.c2f = (float *)(ws + l.c2f); c.c3f = (float *)(ws + l.c3f); c.c4f = (float *)(ws + l.c4f);
     c.seg_pos = d_pos; c.seg_lim = d_lim;
     c.B = B; c.T = T; c.hop = hop; c.NF = n_frames;
-    HIPCHK(launch_cond_frames(c, stream));
+    if (pl.kind == K_DUO) {
+        // the aux tables are per segment and slab (filled in the slab loop): a slab may not span more than tab_fps - 2 whole hops
+        const long eff = (long)(pl.tab_fps - 2) * hop + 1;
+        if (pl.slab > eff) pl.slab = (int)eff;
+    } else HIPCHK(launch_cond_frames(c, stream));
 
     LoopArgs a;
     memset(&a, 0, sizeof a);
@@ -713,6 +723,11 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
             } else {
                 a.noise_t0 = pl.t0;
             }
+            if (duo) {   // this slab's aux tables of every segment of the call
+                c.t0 = s0; c.B = B; c.FPS = pl.tab_fps;
+                HIPCHK(launch_cond_frames_slab(c, stream));
+                a.tab_fps = pl.tab_fps; a.tab_t0 = s0;
+            }
             for (int r = 0; r < pl.rounds; ++r) {
                 const int rb0 = (int)(((long)r * B) / pl.rounds), rb1 = (int)(((long)(r + 1) * B) / pl.rounds);
                 const int nr = rb1 - rb0;
@@ -731,16 +746,8 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                 a.kind_tag = duo ? 2 : 1;
                 if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
                 hipError_t e = duo ? launch_duo(a, pl.ncl, stream) : launch_loop(a, pl.ncl, p->mode, stream);
-                if (e == hipErrorCooperativeLaunchTooLarge && duo && o->algo == WRNN_ALGO_AUTO && info.launches == 0 && pl.t0 == 0) {
-                    // two workgroups per CU are not co-resident right now: `auto` falls back to the one-workgroup-per-CU kernel
-                    // (the workspace was sized for the larger of the two layouts)
-                    (void)hipGetLastError();
-                    wrnn_options o2 = *o;
-                    o2.algo = WRNN_ALGO_LOOP;
-                    o2.tuning = 0;                       // (the bits mean other things to the other kernel)
-                    return wrnn_generate_segments(p, B, T, seg_pos, seg_lim, L, hop, n_frames, mels_up, aux, noise, out, workspace,
-                                                  workspace_bytes, &o2, stream_);
-                }
+                // (two workgroups per CU not co-resident right now: WRNN_ERR_RESIDENCY -- the caller re-plans with WRNN_ALGO_LOOP, whose
+                // workspace layout is another one: wavernn_amd/engine.py does)
                 if (e != hipSuccess) {
                     (void)hipGetLastError();
                     set_err("%s cooperative launch failed: %s", info.kernel, hipGetErrorString(e));

@@ -227,6 +227,36 @@ __global__ __launch_bounds__(H) void wrnn_cond_frame_kernel(const CondArgs a)
     a.c4f[(size_t)f * H + r] = y4 + a.fc2_b[r];
 }
 
+// The same tables for ONE SLAB of steps [a.t0, a.t0 + slab) of a call, per SEGMENT (wrnn_duo.hip, SURVEY.md 8 row f1: nothing that grows
+// with the call's length or with the corpus' frame count): row b * a.FPS + j = frame (seg_pos[b] + a.t0) / hop + j of segment b,
+// j < a.FPS = (slab - 1) / hop + 2 (every frame the segment can touch in the slab); the last row, a.B * a.FPS, is the zero-conditioning row.
+__global__ __launch_bounds__(H) void wrnn_cond_frame_slab_kernel(const CondArgs a)
+{
+    __shared__ float ax[4 * AUX];
+    const int row = blockIdx.x, r = threadIdx.x;
+    int f = a.NF;
+    if (row < a.B * a.FPS) {
+        const int b = row / a.FPS, j = row % a.FPS;
+        f = (a.seg_pos[b] + a.t0) / a.hop + j;
+    }
+    if (r < 4 * AUX) ax[r] = (f < a.NF) ? a.aux[(size_t)f * 4 * AUX + r] : 0.f;
+    __syncthreads();
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, y3 = 0.f, y4 = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < AUX; ++k) {
+        g0 = fmaf(a.c2_wT[k * 3 * H + r], ax[AUX + k], g0);
+        g1 = fmaf(a.c2_wT[k * 3 * H + H + r], ax[AUX + k], g1);
+        g2 = fmaf(a.c2_wT[k * 3 * H + 2 * H + r], ax[AUX + k], g2);
+        y3 = fmaf(a.c3_wT[k * H + r], ax[2 * AUX + k], y3);
+        y4 = fmaf(a.c4_wT[k * H + r], ax[3 * AUX + k], y4);
+    }
+    a.c2f[(size_t)row * 3 * H + r] = g0 + a.b_ih2[r];
+    a.c2f[(size_t)row * 3 * H + H + r] = g1 + a.b_ih2[H + r];
+    a.c2f[(size_t)row * 3 * H + 2 * H + r] = g2 + a.b_ih2[2 * H + r];
+    a.c3f[(size_t)row * H + r] = y3 + a.fc1_b[r];
+    a.c4f[(size_t)row * H + r] = y4 + a.fc2_b[r];
+}
+
 // MOL sampling noise -> the two derived variates the sampler needs (utils/distribution.py:106-108,118-121), once per
 // launch instead of once per workgroup and step: mixture columns u -> log(-log u) (Gumbel), logistic column
 // u -> log u - log(1-u).  Same device math functions and operation order as the in-loop form (mol_gumbel / mol_sample).
@@ -253,6 +283,13 @@ hipError_t launch_noise_mol(const float *in, float *out, long n, int B, int n_cu
 hipError_t launch_cond_frames(const CondArgs &a, hipStream_t stream)
 {
     hipLaunchKernelGGL(wrnn_cond_frame_kernel, dim3(a.NF + 1), dim3(H), 0, stream, a);
+    return hipGetLastError();
+}
+
+// the per-segment tables of one slab starting at a.t0 (all a.B segments of the call; a.FPS rows each + the zero row)
+hipError_t launch_cond_frames_slab(const CondArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(wrnn_cond_frame_slab_kernel, dim3(a.B * a.FPS + 1), dim3(H), 0, stream, a);
     return hipGetLastError();
 }
 

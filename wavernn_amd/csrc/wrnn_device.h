@@ -100,6 +100,8 @@ struct LoopArgs {
     int hop_shift;
     const float *mels_up, *aux_fr;      // [L][MEL], [NF][4 AUX]: the conditioning itself (wrnn_duo.hip forms cI(t) in the loop: SURVEY.md 8 row f1)
     const float *I_cT, *I_b;            // [KCOND][H] transposed I.weight[:, 1:], [H] I.bias
+    int tab_fps, tab_t0;                // wrnn_duo.hip: c2f / c3f / c4f are per-SEGMENT tables of the slab that starts at step tab_t0: row
+                                        // (segment index in the call) * tab_fps + frame - (seg_pos + tab_t0) / hop; zero row = Nall * tab_fps
     unsigned *xcc_tab;                  // [MAXCL * 128] zeroed before every launch: XCC id + 1 of every workgroup (placement handshake)
     int kind_tag;                       // 1 wrnn_loop_kernel, 2 wrnn_duo_kernel: recorded in status[8] by the launch that starts a call at step 0,
                                         // checked by every continuing launch (the two kernels keep different state / ring layouts)
@@ -150,6 +152,7 @@ struct CondArgs {
     const int *seg_pos, *seg_lim;       // [B] (see LoopArgs)
     int B, T, hop, NF;
     int t0, t1, rb0, NG;                // fragment-order slab form (wrnn_cond_frag_kernel): steps [t0, t1) of the round [rb0, rb0 + B)
+    int FPS;                            // per-segment slab tables (wrnn_cond_frame_slab_kernel): rows per segment
 };
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }

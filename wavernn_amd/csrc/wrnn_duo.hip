@@ -77,7 +77,7 @@ __host__ __device__ inline DuoLds duo_lds(int G)
     DuoLds l;
     int o = 0;
     l.off_h = o;    o += G * 256;            // h of the owned (unit, segment), per slot (thread-private words)
-    l.off_seg = o;  o += G * 32;             // ints: [slot][16 positions | 16 limits]
+    l.off_seg = o;  o += G * 48;             // ints: [slot][16 positions | 16 limits | 16 table-row bases (this slab's per-segment aux tables)]
     l.off_xs = o;   o += G * 16;             // A-ih: x_{t0-1} of a continuing launch, x_{t1-1} at its end
     l.off_part = o; o += DPART;
     l.off_log = o;  o += SEG * DLOGS;
@@ -175,11 +175,13 @@ __device__ __forceinline__ void publish4l(__amdgpu_buffer_rsrc_t rs, int soff, i
     }
 }
 
-// conditioning frame of position p of a segment whose conditioning ends at lim (Stretch2d: constant over a hop; the fold's zero pad -> NF)
-__device__ __forceinline__ int frame_of(int p, int lim, unsigned magic, int shift, int hop, int NF)
+// row of the slab's per-segment aux tables for position p of a segment whose conditioning ends at lim: its frame (Stretch2d: constant
+// over a hop) relative to the segment's first frame of the slab (tbase = segment * rows per segment - that frame); the fold's zero pad
+// -> the zero row
+__device__ __forceinline__ int table_row(int p, int lim, int tbase, unsigned magic, int shift, int hop, int zrow)
 {
     const int q = magic ? (int)(__umulhi((unsigned)p, magic) >> shift) : p / hop;
-    return p < lim ? q : NF;
+    return p < lim ? tbase + q : zrow;
 }
 
 #define DPARTOF(q) (PART + (q) * (NW * 3 * 256))
@@ -229,7 +231,8 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
     float *const state = a.state;
     u64 *const profp = a.prof;
     const float *const bhhp = LA ? a.b_hh1 : a.b_hh2;
-    const int resume = a.resume, hop = a.hop, NF = a.NF;
+    const int resume = a.resume, hop = a.hop;
+    const int zrow = a.Nall * a.tab_fps;
     constexpr int L_H = LA ? 0 : 1, L_XR = LA ? 5 : 6, L_Y = LA ? 2 : 3, L_GH = LA ? 8 : 12;       // layers this role publishes / reads gh from
     constexpr int L_P0 = LA ? 4 : 5, L_P2 = LA ? 6 : 2;                                            // layers its stages poll (rnn1's gates: cI, formed in the loop by rnn1's hh workgroups)
 
@@ -262,11 +265,19 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             const float *sg = a.state + state_wg + (size_t)i * LGRP;
             HS[i * 256 + tid] = sg[O_HOWN + tid];
             if (tid < SEG) XS[i * 16 + tid] = sg[O_XS + tid];
-            if (tid < 2 * SEG) SEGT[i * 32 + tid] = reinterpret_cast<const int *>(sg + O_SP)[tid];
+            if (tid < 2 * SEG) SEGT[i * 48 + tid] = reinterpret_cast<const int *>(sg + O_SP)[tid];
         } else if (tid < SEG) {                         // fatchord_version.py:194-196: h1 = h2 = 0, x = 0 (LDS is zero)
             const int sc = a.rb0 + b0 + (tid < nb ? tid : nb - 1);
-            SEGT[i * 32 + tid] = a.seg_pos[sc];
-            SEGT[i * 32 + SEG + tid] = a.seg_lim[sc];
+            SEGT[i * 48 + tid] = a.seg_pos[sc];
+            SEGT[i * 48 + SEG + tid] = a.seg_lim[sc];
+        }
+    }
+    __syncthreads();
+    for (int i = 0; i < geo.nact; ++i) {                // this slab's table rows of every segment (after the table above is in place)
+        if (tid < SEG) {
+            const int nb = (int)((geo.nbpack >> (8 * i)) & 255u);
+            const int sc = GEO[2 * i] + (tid < nb ? tid : nb - 1);
+            SEGT[i * 48 + 2 * SEG + tid] = sc * a.tab_fps - (SEGT[i * 48 + tid] + a.tab_t0) / a.hop;
         }
     }
     __syncthreads();
@@ -394,7 +405,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             if constexpr (LA) {
                 if (t > T0) nc.xt = __builtin_amdgcn_raw_buffer_load_b32(xrs, pj * 4, sbase + 7 * DLAYERB + ((t - 1) & (DRING - 1)) * XTB, 16 /* sc1 */);
             } else {
-                const int fr = frame_of(SEGT[i * 32 + pj] + t, SEGT[i * 32 + SEG + pj], magic, mshift, hop, NF);
+                const int fr = table_row(SEGT[i * 48 + pj] + t, SEGT[i * 48 + SEG + pj], SEGT[i * 48 + 2 * SEG + pj], magic, mshift, hop, zrow);
                 const int vo = (fr * 3 * H + prow) * 4;
                 nc.c0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, 0, 0));
                 nc.c1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, H * 4, 0));
@@ -405,7 +416,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             soff_x = sb + L_P2 * DLAYERB;
 #pragma unroll
             for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
-            const int fr = frame_of(SEGT[i * 32 + pj] + t, SEGT[i * 32 + SEG + pj], magic, mshift, hop, NF);
+            const int fr = table_row(SEGT[i * 48 + pj] + t, SEGT[i * 48 + SEG + pj], SEGT[i * 48 + 2 * SEG + pj], magic, mshift, hop, zrow);
             nc.c0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(frs, (fr * H + prow) * 4, 0, 0));
         }
         PHX(cur + 0);
@@ -493,7 +504,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         float *sg = state + state_wg + (size_t)i * LGRP;
         sg[tid] = __uint_as_float(gq.x); sg[256 + tid] = __uint_as_float(gq.y); sg[512 + tid] = __uint_as_float(gq.z);
         sg[O_HOWN + tid] = HS[i * 256 + tid];
-        if (tid < 2 * SEG) reinterpret_cast<int *>(sg + O_SP)[tid] = SEGT[i * 32 + tid];
+        if (tid < 2 * SEG) reinterpret_cast<int *>(sg + O_SP)[tid] = SEGT[i * 48 + tid];
         if constexpr (LA) {
             const int sx = sbase + 7 * DLAYERB + ((T1 - 1) & (DRING - 1)) * XTB;
             unsigned v = __builtin_amdgcn_raw_buffer_load_b32(xrs, fi * 4, sx, 16 /* sc1 */);
@@ -569,8 +580,8 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         nbpack |= (u64)(unsigned)nb << (8 * i);
         if (LA && tid < SEG) {                          // segment table of the slot (the conditioning it forms)
             const int sc = a.rb0 + b0 + (tid < nb ? tid : nb - 1);
-            SEGT[i * 32 + tid] = a.seg_pos[sc];
-            SEGT[i * 32 + SEG + tid] = a.seg_lim[sc];
+            SEGT[i * 48 + tid] = a.seg_pos[sc];
+            SEGT[i * 48 + SEG + tid] = a.seg_lim[sc];
         }
     }
     __syncthreads();
@@ -649,8 +660,8 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         if constexpr (LA) {
 #pragma unroll 1
             for (int i = w; i < nact; i += NW) {
-                const int p = SEGT[i * 32 + fi] + tt;
-                const bool valid = fi < slot_nb(i) && p < SEGT[i * 32 + SEG + fi];
+                const int p = SEGT[i * 48 + fi] + tt;
+                const bool valid = fi < slot_nb(i) && p < SEGT[i * 48 + SEG + fi];
                 const int fr = magic ? (int)(__umulhi((unsigned)p, magic) >> mshift) : p / hop;
                 const f32x4 v = cond_tile(ct, mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane);
                 const u32x4 q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};

@@ -112,7 +112,7 @@ class LoopEngine:
 
     def run_segments(self, mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='auto', force_x=None, want_logits=False,
                      check=True, depth=0, clusters=0, slab_steps=0, cond_valu=False, t_range=None, out=None, logits=None,
-                     phase_clocks=None, tuning=0, progress=None):
+                     phase_clocks=None, tuning=0, progress=None, _fallback=False):
         """mels_up (L,feat) / aux (n_frames,4*aux_dims) / noise: float32 CUDA tensors; seg_pos / seg_lim: host
         int32 arrays (B,) -- segment b, step t reads position seg_pos[b]+t, zero conditioning from seg_lim[b] on
         (several utterances: concatenated conditioning).  Returns out (B,T) CUDA [and logits (T,B,C)].
@@ -174,17 +174,27 @@ class LoopEngine:
         rc = self.lib.wrnn_generate_segments(self._pack, B, T, seg_pos.ctypes.data, seg_lim.ctypes.data, L, hop, n_frames,
                                              mels_up.data_ptr(), aux.data_ptr(), noise.data_ptr(), out.data_ptr(),
                                              self._ws.data_ptr(), self._ws.numel(), ctypes.byref(o), stream)
-        if rc == _lib.ERR_RESIDENCY and algo == 'auto' and t0 == 0 and t1 == T:
-            # the persistent grid is not co-resident right now (CU masking, a smaller partition, another cooperative kernel):
-            # `auto` degrades to the stream kernel (any device, no inter-workgroup traffic) instead of failing
+        if rc == _lib.ERR_RESIDENCY and t0 == 0 and (algo == 'auto' or _fallback):
+            # the persistent grid is not co-resident right now (CU masking, a smaller partition, another cooperative kernel).  `auto`
+            # degrades in two steps: two workgroups per CU (wrnn_duo_kernel) -> one (wrnn_loop_kernel, its own workspace layout;
+            # continuations are pinned to it) -> the stream kernel (any device, no inter-workgroup traffic; whole calls only)
             import warnings
-            warnings.warn('wavernn_amd: cooperative launch refused (' + self.lib.wrnn_last_error().decode() + '); using the stream kernel')
-            return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='stream', force_x=force_x,
-                                     want_logits=want_logits, check=check, cond_valu=cond_valu, out=out, logits=logits, progress=progress)
-        if rc == _lib.ERR_RESIDENCY and algo == 'auto' and t0 == 0:
-            # ... the same refusal on the first slice of a step-sliced run (only the loop kernel continues a call): the caller,
-            # who owns the slicing and the noise stream, redoes the whole call on the stream kernel
-            raise _lib.ResidencyError('cooperative launch refused (' + self.lib.wrnn_last_error().decode() + ')')
+            why = self.lib.wrnn_last_error().decode()
+            planned = _lib.RunInfo()
+            self.lib.wrnn_plan_segments(self._pack, B, T, ctypes.byref(o), ctypes.byref(planned))
+            if algo == 'auto' and (planned.kernel or b'') == b'wrnn_duo_kernel':
+                warnings.warn('wavernn_amd: cooperative launch refused (' + why + '); using wrnn_loop_kernel')
+                self._ws = None
+                return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='loop', force_x=force_x, want_logits=want_logits,
+                                         check=check, cond_valu=cond_valu, t_range=t_range, out=out, logits=logits, progress=progress,
+                                         _fallback=True)
+            if t1 == T:
+                warnings.warn('wavernn_amd: cooperative launch refused (' + why + '); using the stream kernel')
+                return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='stream', force_x=force_x,
+                                         want_logits=want_logits, check=check, cond_valu=cond_valu, out=out, logits=logits, progress=progress)
+            # ... the same refusal on the first slice of a step-sliced run (only the loop kernels continue a call): the caller, who owns
+            # the slicing and the noise stream, redoes the whole call on the stream kernel
+            raise _lib.ResidencyError('cooperative launch refused (' + why + ')')
         _lib.check(rc, 'wrnn_generate_segments')
         self._launches = (self._launches if t0 > 0 else 0) + int(self._info.launches)
         if t0 == 0:
