@@ -125,7 +125,8 @@ def test_bench_workload_256_segments_matches_oracle(gpu, algo):
                            torch.from_numpy(flat).to(gpu), HOP, algo=algo).cpu().numpy()
     info = eng.last_run_info()
     print(f'bench workload [{algo}]: {info} {eng.last_loop_ms():.1f} ms')
-    assert info['kernel'] == want['kernel'] and (info['clusters'], info['depth'], info['slab_steps']) == (want['clusters'], want['depth'], want['slab_steps'])
+    # (the plan does not know the hop: its slab length is an upper bound -- the duo kernel's per-slab aux tables cover 6 hops + 1 steps)
+    assert info['kernel'] == want['kernel'] and (info['clusters'], info['depth']) == (want['clusters'], want['depth']) and info['slab_steps'] <= want['slab_steps']
     assert info['clusters'] * info['depth'] * 16 >= 256 and info['rounds'] == 1          # all 256 segments in flight at once
     worst = 0.0
     for u, ref in enumerate(refs):
@@ -163,7 +164,7 @@ def _sweep_case(sd, mode, n, T, seed):
     return _SWEEP[key]
 
 
-@pytest.mark.parametrize('mode,algo', [('MOL', 'loop'), ('RAW', 'loop'), ('MOL', 'duo')])
+@pytest.mark.parametrize('mode,algo', [('MOL', 'loop'), ('RAW', 'loop'), ('MOL', 'duo'), ('RAW', 'duo')])
 @pytest.mark.parametrize('clusters', [1, 4])
 def test_every_depth_the_planner_can_pick(gpu, mode, clusters, algo):
     """Depth 4, 5, 6, 7, 8 groups in flight per cluster (and 3 for wrnn_duo_kernel, the shallowest depth `auto` picks it

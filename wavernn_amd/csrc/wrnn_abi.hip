@@ -24,7 +24,7 @@ int loop_clusters(int n_cus);
 size_t loop_state_floats(int G);
 hipError_t launch_generic(const GenArgs &args, int mode, hipStream_t stream);
 bool generic_dims_ok(int H, int F, int M, int A, int C, int mode);
-hipError_t launch_duo(const LoopArgs &args, int ncl, hipStream_t stream);
+hipError_t launch_duo(const LoopArgs &args, int ncl, int mode, hipStream_t stream);
 int duo_clusters(int n_cus);
 int duo_max_depth();
 size_t duo_xbuf_bytes(int G);
@@ -203,9 +203,9 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
                 b.host[o_fc3f + (size_t)q * 4 + e] = row < C ? w->fc3_w[(size_t)row * H + 128 * wv + 16 * r + 4 * kq + e] : 0.f;
         }
     }
-    // MOL: u1 = rnn1.weight_ih . I.weight[:,0] (double accumulation, rounded once): gi = W_ih . (cI + w0 x) + b = W_ih . cI + x u1 + b
+    // u1 = rnn1.weight_ih . I.weight[:,0] (double accumulation, rounded once): gi = W_ih . (cI + w0 x) + b = W_ih . cI + x u1 + b
     size_t o_u1 = 0;
-    if (w->mode == WRNN_MODE_MOL) {
+    {
         o_u1 = b.add(nullptr, (size_t)3 * H);
         for (int r = 0; r < 3 * H; ++r) {
             double acc = 0.0;
@@ -275,7 +275,7 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     p->fc1T = base + o_fc1T; p->fc2T = base + o_fc2T; p->fc3T = base + o_fc3T;
     p->c2_wT = base + o_c2_wT; p->c3_wT = base + o_c3_wT; p->c4_wT = base + o_c4_wT;
     p->fc3f = w->mode == WRNN_MODE_MOL ? base + o_fc3f : nullptr;
-    p->u1 = w->mode == WRNN_MODE_MOL ? base + o_u1 : nullptr;
+    p->u1 = base + o_u1;
     p->sp_nbp = sp_nbp; p->sp_max_blocks = sp_max;
     p->sp_vals = sp_nbp ? base + o_spv : nullptr;
     p->sp_cols = sp_nbp ? reinterpret_cast<const int *>(base + o_spc) : nullptr;
@@ -444,13 +444,13 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
         if ((double)pl->rounds * T >= 4.0e9) { set_err("too many steps"); return WRNN_ERR_ARG; }
     } else if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_LOOP || algo == WRNN_ALGO_DUO) {
         int ncl = loop_clusters(p->n_cus);
-        if (algo == WRNN_ALGO_DUO && (p->mode != WRNN_MODE_MOL || duo_clusters(p->n_cus) < 1)) {
-            set_err("the two-workgroups-per-CU loop kernel needs MOL and >= 64 CUs (mode %d, device has %d CUs)", p->mode, p->n_cus);
-            return p->mode != WRNN_MODE_MOL ? WRNN_ERR_ARG : WRNN_ERR_RESIDENCY;
+        if (algo == WRNN_ALGO_DUO && (!shape_ok || duo_clusters(p->n_cus) < 1)) {
+            set_err("the two-workgroups-per-CU loop kernel needs MOL or RAW with 512 classes, and >= 64 CUs (C = %d, device has %d CUs)", p->C, p->n_cus);
+            return !shape_ok ? WRNN_ERR_ARG : WRNN_ERR_RESIDENCY;
         }
         if (shape_ok && ncl >= 1) {
             if (o->clusters == 1 || o->clusters == 2 || o->clusters == 4) ncl = o->clusters < ncl ? o->clusters : ncl;
-            else if (groups < ncl && !(p->mode == WRNN_MODE_MOL && DUO_AUTO && algo != WRNN_ALGO_LOOP && ncl == MAXCL)) {
+            else if (groups < ncl && !(DUO_AUTO && algo != WRNN_ALGO_LOOP && ncl == MAXCL)) {
                 // no more clusters than groups (rounded up to 1, 2, 4).  Not for the duo kernel: its grid is always 4 clusters (a cluster
                 // without a group leaves at once), so that a small batch sits on whole XCDs exactly as a large one does
                 int c2 = 1; while (c2 < groups) c2 *= 2; if (c2 < ncl) ncl = c2;
@@ -468,7 +468,7 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
             pl->kind = K_LOOP; pl->ncl = ncl; pl->G = g;
             // the two-workgroups-per-CU form (MOL): on request, or when `auto` has >= DUO_MIN_DEPTH groups in flight per cluster
             // (busy time bounds a step there; with fewer the latency of a slot's chain does, and the duo kernel's chain is one hop longer)
-            if (p->mode == WRNN_MODE_MOL && (algo == WRNN_ALGO_DUO || (algo == WRNN_ALGO_AUTO && DUO_AUTO && g >= DUO_MIN_DEPTH && ncl == MAXCL)))
+            if (algo == WRNN_ALGO_DUO || (algo == WRNN_ALGO_AUTO && DUO_AUTO && g >= DUO_MIN_DEPTH && ncl == MAXCL))
                 pl->kind = K_DUO;
             pl->rounds = (groups + ncl * g - 1) / (ncl * g);
             // balanced rounds of whole segments; every round is cut into <= ncl * g groups of <= 16
@@ -479,7 +479,7 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
             if (slab < 1) {
                 // what a slab holds: wrnn_loop_kernel -- the hoisted conditioning cI (2 KB per segment-step) + the derived MoL noise;
                 // wrnn_duo_kernel forms cI in the loop: only the derived noise (44 B per segment-step)
-                if (pl->kind == K_DUO) slab = (int)((32u << 20) / ((size_t)pl->per_round * 11 * sizeof(float) * pl->rounds));
+                if (pl->kind == K_DUO) slab = p->mode == WRNN_MODE_MOL ? (int)((32u << 20) / ((size_t)pl->per_round * 11 * sizeof(float) * pl->rounds)) : 4096;
                 else slab = (int)((96u << 20) / ((size_t)pl->ngr_max * SEG * H * sizeof(float)));
                 if (slab < 16) slab = 16;
                 if (slab > (pl->kind == K_DUO ? 4096 : 1024)) slab = pl->kind == K_DUO ? 4096 : 1024;
@@ -745,7 +745,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                 a.t0 = s0; a.t1 = s1; a.cI_t0 = s0; a.rb0 = rb0; a.Btot = nr; a.NG = ngr; a.resume = s0 > 0 ? 1 : 0;
                 a.kind_tag = duo ? 2 : 1;
                 if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
-                hipError_t e = duo ? launch_duo(a, pl.ncl, stream) : launch_loop(a, pl.ncl, p->mode, stream);
+                hipError_t e = duo ? launch_duo(a, pl.ncl, p->mode, stream) : launch_loop(a, pl.ncl, p->mode, stream);
                 // (two workgroups per CU not co-resident right now: WRNN_ERR_RESIDENCY -- the caller re-plans with WRNN_ALGO_LOOP, whose
                 // workspace layout is another one: wavernn_amd/engine.py does)
                 if (e != hipSuccess) {

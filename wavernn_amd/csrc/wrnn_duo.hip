@@ -54,7 +54,7 @@ namespace wrnn {
 #define DUO_XR_FIRST 1                       // 1 = the residual sum (on a slot's chain) is published before h (read a step later)
 #endif
 
-constexpr int DNX = 16;                      // layers: 0 h1  1 h2  2 y1  3 y2  4 cI  5 x1  6 x2  7 x_t  8-11 gh1  12-15 gh2 ([32 unit blocks][256 threads][r, z, n, tag])
+constexpr int DNX = 17;                      // layers: 0 h1  1 h2  2 y1  3 y2  4 cI  5 x1  6 x2  7 x_t  8-11 gh1  12-15 gh2 ([32 unit blocks][256 threads][r, z, n, tag])  16 RAW logits
 constexpr int DRING = 8;
 constexpr int DAHEAD = 4;                    // re-arm distance (steps)
 constexpr int DNWGC = 4 * LNJ;               // workgroups per cluster (128)
@@ -84,7 +84,8 @@ __host__ __device__ inline DuoLds duo_lds(int G)
     l.off_misc = o; o += 2 * LMAXG + 2 * DNWGC;      // [2 i], [2 i + 1]: first segment / count of slot i; then the placement table (ints)
     l.off_prof = o; o += 2 * 16;             // [16] u64 phase clocks (profiling builds)
     o = (o + 3) & ~3;
-    l.off_f3 = o;   o += XT;                 // sampling workgroups: fc3's first tile in A-fragment order (its L2 latency off the slot's chain)
+    l.off_f3 = o;   o += SEG * LDC;          // sampling workgroups: MOL fc3's first tile in A-fragment order (XT floats: its L2 latency off the slot's
+                                             // chain); RAW the gathered logits as [segment][class] rows of stride LDC
     l.total = o;
     return l;
 }
@@ -208,7 +209,7 @@ struct DuoGeo {
 // PROF (thread 0, shader clocks per segment of a stage, [gates: 0-7, fc: 8-15]): 0 front issue, 1 barrier wait, 2 back half, 3 operand
 // wait / poll, 4 ring hygiene, 5 MFMA tiles + partial writes, 6 stages, 7 stages whose operand was not there at the first look
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <bool LA, bool PF, bool PROF>
+template <int MODE, bool LA, bool PF, bool PROF>
 __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int cl, const int J, const int ncl, const bool loc_h, const bool loc_y)
 {
     const int G = a.G;
@@ -360,7 +361,8 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             gir = pr + c.c0; giz = pz + c.c1; gin = pn + c.c2;
             xin = __uint_as_float(xw);
         }
-        const float hn = gru_update_fast(gir, giz, gin, ghr, ghz, ghn, hprev);
+        // MoL: hardware exp / rcp (inside the 1e-5 tolerance); RAW (class indices compared bit for bit): the library forms
+        const float hn = MODE == 1 ? gru_update_fast(gir, giz, gin, ghr, ghz, ghn, hprev) : gru_update(gir, giz, gin, ghr, ghz, ghn, hprev);
         HS[bi * 256 + tid] = hn;
         if (DUO_XR_FIRST) publish4l(xrs, sb + L_XR * DLAYERB + J * 1024, tid, xin + hn, live, false);    // x1 = xi + h1 (:212) / x2 = x1 + h2 (:216): to the other XCD, written through
         publish4l(xrs, sb + L_H * DLAYERB + J * 1024, tid, hn, live, loc_h);
@@ -525,7 +527,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
 // ring layer 4 one step ahead -- nothing of the conditioning is materialised per call.  Keeps no state between launches.
 // PROF: as duo_ih, [gh stages: 0-7, the sampling stage: 8-15]
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <bool LA, bool PF, bool PROF>
+template <int MODE, bool LA, bool PF, bool PROF>
 __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int cl, const int J, const int ncl, const bool loc_h)
 {
     const int G = a.G;
@@ -546,7 +548,8 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     unsigned *const status = a.status;                  // (local values for the stage lambdas: see duo_ih)
     u64 *const profp = a.prof;
     float *const outp = a.out, *const dbgl = a.dbg_logits;
-    const float *const forcex = a.force_x, *const noise_pre = a.noise_pre, *const fc3f = a.fc3f;
+    const float *const forcex = a.force_x, *const noise_pre = a.noise_pre, *const fc3f = a.fc3f, *const noise_raw = a.noise;
+    constexpr bool MOL = MODE == 1;
     const int Tall = a.T, noise_t0 = a.noise_t0;
     const float *const mels_up = a.mels_up, *const aux_fr = a.aux_fr;
     const int hop = a.hop;
@@ -561,10 +564,16 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     for (int g = 0; g < 3; ++g) load_afrag(A_hh[g], LA ? a.w_hh1 : a.w_hh2, H, g * H + LU * J + fi, true, kbase_lane);
     const float *bhh = LA ? a.b_hh1 : a.b_hh2;
     const float bh_r = bhh[prow], bh_z = bhh[H + prow], bh_n = bhh[2 * H + prow];
-    float b3a = 0.f, b3b = 0.f;                         // logit rows pu and 16 + pu
+    float b3a = 0.f, b3b = 0.f;                         // MOL: logit rows pu and 16 + pu; RAW: logit row (class) 16 J + pu of the owned block
+    float A_f3[AF];                                     // RAW: fc3 rows [16 J, 16 J + 16) of rnn2's hh workgroup J (the 512 logits are a sixth exchange)
     if constexpr (!LA) {
-        b3a = a.fc3_b[pu];
-        b3b = (16 + pu < 30) ? a.fc3_b[16 + pu] : 0.f;
+        if constexpr (MOL) {
+            b3a = a.fc3_b[pu];
+            b3b = (16 + pu < 30) ? a.fc3_b[16 + pu] : 0.f;
+        } else {
+            b3a = a.fc3_b[prow];
+            load_afrag(A_f3, a.fc3_w, H, LU * J + fi, true, kbase_lane);
+        }
     }
 
     for (int q = tid; q < L.total; q += NT) smem[q] = 0.f;
@@ -588,9 +597,10 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     // rnn2's hh workgroup J samples slot J (y2 comes from rnn2's ih workgroups: the same XCD under the placement above)
     const bool sampler = !LA && J < nact;
     const int my_slot = J;
-    if (sampler) {                                      // fc3's first tile -> LDS (fragment order as in the pack)
+    if (MOL && sampler) {                               // fc3's first tile -> LDS (fragment order as in the pack)
         for (int q = tid; q < XT / 4; q += NT) reinterpret_cast<float4 *>(F3)[q] = reinterpret_cast<const float4 *>(a.fc3f)[q];
     }
+    float *const LGT = F3;                              // RAW: the gathered logits of the slot being sampled, [segment][class] rows of stride LDC
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.xbuf, (unsigned)(DXBUF_FLOATS * 4));
@@ -620,6 +630,15 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             if (loc_h) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, voff_gh, so, 0);
             else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, voff_gh, so, 16 /* sc1 */);
         }
+        PHX(cur + 2);
+    };
+    // ---------------- RAW: back half of a logits stage: the owned 16 classes x 16 segments of fc3 (:223) -> ring layer 16 (read by the slot's sampler)
+    auto back_lg = [&](const Carry &c) {
+        const float *PB = DPARTOF(c.pp);
+        lds_barrier();
+        PHX(cur + 1);
+        publish4l(xrs, cbase + c.i * (MAXCL * DSLOTB) + 16 * DLAYERB + (c.t & (DRING - 1)) * XTB + J * 1024, tid, get_partial<3>(PB, 0, pu, pj) + b3a,
+                  pj < slot_nb(c.i), loc_h);
         PHX(cur + 2);
     };
     // ---------------- back half of the sampling stage: fc3 logits -> sample x_t (utils/distribution.py:102-121)
@@ -684,30 +703,34 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             }
         }
     };
-    enum { BK_NONE = 0, BK_GH = 1, BK_SAMPLE = 2, BK_ANY = 3 };
+    enum { BK_NONE = 0, BK_GH = 1, BK_SAMPLE = 2, BK_ANY = 3, BK_LG = 4 };
     int pend = BK_NONE;                                 // run-time kind of the pending half, read only where two kinds can meet (BK_ANY sites)
 
-    // kind 1: gh stage of slot i (polls h(t)); kind 3: sampling stage of my_slot (polls y2(t))
+    // kind 1: gh stage of slot i (polls h(t)); kind 3: MOL sampling stage of my_slot (polls y2(t)); RAW: kind 2: logits stage of slot i (polls y2(t)),
+    // kind 4: sampling stage of my_slot (polls the 512 logits)
     auto stage = [&](auto KC, auto BKC, int i) {
         constexpr int kind = decltype(KC)::value;
         constexpr int BK = decltype(BKC)::value;
         const int nb = slot_nb(i);
         const int ring = t & (DRING - 1);
         const int sbase = cbase + i * (MAXCL * DSLOTB);
-        const int soff_x = sbase + (kind == 1 ? L_H : 3) * DLAYERB + ring * XTB;
+        const int soff_x = sbase + (kind == 1 ? L_H : (kind == 4 ? 16 : 3)) * DLAYERB + ring * XTB;
         Carry nc;
         nc.c0 = nc.c1 = 0.f; nc.i = i; nc.pp = pp; nc.t = t;
         auto run_back = [&] {
             if constexpr (BK == BK_GH) back_gh(cy);
             else if constexpr (BK == BK_SAMPLE) back_sample(cy);
+            else if constexpr (BK == BK_LG) back_lg(cy);
             else if constexpr (BK == BK_ANY) {
                 if (pend == BK_GH) back_gh(cy);
-                else if (pend == BK_SAMPLE) { if constexpr (!LA) back_sample(cy); }
+                else if (pend == BK_SAMPLE) { if constexpr (!LA && MOL) back_sample(cy); }
+                else if (pend == BK_LG) { if constexpr (!LA && !MOL) back_lg(cy); }
             }
         };
         if (PROF && tid == 0 && plast == 0) plast = __builtin_amdgcn_s_memtime();
-        if constexpr (PF) run_back();
+        if constexpr (PF || kind == 4) run_back();      // (RAW sampling: this workgroup's own logit rows of the slot must be out before it gathers them)
         cur = kind == 1 ? 0 : 8;
+
         if (!xahead) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
@@ -722,7 +745,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             nc.c1 = nrow[(size_t)10 * Nall + b0 + suc];
         }
         PHX(cur + 0);
-        if constexpr (!PF) run_back();
+        if constexpr (!PF && kind != 4) run_back();
         {
             const bool live = fi < nb;
             const bool there = frag_there(x, live);
@@ -736,7 +759,20 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
                          status, dead, 0x600u | (LA ? 0u : 8u) | (unsigned)kind, t);
         }
         PHX(cur + 3);
-        if (sampler && kind == 3) {
+        if (kind == 2 && i == nact - 1) {
+            // RAW ring hygiene (see the header): drain, then re-arm this wave's quarter of the workgroup's logit block of every slot in entry (t + 4) % 8
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane < 16) {
+                const u32x4 q = {SENT, SENT, SENT, SENT};
+                const int so = cbase + 16 * DLAYERB + ((t + DAHEAD) & (DRING - 1)) * XTB;
+#pragma unroll 1
+                for (int i2 = 0; i2 < nact; ++i2) {
+                    if (loc_h) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + w * 256 + lane * 16, so + i2 * (MAXCL * DSLOTB), 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + w * 256 + lane * 16, so + i2 * (MAXCL * DSLOTB), 16 /* sc1 */);
+                }
+            }
+        }
+        if (sampler && (kind == 3 || kind == 4)) {
             // ring hygiene (see the header): drain, then re-arm the x_t words of the slot this workgroup samples in entry (t + 4) % 8
             // (the gh words carry a step tag instead of relying on a sentinel: nothing to re-arm)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -749,10 +785,11 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         frag_to_b(x, b);
         {   // the next stage's polled layer, one stage ahead (not across a step boundary: nothing of the next step is published yet)
             xahead = false;
-            if (kind == 1) {
+            if (kind == 1 || kind == 2) {
                 int so = -1;
-                if (i + 1 < nact) so = sbase + MAXCL * DSLOTB + L_H * DLAYERB + ring * XTB;
-                else if (sampler) so = cbase + my_slot * (MAXCL * DSLOTB) + 3 * DLAYERB + ring * XTB;
+                if (i + 1 < nact) so = sbase + MAXCL * DSLOTB + (kind == 1 ? L_H : 3) * DLAYERB + ring * XTB;
+                else if (kind == 1 && !LA && !MOL) so = cbase + 3 * DLAYERB + ring * XTB;                                   // RAW: the logits stage of slot 0
+                else if (sampler) so = cbase + my_slot * (MAXCL * DSLOTB) + (MOL ? 3 : 16) * DLAYERB + ring * XTB;      // the sampling stage
                 if (so >= 0) {
                     xahead = true;
 #pragma unroll
@@ -769,6 +806,109 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             put_partial<3>(PW, w, 1, lane, o1);
             put_partial<3>(PW, w, 2, lane, o2);
             pend = BK_GH;
+        } else if constexpr (kind == 2) {
+            put_partial<3>(PW, w, 0, lane, mfma1(A_f3, b));
+            pend = BK_LG;
+        } else if constexpr (kind == 4) {
+            // fatchord_version.py:231-237: softmax -> Categorical (renormalise) -> argmax(p / q) -- the loop kernel's code: one wave per 4 segments,
+            // the four handled in lock step; per segment the operation order is the reference's (class indices compared bit for bit)
+            const int b0 = GEO[2 * i];
+            {
+                float *lp = LGT + fi * LDC + kbase_lane;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) *reinterpret_cast<float4 *>(lp + 16 * r) = make_float4(b[4 * r], b[4 * r + 1], b[4 * r + 2], b[4 * r + 3]);
+            }
+            // the Exp(1) variates of this wave's 4 segments (2 KB per segment): requested now, needed after the two softmax passes
+            float qn[4][8];
+            {
+                const size_t tn = (size_t)(t - noise_t0);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int sjc = (4 * w + s4 < nb) ? 4 * w + s4 : nb - 1;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qn[s4][e] = noise_raw[(tn * Nall + b0 + sjc) * C + lane + 64 * e];
+                }
+            }
+            lds_barrier();
+            {
+                float lg[4][8], mx[4], sum[4], sum2[4], best[4];
+                int bidx[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int sjc = (4 * w + s4 < nb) ? 4 * w + s4 : nb - 1;
+                    mx[s4] = -INFINITY;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        lg[s4][e] = LGT[sjc * LDC + lane + 64 * e];
+                        mx[s4] = fmaxf(mx[s4], lg[s4][e]);
+                    }
+                }
+                if (dbgl) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        if (4 * w + s4 < nb)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) dbgl[((size_t)t * Nall + b0 + 4 * w + s4) * C + lane + 64 * e] = lg[s4][e];
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) mx[s4] = fmaxf(mx[s4], __shfl_xor(mx[s4], m, 64));
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    sum[s4] = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { lg[s4][e] = expf(lg[s4][e] - mx[s4]); sum[s4] += lg[s4][e]; }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) sum[s4] += __shfl_xor(sum[s4], m, 64);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    sum2[s4] = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { lg[s4][e] = lg[s4][e] / sum[s4]; sum2[s4] += lg[s4][e]; }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) sum2[s4] += __shfl_xor(sum2[s4], m, 64);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    best[s4] = -INFINITY;
+                    bidx[s4] = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float rr = (lg[s4][e] / sum2[s4]) / qn[s4][e];
+                        if (rr > best[s4]) { best[s4] = rr; bidx[s4] = lane + 64 * e; }
+                    }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const float ob = __shfl_xor(best[s4], m, 64);
+                        const int oi = __shfl_xor(bidx[s4], m, 64);
+                        if (ob > best[s4] || (ob == best[s4] && oi < bidx[s4])) { best[s4] = ob; bidx[s4] = oi; }
+                    }
+                if (lane == 0) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int sj = 4 * w + s4;
+                        if (sj < nb) {
+                            float xv = 2.f * (float)bidx[s4] / ((float)C - 1.f) - 1.f;
+                            outp[(size_t)(b0 + sj) * Tall + t] = xv;
+                            if (forcex) xv = forcex[(size_t)(b0 + sj) * Tall + t];
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xv), xrs, sj * 4, sbase + 7 * DLAYERB + ring * XTB, 16 /* sc1 */);
+                        }
+                    }
+                }
+            }
+            lds_barrier();                              // LGT is read by every wave before the next step's gather overwrites it
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] = u32x4{0u, 0u, 0u, 0u};      // (the look-ahead registers are dead through the sampling: say so)
+            pend = BK_NONE;
         } else {
             // fc3 (30 x 512: two 16-row tiles in A-fragment order).  Tile 0 sits in LDS (copied once per launch): requesting it from L2
             // here costs ~0.8 us per step on a slot's chain (25.35 vs 24.59 us per step at depth 4 with the request moved ahead of the
@@ -792,8 +932,11 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     };
 
     using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
     using K3 = std::integral_constant<int, 3>;
+    using K4 = std::integral_constant<int, 4>;
     using BGH = std::integral_constant<int, BK_GH>;
+    using BLG = std::integral_constant<int, BK_LG>;
     using BANY = std::integral_constant<int, BK_ANY>;
     cond_step(T0);                                      // (the step a launch starts with; every later one is formed a step ahead)
     for (; t < T1; ++t) {
@@ -801,14 +944,21 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         stage(K1{}, BANY{}, 0);
 #pragma unroll 1
         for (int i = 1; i < nact; ++i) stage(K1{}, BGH{}, i);
-        if constexpr (!LA) {
+        if constexpr (!LA && MOL) {
             if (sampler) stage(K3{}, BGH{}, my_slot);
+        }
+        if constexpr (!LA && !MOL) {
+            stage(K2{}, BGH{}, 0);
+#pragma unroll 1
+            for (int i = 1; i < nact; ++i) stage(K2{}, BLG{}, i);
+            if (sampler) stage(K4{}, BLG{}, my_slot);
         }
         cond_rearm(t);
     }
     cur = 0;
     if (pend == BK_GH) back_gh(cy);
-    else if (pend == BK_SAMPLE) { if constexpr (!LA) back_sample(cy); }
+    else if (pend == BK_SAMPLE) { if constexpr (!LA && MOL) back_sample(cy); }
+    else if (pend == BK_LG) { if constexpr (!LA && !MOL) back_lg(cy); }
     if (PROF && tid == 0 && profp) {
         for (int k = 0; k < 16; ++k) profp[(size_t)(blockIdx.x & 255) * 32 + 16 + k] += PROFL[k];
     }
@@ -818,7 +968,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
 
 // Grid = clusters x 128 workgroups of 256 threads (two per CU), cooperative launch.  Whole XCDs per cluster (speed only: nothing
 // depends on the placement; what the placement is, is looked at below).
-template <bool PF, bool PROF>
+template <int MODE, bool PF, bool PROF>
 __global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -884,11 +1034,11 @@ __global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
     // loc_a / loc_b: every workgroup of the first / second half of the cluster was seen on one XCC -> h, gh (ih <-> hh workgroups of a
     // layer) and y2 (rnn2's ih workgroups -> the sampling workgroups) stay in that XCD's L2
     if (layer == 0) {
-        if (hh == 0) duo_ih<true, PF, PROF>(a, smem, cl, J, ncl, loc_a, false);
-        else duo_hh<true, PF, PROF>(a, smem, cl, J, ncl, loc_a);
+        if (hh == 0) duo_ih<MODE, true, PF, PROF>(a, smem, cl, J, ncl, loc_a, false);
+        else duo_hh<MODE, true, PF, PROF>(a, smem, cl, J, ncl, loc_a);
     } else {
-        if (hh == 0) duo_ih<false, PF, PROF>(a, smem, cl, J, ncl, loc_b, loc_b);
-        else duo_hh<false, PF, PROF>(a, smem, cl, J, ncl, loc_b);
+        if (hh == 0) duo_ih<MODE, false, PF, PROF>(a, smem, cl, J, ncl, loc_b, loc_b);
+        else duo_hh<MODE, false, PF, PROF>(a, smem, cl, J, ncl, loc_b);
     }
 }
 
@@ -909,16 +1059,17 @@ int duo_clusters(int n_cus)
 // Stage order, measured (profiles/r04a_probe_new.json, r04b_probe.json): loads first with 1-2 groups in flight (17.8 vs 18.3 us per step at
 // depth 2), publish first from 3 on (25.8 vs 26.1 at depth 4; equal at depth 8).
 constexpr int DUO_PUBFIRST_DEPTH = 3;
-hipError_t launch_duo(const LoopArgs &args, int ncl, hipStream_t stream)
+hipError_t launch_duo(const LoopArgs &args, int ncl, int mode, hipStream_t stream)
 {
-    if (ncl < 1 || args.G < 1 || args.G > LMAXG || !args.fc3f || !args.u1 || !args.xcc_tab) return hipErrorInvalidValue;
+    if (ncl < 1 || args.G < 1 || args.G > LMAXG || (mode == 1 && !args.fc3f) || !args.u1 || !args.xcc_tab) return hipErrorInvalidValue;
     const size_t lds = duo_lds_bytes(args.G);
     // wrnn_options.tuning (A/B switches): bit 0 = loads first, bit 1 = publish first; bit 8 = every layer written through (no XCD-local
     // plain stores); bit 6 = placement read-out through the phase-clock buffer
     const bool pf = (args.tuning & 2) ? true : ((args.tuning & 1) ? false : args.G >= DUO_PUBFIRST_DEPTH);
-    const bool prof = args.prof && !(args.tuning & 64);
-    const void *fn = pf ? (prof ? (const void *)wrnn_duo_kernel<true, true> : (const void *)wrnn_duo_kernel<true, false>)
-                        : (prof ? (const void *)wrnn_duo_kernel<false, true> : (const void *)wrnn_duo_kernel<false, false>);
+    const bool prof = mode == 1 && args.prof && !(args.tuning & 64);              // phase clocks: MOL builds only
+    const void *fn = mode == 1 ? (pf ? (prof ? (const void *)wrnn_duo_kernel<1, true, true> : (const void *)wrnn_duo_kernel<1, true, false>)
+                                     : (prof ? (const void *)wrnn_duo_kernel<1, false, true> : (const void *)wrnn_duo_kernel<1, false, false>))
+                               : (pf ? (const void *)wrnn_duo_kernel<0, true, false> : (const void *)wrnn_duo_kernel<0, false, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     LoopArgs a = args;
