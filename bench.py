@@ -468,6 +468,34 @@ def main():
                 except Exception as e:
                     res['config']['batch_of_8_utterances'] = {'error': repr(e)}
         if not args.no_single and world == 1 and args.prune == 0 and args.corpus == 'batch' and mode == 'MOL':
+            try:    # BASELINE config 4 is strong scaling: at N = 8 a GPU owns 117-118 of the corpus' 942 segments.  What that share runs at,
+                    # on this one GPU (rank 0's block of the fixed 64-utterance corpus, no collective): the rate the 8-GPU number is made of
+                from wavernn_amd.batch import shard_bounds as _sb
+                f4 = [int(n) for n in np.random.RandomState(2024).randint(300, 901, 64)]
+                p4 = plan_utterances([n * hop for n in f4], target, overlap)
+                lo4, hi4 = _sb(p4.n_segments, 8)[0]
+                m4 = [torch.from_numpy(random_mel(1000 + u, n)).unsqueeze(0).to(dev) for u, n in enumerate(f4)]
+
+                def share_pass():
+                    generate_corpus(model, m4, target, overlap, True, None, noise_source='device', finish='own', check=False, shard=(0, 8))
+                    eng.status()
+                share_pass()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    share_pass()
+                torch.cuda.synchronize()
+                d4 = (time.perf_counter() - t0) / 2
+                k4, i4 = eng.last_loop_ms(), eng.last_run_info()
+                res['config']['config4_share_of_8'] = {
+                    'what': "BASELINE config 4 at N = 8, one GPU's share: rank 0's block of the fixed 64-utterance corpus (942 segments), run alone on this GPU",
+                    'segments': hi4 - lo4, 'segment_steps_per_s': round((hi4 - lo4) * T / d4, 1), 'ms_per_pass': round(d4 * 1e3, 3),
+                    'loop_kernel_ms': round(k4, 3), 'split': i4,
+                    'mfma_frac': round(2.0 * nnz * (hi4 - lo4) * T / (k4 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 5),
+                    'corpus_realtime_factor_if_8_gpus_ran_at_this_rate': round(sum((n - 1) * hop for n in f4) / d4 / SAMPLE_RATE, 1)}
+                del m4
+            except Exception as e:
+                res['config']['config4_share_of_8'] = {'error': repr(e)}
             # the other two single-GPU configurations of BASELINE.json on the SAME 16-utterance geometry, so that they are in the
             # driver's record too: the bit-exact 9-bit mu-law mode (config 1's model, batched) and config 5 (95 % block-sparse GRUs)
             def side_config(sd2, mode2, label):

@@ -77,3 +77,24 @@ def test_sharded_corpus_equals_single_process(tmp_path, mode, world):
             assert np.array_equal(single[u], ref), np.abs(single[u] - ref).max()
         else:
             assert np.abs(single[u] - ref).max() <= MOL_TOL
+
+
+def test_emulated_shard_equals_the_rank_it_stands_for():
+    """`generate_corpus(..., shard=(r, w))` (no process group: how bench.py shows one GPU's share of BASELINE config 4 at N = 1) does
+    what rank r of a w-rank job does on its own: the utterances lying entirely in its block of the segment table come out equal to the
+    single-process run, the others are left to the ranks that own their first segment / need the gather."""
+    from wavernn_amd.batch import generate_corpus, plan_utterances, shard_bounds
+    sd, model, mels = _build('MOL')
+    single = generate_corpus(model, mels, TARGET, OVERLAP, True, SEEDS, loop_fn=oracle_loop_fn(sd, 'MOL'))
+    plan = plan_utterances([n * 275 for n in FRAMES], TARGET, OVERLAP)
+    seen = 0
+    for r in range(2):
+        lo, hi = shard_bounds(plan.n_segments, 2)[r]
+        outs = generate_corpus(model, mels, TARGET, OVERLAP, True, SEEDS, loop_fn=oracle_loop_fn(sd, 'MOL'), shard=(r, 2))
+        for u in range(len(FRAMES)):
+            inside = lo <= plan.first[u] and plan.first[u] + plan.folds[u] <= hi
+            assert (outs[u] is not None) == bool(inside)
+            if inside:
+                assert np.array_equal(outs[u], single[u])
+                seen += 1
+    assert seen >= 2

@@ -126,7 +126,7 @@ def chunk_utterances(plan: Plan, lo: int, hi: int, max_segments: int):
 
 def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bool, seeds: Optional[Sequence[int]] = None,
                     group=None, loop_fn=None, return_segments=False, noise_source='cpu', finish='all', check=True,
-                    max_segments_per_launch: int = 4096):
+                    max_segments_per_launch: int = 4096, shard=None):
     """Generate every utterance of `mels` (each (1, feat, N_u) or (feat, N_u)) with `model` (a `wavernn_amd.WaveRNN`),
     batched, sharding the folded segments over the ranks of `group` (None = single process).
 
@@ -142,6 +142,9 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
     conditioning (320 B per audio sample) and the sampling noise of only one chunk are resident at a time; the loop's own
     workspace does not grow with the corpus (conditioning slabs, `wrnn_workspace_bytes_segments`).
 
+    shard=(r, w), without a group: do what rank r of a w-rank job does on its own -- its block of the segment table, the post-loop
+    stage of the utterances lying entirely in it -- with no collective (how bench.py shows a GPU's share of config 4 at N = 1).
+
     loop_fn(mels_up, aux, seg_pos, seg_lim, T, noise, hop) -> (n, T) tensor replaces the HIP loop (tests inject a CPU
     stand-in to exercise the sharding / gather logic under gloo); the default is the model's LoopEngine.
     """
@@ -152,6 +155,11 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
                          "pass noise_source='device' to draw from the device generator instead")
     world = dist.get_world_size(group) if group is not None else 1
     rank = dist.get_rank(group) if group is not None else 0
+    if shard is not None:
+        if group is not None:
+            raise ValueError('shard=(rank, world) emulates a rank without a process group')
+        rank, world = int(shard[0]), int(shard[1])
+        finish = 'own'
     device = next(model.parameters()).device
     mode = model.mode
     mu_law = mu_law if mode == 'RAW' else False
@@ -236,6 +244,8 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
     def gathered_segments():
         nonlocal work
         if group is None:
+            if shard is not None:
+                raise ValueError('an emulated shard has only its own block of segments')
             return out_local[:plan.n_segments]
         if work is not None:
             work.wait()
@@ -274,6 +284,8 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
             outs[u] = _fold.finish_waveform(y, (frames[u] - 1) * hop, hop)
 
     unfold(out_local, lambda u: int(plan.first[u]) - lo, local_u)          # under the all-gather
+    if shard is not None:
+        return outs
     if rest_u:
         unfold(gathered_segments(), lambda u: int(plan.first[u]), rest_u)
     elif work is not None:
