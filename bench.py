@@ -498,12 +498,13 @@ def main():
                 res['config']['config4_share_of_8'] = {'error': repr(e)}
             # the other two single-GPU configurations of BASELINE.json on the SAME 16-utterance geometry, so that they are in the
             # driver's record too: the bit-exact 9-bit mu-law mode (config 1's model, batched) and config 5 (95 % block-sparse GRUs)
-            def side_config(sd2, mode2, label):
+            def side_config(sd2, mode2, label, algo2='auto'):
                 try:
                     m2 = WaveRNN(**SHIPPED, mode=mode2)
                     m2.num_params = lambda *a, **k: 0
                     m2.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd2.items()}, strict=True)
                     m2 = m2.to(dev).eval()
+                    m2.loop_algo = algo2
                     e2 = m2._loop_engine()
 
                     def p2():
@@ -530,7 +531,9 @@ def main():
             res['config']['raw'] = side_config(random_state_dict(0, mode='RAW'), 'RAW', "9-bit mu-law ('bits', the bit-exact mode) on the same batch")
             from wavernn_amd.prune import block_prune_state_dict
             res['config']['config5'] = side_config(block_prune_state_dict(random_state_dict(0, mode='MOL'), 0.95, (16, 1))[0], 'MOL',
-                                                   'BASELINE config 5: GRU matrices 95 % block-sparse (16x1 blocks) on the same batch')
+                                                   'BASELINE config 5: GRU matrices 95 % block-sparse (16x1 blocks) on the same batch, `auto` kernel')
+            res['config']['config5_sparse_kernel'] = side_config(block_prune_state_dict(random_state_dict(0, mode='MOL'), 0.95, (16, 1))[0], 'MOL',
+                                                                 'BASELINE config 5 on wrnn_sparse_kernel (algo = sparse: the round-1 block-sparse kernel)', algo2='sparse')
         if not args.no_cpu_baseline and world == 1:
             try:
                 res['cpu_baseline'] = cpu_baseline(sd, mode, args.frames, target, overlap, args.cpu_seconds)

@@ -234,8 +234,15 @@ def test_block_sparse_kernel_full_length_matches_oracle(gpu):
     plan, mels_up, aux, flat, refs = _corpus_inputs(sd, 'MOL', [641, 641], [1234, 1235], [77, 78])
     eng = LoopEngine(sd, 'MOL', device=gpu)
     out = eng.run_segments(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), plan.seg_pos, plan.seg_lim, plan.T,
-                           torch.from_numpy(flat).to(gpu), HOP, algo='auto').cpu().numpy()
+                           torch.from_numpy(flat).to(gpu), HOP, algo='sparse').cpu().numpy()
     assert eng.last_loop_kernel() == 'wrnn_sparse_kernel'
+    for u, ref in enumerate(refs):
+        got = out[plan.first[u]:plan.first[u] + plan.folds[u]]
+        assert np.abs(got - ref).max() <= MOL_TOL, (u, np.abs(got - ref).max())
+    # round 4: `auto` runs a block-sparse pack on the (faster) dense wrnn_duo_kernel; same weights, same bar
+    out = eng.run_segments(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), plan.seg_pos, plan.seg_lim, plan.T,
+                           torch.from_numpy(flat).to(gpu), HOP, algo='auto').cpu().numpy()
+    assert eng.last_loop_kernel() == 'wrnn_duo_kernel'
     for u, ref in enumerate(refs):
         got = out[plan.first[u]:plan.first[u] + plan.folds[u]]
         assert np.abs(got - ref).max() <= MOL_TOL, (u, np.abs(got - ref).max())

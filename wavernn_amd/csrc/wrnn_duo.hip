@@ -50,6 +50,9 @@ namespace wrnn {
 #ifndef DUO_POLL_SLEEP
 #define DUO_POLL_SLEEP 1                     // s_sleep(n) between two polls of a layer; 0 = none
 #endif
+#ifndef DUO_RAW_LOCK
+#define DUO_RAW_LOCK 4                       // RAW sampler: segments of a wave handled in lock step (4 = all of them: 13 VGPR spills in that role; 2: none?)
+#endif
 #ifndef DUO_XR_FIRST
 #define DUO_XR_FIRST 1                       // 1 = the residual sum (on a slot's chain) is published before h (read a step later)
 #endif
@@ -818,24 +821,21 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
 #pragma unroll
                 for (int r = 0; r < 8; ++r) *reinterpret_cast<float4 *>(lp + 16 * r) = make_float4(b[4 * r], b[4 * r + 1], b[4 * r + 2], b[4 * r + 3]);
             }
-            // the Exp(1) variates of this wave's 4 segments (2 KB per segment): requested now, needed after the two softmax passes
-            float qn[4][8];
-            {
+            lds_barrier();
+            // One wave per 4 segments, DUO_RAW_LOCK of them in lock step (straight-line code: that many independent butterfly chains in
+            // flight); per segment the operation order is the reference's.  The Exp(1) variates (2 KB per segment and step, streamed
+            // from HBM) are requested before the softmax passes that do not need them yet.
+#pragma unroll
+            for (int h0 = 0; h0 < 4; h0 += DUO_RAW_LOCK) {
+                constexpr int NS = DUO_RAW_LOCK;
+                float qn[NS][8], lg[NS][8], mx[NS], sum[NS], sum2[NS], best[NS];
+                int bidx[NS];
                 const size_t tn = (size_t)(t - noise_t0);
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const int sjc = (4 * w + s4 < nb) ? 4 * w + s4 : nb - 1;
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    const int sjc = (4 * w + h0 + s4 < nb) ? 4 * w + h0 + s4 : nb - 1;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) qn[s4][e] = noise_raw[(tn * Nall + b0 + sjc) * C + lane + 64 * e];
-                }
-            }
-            lds_barrier();
-            {
-                float lg[4][8], mx[4], sum[4], sum2[4], best[4];
-                int bidx[4];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const int sjc = (4 * w + s4 < nb) ? 4 * w + s4 : nb - 1;
                     mx[s4] = -INFINITY;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -845,17 +845,17 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
                 }
                 if (dbgl) {
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4)
-                        if (4 * w + s4 < nb)
+                    for (int s4 = 0; s4 < NS; ++s4)
+                        if (4 * w + h0 + s4 < nb)
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) dbgl[((size_t)t * Nall + b0 + 4 * w + s4) * C + lane + 64 * e] = lg[s4][e];
+                            for (int e = 0; e < 8; ++e) dbgl[((size_t)t * Nall + b0 + 4 * w + h0 + s4) * C + lane + 64 * e] = lg[s4][e];
                 }
 #pragma unroll
                 for (int m = 32; m >= 1; m >>= 1)
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) mx[s4] = fmaxf(mx[s4], __shfl_xor(mx[s4], m, 64));
+                    for (int s4 = 0; s4 < NS; ++s4) mx[s4] = fmaxf(mx[s4], __shfl_xor(mx[s4], m, 64));
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
+                for (int s4 = 0; s4 < NS; ++s4) {
                     sum[s4] = 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { lg[s4][e] = expf(lg[s4][e] - mx[s4]); sum[s4] += lg[s4][e]; }
@@ -863,9 +863,9 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
 #pragma unroll
                 for (int m = 32; m >= 1; m >>= 1)
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) sum[s4] += __shfl_xor(sum[s4], m, 64);
+                    for (int s4 = 0; s4 < NS; ++s4) sum[s4] += __shfl_xor(sum[s4], m, 64);
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
+                for (int s4 = 0; s4 < NS; ++s4) {
                     sum2[s4] = 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { lg[s4][e] = lg[s4][e] / sum[s4]; sum2[s4] += lg[s4][e]; }
@@ -873,9 +873,9 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
 #pragma unroll
                 for (int m = 32; m >= 1; m >>= 1)
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) sum2[s4] += __shfl_xor(sum2[s4], m, 64);
+                    for (int s4 = 0; s4 < NS; ++s4) sum2[s4] += __shfl_xor(sum2[s4], m, 64);
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
+                for (int s4 = 0; s4 < NS; ++s4) {
                     best[s4] = -INFINITY;
                     bidx[s4] = 0;
 #pragma unroll
@@ -887,15 +887,15 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
 #pragma unroll
                 for (int m = 32; m >= 1; m >>= 1)
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
+                    for (int s4 = 0; s4 < NS; ++s4) {
                         const float ob = __shfl_xor(best[s4], m, 64);
                         const int oi = __shfl_xor(bidx[s4], m, 64);
                         if (ob > best[s4] || (ob == best[s4] && oi < bidx[s4])) { best[s4] = ob; bidx[s4] = oi; }
                     }
                 if (lane == 0) {
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const int sj = 4 * w + s4;
+                    for (int s4 = 0; s4 < NS; ++s4) {
+                        const int sj = 4 * w + h0 + s4;
                         if (sj < nb) {
                             float xv = 2.f * (float)bidx[s4] / ((float)C - 1.f) - 1.f;
                             outp[(size_t)(b0 + sj) * Tall + t] = xv;
