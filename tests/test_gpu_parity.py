@@ -97,7 +97,7 @@ def _skip_unless_supported(mode, opts):
 def test_device_selftests(gpu):
     from wavernn_amd import _lib
     L = _lib.lib()
-    assert L.wrnn_abi_version() == 4
+    assert L.wrnn_abi_version() == 5
     assert L.wrnn_device_cus(0) > 0
     _lib.check(L.wrnn_selftest(0, 1), 'mfma selftest')
     print(L.wrnn_last_error().decode())

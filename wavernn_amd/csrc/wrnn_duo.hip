@@ -1056,9 +1056,10 @@ int duo_clusters(int n_cus)
     return ncl;
 }
 
-// Stage order, measured (profiles/r04a_probe_new.json, r04b_probe.json): loads first with 1-2 groups in flight (17.8 vs 18.3 us per step at
-// depth 2), publish first from 3 on (25.8 vs 26.1 at depth 4; equal at depth 8).
-constexpr int DUO_PUBFIRST_DEPTH = 3;
+// Stage order, measured on the final kernel (profiles/r04g_probe_{mol,raw}.json): publish first is faster or equal at every depth
+// (12.04 vs 12.48 us per step with one group in flight, 17.2 vs 17.2 with two, 20.9 vs 21.3 with three; RAW 39.3 vs 40.1 at depth 4);
+// loads first stays as an A/B switch.
+constexpr int DUO_PUBFIRST_DEPTH = 1;
 hipError_t launch_duo(const LoopArgs &args, int ncl, int mode, hipStream_t stream)
 {
     if (ncl < 1 || args.G < 1 || args.G > LMAXG || (mode == 1 && !args.fc3f) || !args.u1 || !args.xcc_tab) return hipErrorInvalidValue;
