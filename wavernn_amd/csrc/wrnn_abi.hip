@@ -738,7 +738,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                 c.t0 = s0; c.t1 = s1; c.rb0 = rb0; c.B = nr; c.NG = ngr;
                 if (!duo) HIPCHK(launch_cond_frag(c, p->n_cus, stream));
                 // every word of the exchange ring = the sentinel.  The duo kernel leaves its ring consistent at the end of a launch
-                // (every step re-arms the entries four steps ahead), so it needs the fill only where a round starts: the first
+                // (every step re-arms the entries it will write two or three steps later), so it needs the fill only where a round starts: the first
                 // launch of a call that starts at step 0, or any launch when several rounds share the buffer
                 if (!duo) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, XBUF_FLOATS * sizeof(float), stream));
                 else if (s0 == 0 || pl.rounds > 1 || (o->tuning & 4)) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, duo_xbuf_bytes(pl.G), stream));

@@ -35,11 +35,24 @@
 // stores are plain write-back stores that stay in that XCD's L2 (consumers always read with sc1 = L2-served loads): no fabric traffic
 // for those layers.  Everything else is written through (sc1) as before.
 //
-// Ring discipline (conservative form of wrnn_loop.hip's): 8 ring entries per layer; at step t a wave re-arms its own words of
-// entry (t + 4) % 8 -- data of step t - 4, which every consumer left behind long ago -- and drains its stores at step t + 1;
-// the entry is written again at step t + 4.  Any poll of that entry belongs to a consumer's step >= t + 4, which exists only if every
-// workgroup of the cluster has published something of its step t + 2 or later, i.e. has passed the drain of step t + 1: the re-arm is
-// visible before the poll.  The gh words {r, z, n, tag = consuming step + 1} and nothing else carry a tag: no re-arm for them.
+// Ring discipline: 4 ring entries per layer (by step), every word the sentinel until its step's value is stored.  (Round 3 ran 8 entries
+// and re-armed 4 ahead; with the layers that stay inside one XCD written by plain stores the ring's footprint decides whether those lines
+// ever leave the L2: 8 entries x 4 slots of h, gh, cI, y2 are 6-7 MB per XCD against 4 MB of L2 -- every stored byte was eventually evicted
+// to the fabric, profiles/r04h_summary.md -- 4 entries and a 2-entry gh ring are ~2 MB.)  Two facts bound the skew inside a cluster: an hh
+// workgroup polls h(t) of every ih workgroup, so it never runs ahead of one; an ih workgroup in step t + 1 holds x(t + 1), which needed
+// everything every ih workgroup publishes in step t, which needed every hh workgroup's gh(t), i.e. every hh workgroup has consumed h(t - 1).
+//   * layers an ih workgroup publishes (h, y, residual sum; DAHEAD_IH = 2): after the last poll of its step t a wave re-arms its own
+//     words of entry (t + 2) % 4 -- data of step t - 2, consumed by every hh workgroup (above) and by every ih workgroup (x(t - 1)
+//     needed it); the wave drains its stores at the top of step t + 1, before it publishes anything of that step; the entry is polled
+//     for step t + 2 by consumers that have consumed this wave's step t + 1 data: the re-arm is visible before the poll.  (Re-arming
+//     data of step t - 1 instead would race an hh workgroup that is a step behind.)
+//   * layers an hh workgroup publishes (cI, x_t, RAW logits; DAHEAD_HH = 3): at step t (cI: at the top of the step; x_t, logits: once
+//     this step's y2 is there) a wave drains, then re-arms its words of entry (t + 3) % 4 -- data of step t - 1: cI(t - 1) and
+//     x_t / logits of step t - 1 were consumed before h(t - 1) / y2(t) could exist; the next drain is at step t + 1, and a consumer that
+//     polls the entry for step t + 3 has seen something this wave published in step t + 2.
+//   * the gh words {r, z, n, tag = consuming step + 1} carry a tag instead of relying on a sentinel: no re-arm, and two ring entries
+//     suffice (the hh workgroup cannot start gh(t+3) before the ih workgroup has consumed gh(t+1): it needs h(t+2), which needs gh(t+2)).
+// A launch ends with every entry in the state the next step expects (kernel end drains everything): continuations need no refill.
 #include <type_traits>
 
 #include "wrnn_ring.h"
@@ -58,8 +71,10 @@ namespace wrnn {
 #endif
 
 constexpr int DNX = 17;                      // layers: 0 h1  1 h2  2 y1  3 y2  4 cI  5 x1  6 x2  7 x_t  8-11 gh1  12-15 gh2 ([32 unit blocks][256 threads][r, z, n, tag])  16 RAW logits
-constexpr int DRING = 8;
-constexpr int DAHEAD = 4;                    // re-arm distance (steps)
+constexpr int DRING = 4;                     // ring entries per layer (by step)
+constexpr int DAHEAD_IH = 2;                 // re-arm distance (steps) of the layers an ih workgroup publishes, see above
+constexpr int DAHEAD_HH = 3;                 // ... of the layers an hh workgroup publishes
+constexpr int DGHRING = 2;                   // ring entries of the tagged gh words (no sentinel, no re-arm: two suffice)
 constexpr int DNWGC = 4 * LNJ;               // workgroups per cluster (128)
 constexpr size_t DXBUF_FLOATS = (size_t)LMAXG * MAXCL * DNX * DRING * XT;      // [slot][cluster][layer][ring][XT]
 constexpr int DLOGS = 36;                    // as LOGS of wrnn_loop.hip
@@ -333,7 +348,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             const unsigned tag = (unsigned)bt + 1u;
             if (__builtin_expect(__any(live && g.w != tag), 0))
                 wait_for([&] { return !__any(live && g.w != tag); },
-                         [&] { g = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, sb + (L_GH + (J >> 3)) * DLAYERB, 16 /* sc1 */); },
+                         [&] { g = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, cbase + bi * (MAXCL * DSLOTB) + (L_GH + (J >> 3)) * DLAYERB + (bt & (DGHRING - 1)) * XTB, 16 /* sc1 */); },
                          status, dead, 0x500u | (LA ? 0u : 8u) | 6u, bt);
             ghr = __uint_as_float(g.x); ghz = __uint_as_float(g.y); ghn = __uint_as_float(g.z);
         } else if (resume) {                          // first step of a continuing launch: gh(t0), saved by the launch that ended there
@@ -416,7 +431,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
                 nc.c1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, H * 4, 0));
                 nc.c2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, 2 * H * 4, 0));
             }
-            if (t > T0) nc.gw = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, sb + (L_GH + (J >> 3)) * DLAYERB, 16 /* sc1 */);
+            if (t > T0) nc.gw = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, sbase + (L_GH + (J >> 3)) * DLAYERB + (t & (DGHRING - 1)) * XTB, 16 /* sc1 */);
         } else {
             soff_x = sb + L_P2 * DLAYERB;
 #pragma unroll
@@ -443,16 +458,16 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
                          status, dead, 0x500u | (LA ? 0u : 8u) | (unsigned)ph, t);
         }
         PHX(cur + 3);
+        if (ph == 0 && i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ring hygiene: last step's re-arm stores are out before anything of this step is published
         if (ph == 2 && i == nact - 1) {
-            // ring hygiene, once per step, after the last layer this workgroup polls in the step has arrived (see the header): drain, then
-            // re-arm this wave's own words of entry (t + 4) % 8 in the three layers it publishes, for every slot
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ring hygiene, once per step, after the last layer this workgroup polls in the step has arrived (see the header): re-arm this
+            // wave's own words of entry (t + 2) % 4 in the three layers it publishes, for every slot (drained at the top of the next step)
             const int which = lane >> 4;
             const int layer = which == 0 ? L_H : (which == 1 ? L_Y : L_XR);
             const bool lloc = ((locbits >> which) & 1) != 0;          // (NOT a select between the captured flags: a select of pointers to
                                                                       // captured locals keeps the whole closure -- every local -- in scratch)
             const int vo = layer * DLAYERB + J * 1024 + w * 256 + (lane & 15) * 16;
-            const int so = cbase + ((t + DAHEAD) & (DRING - 1)) * XTB;
+            const int so = cbase + ((t + DAHEAD_IH) & (DRING - 1)) * XTB;
             const u32x4 q = {SENT, SENT, SENT, SENT};
             if (which < 3) {
 #pragma unroll 1
@@ -501,7 +516,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         const int nb = slot_nb(i);
         const bool live = pj < nb;
         const int sbase = cbase + i * (MAXCL * DSLOTB);
-        const int so = sbase + (L_GH + (J >> 3)) * DLAYERB + (T1 & (DRING - 1)) * XTB;
+        const int so = sbase + (L_GH + (J >> 3)) * DLAYERB + (T1 & (DGHRING - 1)) * XTB;
         u32x4 gq = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, so, 16 /* sc1 */);
         const unsigned tag = (unsigned)T1 + 1u;
         wait_for([&] { return !__any(live && gq.w != tag); },
@@ -629,7 +644,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         const float g0 = get_partial<3>(PB, 0, pu, pj) + bh_r, g1 = get_partial<3>(PB, 1, pu, pj) + bh_z, g2 = get_partial<3>(PB, 2, pu, pj) + bh_n;
         if (pj < slot_nb(c.i)) {                        // one 16-byte word {r, z, n, tag} per (unit, segment): one store, its own flag (hand-off form R2)
             const u32x4 q = {__float_as_uint(g0), __float_as_uint(g1), __float_as_uint(g2), (unsigned)c.t + 2u};      // tag: consuming step (t + 1) + 1
-            const int so = cbase + c.i * (MAXCL * DSLOTB) + (L_GH + (J >> 3)) * DLAYERB + ((c.t + 1) & (DRING - 1)) * XTB;
+            const int so = cbase + c.i * (MAXCL * DSLOTB) + (L_GH + (J >> 3)) * DLAYERB + ((c.t + 1) & (DGHRING - 1)) * XTB;
             if (loc_h) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, voff_gh, so, 0);
             else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, voff_gh, so, 16 /* sc1 */);
         }
@@ -693,14 +708,14 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             }
         }
     };
-    // ring hygiene of layer 4 (see the header), once per step and wave: drain, then re-arm this wave's slots' blocks of entry (t + 4) % 8
+    // ring hygiene of layer 4 (see the header), once per step and wave, at the top of the step: drain, then re-arm this wave's slots' blocks of entry (t + 3) % 4
     auto cond_rearm = [&](int tt) {
         if constexpr (LA) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const u32x4 q = {SENT, SENT, SENT, SENT};
 #pragma unroll 1
             for (int i = w; i < nact; i += NW) {
-                const int so = cbase + i * (MAXCL * DSLOTB) + 4 * DLAYERB + ((tt + DAHEAD) & (DRING - 1)) * XTB;
+                const int so = cbase + i * (MAXCL * DSLOTB) + 4 * DLAYERB + ((tt + DAHEAD_HH) & (DRING - 1)) * XTB;
                 if (loc_h) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 0);
                 else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 16 /* sc1 */);
             }
@@ -763,11 +778,11 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         }
         PHX(cur + 3);
         if (kind == 2 && i == nact - 1) {
-            // RAW ring hygiene (see the header): drain, then re-arm this wave's quarter of the workgroup's logit block of every slot in entry (t + 4) % 8
+            // RAW ring hygiene (see the header): drain, then re-arm this wave's quarter of the workgroup's logit block of every slot in entry (t + 3) % 4
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane < 16) {
                 const u32x4 q = {SENT, SENT, SENT, SENT};
-                const int so = cbase + 16 * DLAYERB + ((t + DAHEAD) & (DRING - 1)) * XTB;
+                const int so = cbase + 16 * DLAYERB + ((t + DAHEAD_HH) & (DRING - 1)) * XTB;
 #pragma unroll 1
                 for (int i2 = 0; i2 < nact; ++i2) {
                     if (loc_h) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + w * 256 + lane * 16, so + i2 * (MAXCL * DSLOTB), 0);
@@ -776,12 +791,12 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             }
         }
         if (sampler && (kind == 3 || kind == 4)) {
-            // ring hygiene (see the header): drain, then re-arm the x_t words of the slot this workgroup samples in entry (t + 4) % 8
+            // ring hygiene (see the header): drain, then re-arm the x_t words of the slot this workgroup samples in entry (t + 3) % 4
             // (the gh words carry a step tag instead of relying on a sentinel: nothing to re-arm)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 48) {                           // the 4 x_t words of segments 4 w ..
                 const u32x4 q = {SENT, SENT, SENT, SENT};
-                __builtin_amdgcn_raw_buffer_store_b128(q, xrs, 16 * w, sbase + 7 * DLAYERB + ((t + DAHEAD) & (DRING - 1)) * XTB, 16 /* sc1 */);
+                __builtin_amdgcn_raw_buffer_store_b128(q, xrs, 16 * w, sbase + 7 * DLAYERB + ((t + DAHEAD_HH) & (DRING - 1)) * XTB, 16 /* sc1 */);
             }
         }
         float b[32];
@@ -940,6 +955,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     using BANY = std::integral_constant<int, BK_ANY>;
     cond_step(T0);                                      // (the step a launch starts with; every later one is formed a step ahead)
     for (; t < T1; ++t) {
+        cond_rearm(t);
         if (t + 1 < T1) cond_step(t + 1);
         stage(K1{}, BANY{}, 0);
 #pragma unroll 1
@@ -953,7 +969,6 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             for (int i = 1; i < nact; ++i) stage(K2{}, BLG{}, i);
             if (sampler) stage(K4{}, BLG{}, my_slot);
         }
-        cond_rearm(t);
     }
     cur = 0;
     if (pend == BK_GH) back_gh(cy);
