@@ -6,8 +6,9 @@ WaveRNN, ljspeech.wavernn.mol hparams, random-init weights, batched generation t
 one GPU's share of a serving batch / of config 4's corpus): `--utterances` random mels of `--frames` frames per
 GPU (default 16 x 641 frames = 16 x 8 s of audio -> 16 x 16 = 256 folded segments x T=12100 autoregressive steps; the
 same line also carries the 8-utterance batch of round 1 and BASELINE config 2's single-utterance calls, N = 481 / 1001).
-Timed region (mels already resident in HBM): up-sample network (HIP pre-loop kernels) -> per conditioning slab {hoisted
-conditioning -> the persistent loop kernel} -> [N>1: RCCL all-gather of the [n,T] audio] -> cross-fade/unfold on the
+Timed region (mels already resident in HBM): up-sample network (HIP pre-loop kernels: MelResNet + the first two up-sampling stages)
+-> per slab of steps {aux tables -> the persistent loop kernel, which forms the last up-sampling stage and the I-layer conditioning
+itself} -> [N>1: RCCL all-gather of the [n,T] audio] -> cross-fade/unfold on the
 device -> D2H of the float64 waveforms.  The WAV write is excluded (the CPU baseline excludes it too).  Sampling noise is
 drawn on the device (Philox), as the reference does when it runs on a GPU; `--parity-noise` uses the host
 MT19937 stream of the parity tests instead (adds ~25 M host RNG draws per pass).
@@ -412,6 +413,9 @@ def main():
                        'slab_steps': info['slab_steps'], 'units_per_workgroup': u_per_wg, 'clusters': ncl, 'groups_in_flight_per_cluster': depth,
                        'segment_steps_per_s': round(plan.n_segments * T * args.steps / dt, 1),
                        'noise': 'host MT19937 stream (parity mode)' if args.parity_noise else 'device Philox (as the reference on a GPU)',
+                       'mel_last_stage': 'formed inside the loop kernel from the x25 mel (no [L, 80] up-sampled mel is written)'
+                                         if (info['kernel'] == 'wrnn_duo_kernel' and getattr(model, 'mel_in_loop', False) and getattr(model, 'pre_algo', '') == 'native')
+                                         else 'materialised by the pre-loop kernels',
                        'parallelism': par},
         }
         # Which roofline bounds the loop: arithmetic intensity = 2n FLOP per 4 weight bytes = n/2 FLOP/B for n

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define WRNN_ABI_VERSION 5   /* v5 (round 4): WRNN_ALGO_DUO runs RAW too; `auto` never degrades inside the library (WRNN_ERR_RESIDENCY: the caller re-plans); tuning bits per kernel */
+#define WRNN_ABI_VERSION 6   /* v5 (round 4): WRNN_ALGO_DUO runs RAW too; `auto` never degrades inside the library (WRNN_ERR_RESIDENCY: the caller re-plans); tuning bits per kernel */
 
 enum {
     WRNN_OK = 0,
@@ -150,6 +150,19 @@ typedef struct wrnn_options {
      * one launch: they report once, at the end). */
     void (*progress)(int32_t steps_done, int32_t T, int32_t n_segments, void *user);
     void *progress_user;
+    /* the LAST up-sampling stage inside the loop (ABI v6; wrnn_duo_kernel only -- any other kernel: WRNN_ERR_ARG).  The reference
+     * up-samples the mel in three Stretch2d + box-conv stages and crops `indent` samples off both ends (fatchord_version.py:73-80,
+     * :86-88) before the loop reads one [M] row per sample.  With mel_stage = 1 the `mels_up` argument of wrnn_generate* is the INPUT of
+     * the last of those stages instead -- [mel_rows][M], what wrnn_pre_upsample_rows() writes: 1 / mel_scale of the rows -- and the loop
+     * forms the row of step t of segment b from the three input rows its 2 * mel_scale + 1 taps reach, at the un-cropped position
+     * j = seg_pos[b] + t + seg_moff[b] (one utterance: seg_moff = indent = pad * hop; utterance u of a concatenation whose S2 blocks
+     * follow one another: indent * (2 u + 1)).  seg_pos / seg_lim / L / aux keep their meaning (the cropped time line).
+     * This build: mel_scale == 11. */
+    int32_t mel_stage;       /* 0 = `mels_up` is the up-sampled mel [L, M] (default) */
+    int32_t mel_rows;        /* rows of `mels_up` when mel_stage = 1 */
+    int32_t mel_scale;       /* stretch factor of the last stage */
+    const float *mel_taps;   /* HOST [2 * mel_scale + 1]: upsample.up_layers.5.weight */
+    const int32_t *seg_moff; /* HOST [n_segments] */
 } wrnn_options;
 
 const char *wrnn_last_error(void);
@@ -260,6 +273,10 @@ size_t wrnn_pre_workspace_bytes(const wrnn_pre *p, int32_t n_frames);
  * left to the loop).  Several utterances: call once per utterance with offset output pointers.  Asynchronous on `stream`. */
 int wrnn_pre_upsample(const wrnn_pre *p, const float *mel, int32_t n_frames, float *mels_up, float *aux,
                       void *workspace, size_t workspace_bytes, void *stream);
+/* The same without the last Stretch2d + conv stage and its crop (ABI v6): mel_rows: device [(n_frames + 2 pad) * s0 * s1][feat], the input
+ * of the last stage, which wrnn_duo_kernel then forms inside the loop (wrnn_options.mel_stage = 1); aux as above. */
+int wrnn_pre_upsample_rows(const wrnn_pre *p, const float *mel, int32_t n_frames, float *mel_rows, float *aux,
+                           void *workspace, size_t workspace_bytes, void *stream);
 const char *wrnn_pre_last_error(void);
 
 /*

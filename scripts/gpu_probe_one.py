@@ -11,7 +11,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--algo', default='duo'); ap.add_argument('--depth', type=int, default=8); ap.add_argument('--B', type=int, default=512)
 ap.add_argument('--T', type=int, default=600); ap.add_argument('--reps', type=int, default=2); ap.add_argument('--mode', default='MOL')
 ap.add_argument('--tuning', type=int, default=0)
+ap.add_argument('--so', default=None, help='A/B builds: load this libwavernn_amd*.so instead of the in-tree one')
 a = ap.parse_args()
+if a.so:
+    from wavernn_amd import _lib as _L
+    _L.SO_PATH = os.path.abspath(a.so)
 dev = torch.device('cuda', 0)
 eng = LoopEngine(random_state_dict(0, mode=a.mode), a.mode, device=dev)
 rs = np.random.RandomState(3)

@@ -66,3 +66,44 @@ def probe_loop_fn(sd, mode):
         first = mels_up[torch.as_tensor(np.asarray(seg_pos, dtype=np.int64)), 0].cpu()
         return first[:, None].expand(len(seg_pos), T).contiguous()
     return fn
+
+
+def mel_rows_tap_sums(taps, scale):
+    """The three tap sums per phase that wrnn_generate_segments builds for `wrnn_options.mel_stage = 1` (csrc/wrnn_abi.hip): with
+    q = scale * a + ph the taps j < scale - ph of out(q) = sum_j w[j] rep(q + j - scale) fall on input row a - 1, the next `scale` on row
+    a, the last ph + 1 on row a + 1.  Restated here (float64 sums, rounded to float32) so the CPU tests can check the derivation."""
+    taps = np.asarray(taps, np.float64).reshape(-1)
+    assert taps.shape[0] == 2 * scale + 1
+    co = np.zeros((scale, 3), np.float32)
+    for ph in range(scale):
+        co[ph] = [taps[:scale - ph].sum(), taps[scale - ph:2 * scale - ph].sum(), taps[2 * scale - ph:].sum()]
+    return co
+
+
+def mel_rows_formula(rows, taps, j, scale=11):
+    """What wrnn_duo_kernel's `cond_tile_rows` forms for un-cropped positions j: fma(c2, r[a+1], fma(c1, r[a], c0 * r[a-1])) in float32
+    (each step rounded; the products are exact in float64).  rows [n_rows, feat] float32, j int array -> [len(j), feat] float32."""
+    co = mel_rows_tap_sums(taps, scale).astype(np.float64)
+    j = np.asarray(j, np.int64)
+    a, ph = j // scale, j % scale
+    assert a.min() >= 1 and a.max() + 1 < rows.shape[0]
+    r = rows.astype(np.float64)
+    acc = (co[ph, 0][:, None] * r[a - 1]).astype(np.float32).astype(np.float64)
+    acc = (co[ph, 1][:, None] * r[a] + acc).astype(np.float32).astype(np.float64)
+    return (co[ph, 2][:, None] * r[a + 1] + acc).astype(np.float32)
+
+
+def oracle_stage2_rows(sd, mel, pad=2, scales=(5, 5)):
+    """The oracle's UpsampleNetwork (oracle/wavernn_oracle.py `upsample_network`) up to the INPUT of its last stage, as [row][channel]:
+    [(N + 2 pad) * 25, 80] -- what `wrnn_pre_upsample_rows` writes."""
+    from oracle import wavernn_oracle as O
+    x = O.pad_tensor(mel.T[None].astype(np.float32), pad, 'both')[0].T
+    for li, s in enumerate(scales):
+        x = np.repeat(x, s, axis=1)
+        w = sd[f'upsample.up_layers.{2 * li + 1}.weight'].astype(np.float32).reshape(-1)
+        xp = np.pad(x, ((0, 0), (s, s)))
+        y = np.zeros_like(x)
+        for j in range(2 * s + 1):
+            y += w[j] * xp[:, j:j + x.shape[1]]
+        x = y.astype(np.float32)
+    return np.ascontiguousarray(x.T)

@@ -97,7 +97,7 @@ def _skip_unless_supported(mode, opts):
 def test_device_selftests(gpu):
     from wavernn_amd import _lib
     L = _lib.lib()
-    assert L.wrnn_abi_version() == 5
+    assert L.wrnn_abi_version() == 6
     assert L.wrnn_device_cus(0) > 0
     _lib.check(L.wrnn_selftest(0, 1), 'mfma selftest')
     print(L.wrnn_last_error().decode())
@@ -281,6 +281,88 @@ def test_pre_loop_kernels_match_reference_golden(gpu, name):
     np.testing.assert_allclose(mels_up.cpu().numpy()[::97], g['mels_up_strided'], rtol=0, atol=5e-6)
     rows = (np.arange(g['aux_up_strided'].shape[0]) * 97) // 275
     np.testing.assert_allclose(aux.cpu().numpy()[rows], g['aux_up_strided'], rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize('frames', [21, 100])
+def test_mel_rows_pre_kernel_matches_oracle(gpu, frames):
+    """`wrnn_pre_upsample_rows` (the pre-loop stage one up-sampling stage short) vs the oracle's UpsampleNetwork
+    stopped in front of its last stage; aux is the same tensor `wrnn_pre_upsample` writes."""
+    from helpers import oracle_stage2_rows
+    from wavernn_amd.pre import PreEngine
+    from wavernn_amd.synthetic import random_state_dict, random_mel
+    sd = random_state_dict(61, mode='MOL')
+    mel = random_mel(700 + frames, frames)
+    eng = PreEngine(sd, device=gpu)
+    rows, aux = eng.upsample_rows(torch.from_numpy(mel).to(gpu))
+    _, aux_full = eng.upsample(torch.from_numpy(mel).to(gpu))
+    assert rows.shape == ((frames + 4) * 25, 80) == (eng.rows_of(frames), 80) and eng.scales == [5, 5, 11] and eng.pad == 2
+    np.testing.assert_allclose(rows.cpu().numpy(), oracle_stage2_rows(sd, mel), rtol=0, atol=5e-6)
+    assert torch.equal(aux, aux_full)
+
+
+@pytest.mark.parametrize('mode', ['MOL', 'RAW'])
+def test_mel_rows_loop_equals_the_materialised_mel(gpu, mode):
+    """SURVEY.md 8 row f1, last part: wrnn_duo_kernel forms the LAST up-sampling stage (Stretch2d(11) + 23-tap conv + crop, reference
+    models/fatchord_version.py:73-80, :86-88) inside the loop from that stage's input (`engine.MelRows`, wrnn_options.mel_stage = 1): no
+    [L, 80] mel exists.  Three utterances concatenated (the per-utterance offsets of the un-cropped time line), trained-looking taps,
+    ragged last folds.  Against the same loop fed the materialised mel of `wrnn_pre_upsample`: teacher-forced logits of every step
+    within 1e-4 (the two mels differ by float32 rounding, ~1e-7), the free run within MOL_TOL (RAW: at most one segment may part ways --
+    a class index flipped by 1e-7 is legitimate, the reference goldens in test_generate_end_to_end hold the bit-exact bar); against
+    the oracle fed the oracle's own up-sampled mel: the same bounds."""
+    from oracle import c_oracle as C
+    from wavernn_amd.batch import plan_utterances
+    from wavernn_amd.engine import LoopEngine, MelRows
+    from wavernn_amd.pre import PreEngine
+    from wavernn_amd.synthetic import random_state_dict, random_mel
+    from wavernn_amd import _lib
+    sd = dict(random_state_dict(23, mode=mode))
+    sd['upsample.up_layers.5.weight'] = (np.random.default_rng(1).random((1, 1, 1, 23)) / 12).astype(np.float32)
+    frames, hop, target, overlap = [33, 21, 47], 275, 1100, 55
+    plan = plan_utterances([n * hop for n in frames], target, overlap)
+    pre, eng = PreEngine(sd, device=gpu), LoopEngine(sd, mode, device=gpu)
+    ups, rows, auxs = [], [], []
+    for k, n in enumerate(frames):
+        mel = torch.from_numpy(random_mel(900 + k, n)).to(gpu)
+        mu, au = pre.upsample(mel)
+        ups.append(mu); auxs.append(au); rows.append(pre.upsample_rows(mel)[0])
+    mels_up, aux, rows = torch.cat(ups).contiguous(), torch.cat(auxs).contiguous(), torch.cat(rows).contiguous()
+    indent = pre.pad * hop
+    seg_off = np.array([indent * (2 * int(u) + 1) for u in plan.seg_utt], dtype=np.int32)
+    mr = MelRows(rows, mels_up.shape[0], pre.scales[2], pre.last_taps, seg_off)
+    n, T = plan.n_segments, plan.T
+    g = torch.Generator().manual_seed(5)
+    if mode == 'MOL':
+        noise = torch.rand(T, 11 * n, generator=g) * (1 - 2e-5) + 1e-5
+        force = torch.rand(n, T, generator=g) * 2 - 1
+    else:
+        noise = -torch.log(torch.rand(T, n, 512, generator=g).clamp_min(1e-30))
+        force = torch.randint(0, 512, (n, T), generator=g).float() * (2.0 / 511) - 1
+    noise = noise.to(gpu).contiguous()
+    kw = dict(algo='duo', slab_steps=300)
+    _, lg_a = eng.run_segments(mels_up, aux, plan.seg_pos, plan.seg_lim, T, noise, hop, force_x=force, want_logits=True, **kw)
+    _, lg_b = eng.run_segments(mr, aux, plan.seg_pos, plan.seg_lim, T, noise, hop, force_x=force, want_logits=True, **kw)
+    assert eng.last_loop_kernel() == 'wrnn_duo_kernel' and eng.last_run_info()['launches'] >= 4
+    err = (lg_a - lg_b).abs().max().item()
+    assert err <= 1e-4, err
+    a = eng.run_segments(mels_up, aux, plan.seg_pos, plan.seg_lim, T, noise, hop, **kw).cpu().numpy()
+    b = eng.run_segments(mr, aux, plan.seg_pos, plan.seg_lim, T, noise, hop, **kw).cpu().numpy()
+    # ... continued in slices, at two depths
+    c = None
+    for t0, t1 in ((0, 500), (500, T)):
+        c = eng.run_segments(mr, aux, plan.seg_pos, plan.seg_lim, T, noise[t0:t1].contiguous(), hop, algo='duo', depth=2, clusters=1,
+                             t_range=(t0, t1), out=c)
+    assert np.array_equal(c.cpu().numpy(), b)
+    if mode == 'MOL':
+        assert np.abs(a - b).max() <= MOL_TOL, np.abs(a - b).max()
+    else:
+        assert np.count_nonzero((a != b).any(axis=1)) <= 1, np.argwhere(a != b)[:4]
+    print(f'{mode}: mel formed in the loop vs materialised: logits {err:.2e}, free run max |d| {np.abs(a - b).max():.2e}')
+    # the other loop kernels read the up-sampled mel: asking them for the last stage is an argument error, not a silent mis-read
+    with pytest.raises(_lib.WrnnError, match='mel_stage'):
+        eng.run_segments(mr, aux, plan.seg_pos, plan.seg_lim, T, noise, hop, algo='loop')
+    # ... and so is a segment whose rows would lie outside the buffer
+    with pytest.raises(_lib.WrnnError, match='input rows'):
+        eng.run_segments(MelRows(rows[:-30].contiguous(), mels_up.shape[0], 11, pre.last_taps, seg_off), aux, plan.seg_pos, plan.seg_lim, T, noise, hop, **kw)
 
 
 @pytest.mark.parametrize('mode,mu_law,batched', [('RAW', True, True), ('RAW', False, True), ('MOL', False, True), ('RAW', True, False)])

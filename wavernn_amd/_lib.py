@@ -14,7 +14,7 @@ SO_PATH = os.path.join(CSRC, 'libwavernn_amd.so')
 WRNN_OK = 0
 ERR_RESIDENCY = -6          # WRNN_ERR_RESIDENCY: the persistent grid cannot be co-resident on this device
 MODE_RAW, MODE_MOL = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 ALGO_AUTO, ALGO_STREAM, ALGO_LOOP, ALGO_SPARSE, ALGO_DUO = 0, 1, 2, 5, 6
 ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'loop': ALGO_LOOP, 'sparse': ALGO_SPARSE, 'duo': ALGO_DUO}
 
@@ -23,7 +23,7 @@ EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_
            'wrnn_pack_weight_bytes', 'wrnn_pack_sparse_blocks', 'wrnn_workspace_bytes', 'wrnn_workspace_bytes_segments', 'wrnn_generate',
            'wrnn_generate_segments', 'wrnn_plan_segments', 'wrnn_status', 'wrnn_timer_create', 'wrnn_timer_destroy', 'wrnn_timer_ms',
            'wrnn_timer_launches', 'wrnn_debug_read_exchange', 'wrnn_selftest', 'wrnn_selftest_metric', 'wrnn_pre_create',
-           'wrnn_pre_destroy', 'wrnn_pre_hop', 'wrnn_pre_workspace_bytes', 'wrnn_pre_upsample', 'wrnn_pre_last_error',
+           'wrnn_pre_destroy', 'wrnn_pre_hop', 'wrnn_pre_workspace_bytes', 'wrnn_pre_upsample', 'wrnn_pre_upsample_rows', 'wrnn_pre_last_error',
            'wrnn_post_unfold', 'wrnn_post_last_error', 'wrnn_taco_workspace_bytes', 'wrnn_taco_decode', 'wrnn_taco_status',
            'wrnn_taco_last_error', 'wrnn_bigru']
 
@@ -81,7 +81,9 @@ class Options(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('struct_bytes', 'algo', 'depth', 'clusters', 'cond_valu', 'slab_steps', 't_begin',
                                               't_end', 'tuning')] + \
                [('force_x', ctypes.c_void_p), ('logits', ctypes.c_void_p), ('phase_clocks', ctypes.c_void_p), ('timer', ctypes.c_void_p),
-                ('info', ctypes.POINTER(RunInfo)), ('progress', ctypes.c_void_p), ('progress_user', ctypes.c_void_p)]
+                ('info', ctypes.POINTER(RunInfo)), ('progress', ctypes.c_void_p), ('progress_user', ctypes.c_void_p),
+                ('mel_stage', ctypes.c_int32), ('mel_rows', ctypes.c_int32), ('mel_scale', ctypes.c_int32),
+                ('mel_taps', ctypes.c_void_p), ('seg_moff', ctypes.c_void_p)]
 
     def __init__(self, **kw):
         super().__init__(**kw)
@@ -168,6 +170,7 @@ def lib():
     L.wrnn_pre_workspace_bytes.restype = ctypes.c_size_t
     L.wrnn_pre_upsample.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.wrnn_pre_upsample_rows.argtypes = L.wrnn_pre_upsample.argtypes
     L.wrnn_pre_last_error.restype = ctypes.c_char_p
     L.wrnn_post_unfold.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,

@@ -183,16 +183,34 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
             for u in utts:
                 local_off[u] = off
                 off += frames[u] * hop
-            if native_pre:     # the pre-loop kernels write straight into their slices of the concatenated buffers
-                mels_up = torch.empty(off, mels[utts[0]].size(1), dtype=torch.float32, device=device)
-                aux = torch.empty(off // hop, 4 * model.aux_dims, dtype=torch.float32, device=device)
-                pre = model._pre_engine()
-                for u in utts:
-                    a0 = local_off[u]
-                    pre.upsample(mels[u].to(device).float(), mels_up=mels_up[a0:a0 + frames[u] * hop], aux=aux[a0 // hop:a0 // hop + frames[u]])
-            else:
+            n_seg, T = chi - clo, plan.T
+            eng = model._loop_engine() if loop_fn is None else None
+
+            def conditioning(rows):
+                """rows: the mel one up-sampling stage short (`engine.MelRows`; wrnn_duo_kernel forms the last stage in the loop)"""
+                if native_pre:     # the pre-loop kernels write straight into their slices of the concatenated buffers
+                    pre = model._pre_engine()
+                    n_rows = [pre.rows_of(frames[u]) for u in utts] if rows else None
+                    mels_up = torch.empty(sum(n_rows) if rows else off, mels[utts[0]].size(1), dtype=torch.float32, device=device)
+                    aux = torch.empty(off // hop, 4 * model.aux_dims, dtype=torch.float32, device=device)
+                    r0 = 0
+                    for k, u in enumerate(utts):
+                        a0 = local_off[u]
+                        if rows:
+                            pre.upsample_rows(mels[u].to(device).float(), rows=mels_up[r0:r0 + n_rows[k]], aux=aux[a0 // hop:a0 // hop + frames[u]])
+                            r0 += n_rows[k]
+                        else:
+                            pre.upsample(mels[u].to(device).float(), mels_up=mels_up[a0:a0 + frames[u] * hop], aux=aux[a0 // hop:a0 // hop + frames[u]])
+                    if rows:       # utterance k of the chunk: its rows start 2 * indent * k samples later than its cropped samples do
+                        from .engine import MelRows
+                        indent, order = pre.pad * hop, {u: k for k, u in enumerate(utts)}
+                        seg_off = np.array([indent * (2 * order[int(u)] + 1) for u in plan.seg_utt[clo:chi]], dtype=np.int32)
+                        mels_up = MelRows(mels_up, off, pre.scales[2], pre.last_taps, seg_off)
+                    return mels_up, aux
                 ups, auxs = zip(*[model.conditioning(mels[u])[:2] for u in utts])
-                mels_up, aux = torch.cat(ups).contiguous(), torch.cat(auxs).contiguous()
+                return torch.cat(ups).contiguous(), torch.cat(auxs).contiguous()
+            rows = eng is not None and native_pre and model.mel_rows_ok(eng, n_seg, T)
+            mels_up, aux = conditioning(rows)
             if noise_source == 'cpu':
                 for u in utts:
                     g = torch.Generator(device='cpu').manual_seed(int(seeds[u]))
@@ -202,9 +220,7 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
             rebase = np.array([local_off[int(u)] - int(plan.offsets[int(u)]) for u in plan.seg_utt[clo:chi]], dtype=np.int64)
             seg_pos = (plan.seg_pos[clo:chi].astype(np.int64) + rebase).astype(np.int32)
             seg_lim = (plan.seg_lim[clo:chi].astype(np.int64) + rebase).astype(np.int32)
-            n_seg, T = chi - clo, plan.T
             out_view = out_local[clo - lo:chi - lo]
-            eng = model._loop_engine() if loop_fn is None else None
             if noise_source == 'cpu':
                 nz = pack_noise(mode, plan, noise, clo, chi).to(device)
             elif eng is not None and eng.plan(n_seg, T, algo=model.loop_algo)['kernel'] in ('wrnn_loop_kernel', 'wrnn_duo_kernel'):
@@ -224,13 +240,22 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
                 except ResidencyError as e:     # the persistent grid was refused on the first slice: the whole chunk on the stream kernel
                     import warnings
                     warnings.warn(f'wavernn_amd: {e}; using the stream kernel')
+                    if rows:
+                        mels_up, aux = conditioning(False)
                     nz = draw_noise(mode, n_seg, T, model.n_classes, model.rnn_dims, model.aux_dims, device, 'device')
                     eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo='stream', check=check, out=out_view)
                     continue
             else:
                 nz = draw_noise(mode, n_seg, T, model.n_classes, model.rnn_dims, model.aux_dims, device, 'device')
             if loop_fn is None:
-                eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo=model.loop_algo, check=check, out=out_view)
+                from ._lib import ResidencyError
+                try:
+                    eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo=model.loop_algo, check=check, out=out_view)
+                except ResidencyError:
+                    if not rows:
+                        raise
+                    mels_up, aux = conditioning(False)      # (the other loop kernels read the up-sampled mel; the engine degrades as usual)
+                    eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo=model.loop_algo, check=check, out=out_view)
             else:
                 out_view[:] = loop_fn(mels_up, aux, seg_pos, seg_lim, T, nz, hop)
     # ---- the ONE collective of the path: an all-gather of the finished audio, asynchronous so that the utterances lying entirely in

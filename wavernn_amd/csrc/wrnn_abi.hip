@@ -387,7 +387,7 @@ struct Plan {
 };
 
 struct WsLayout {
-    size_t status, xcc, segs, c2f, c3f, c4f;
+    size_t status, xcc, segs, melc, c2f, c3f, c4f;
     size_t gran, cI, npre;              // stream / sparse kernels: granules, whole-T conditioning, derived MOL noise
     size_t xbuf, state, cIf;            // loop kernel: exchange buffer, per-round state, conditioning slab
     size_t total;
@@ -508,7 +508,8 @@ WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frame
     size_t o = 0;
     l.status = o; o = al(o + STATUS_WORDS * sizeof(unsigned));
     l.xcc = o;    o = al(o + XCC_WORDS * sizeof(unsigned));
-    l.segs = o;   o = al(o + (size_t)2 * B * sizeof(int));
+    l.segs = o;   o = al(o + (size_t)3 * B * sizeof(int));       // positions | limits | mel offsets (wrnn_options.mel_stage)
+    l.melc = o;   o = al(o + (size_t)3 * LAST_SCALE * sizeof(float));
     if (pl.kind == K_GENERIC) { l.total = o; return l; }
     // per-frame aux tables: one row per frame of the call's conditioning (+ the zero row) -- or, for wrnn_duo_kernel, per SEGMENT and
     // slab: (slab - 1) / hop + 2 rows per segment (+ the zero row), refilled for every slab: independent of the corpus' length
@@ -651,6 +652,37 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     HIPCHK(hipMemcpyAsync(ws + l.segs, seg_pos, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(ws + l.segs + (size_t)B * sizeof(int), seg_lim, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
     const int *d_pos = (const int *)(ws + l.segs), *d_lim = d_pos + B;
+    if (o->mel_stage) {
+        // the last up-sampling stage inside the loop: `mels_up` is that stage's input.  Everything is checked here, on the host: the
+        // kernel reads rows j / s - 1 .. j / s + 1 without a bound.
+        if (pl.kind != K_DUO) { set_err("wrnn_options.mel_stage: only wrnn_duo_kernel forms the last up-sampling stage (this call runs on another kernel)"); return WRNN_ERR_ARG; }
+        if (o->mel_stage != 1 || o->mel_scale != LAST_SCALE || !o->mel_taps || !o->seg_moff || o->mel_rows < 3) {
+            set_err("wrnn_options.mel_stage=%d: needs mel_scale == %d (got %d), mel_taps, seg_moff, mel_rows >= 3", o->mel_stage, LAST_SCALE, o->mel_scale);
+            return WRNN_ERR_ARG;
+        }
+        for (int b = 0; b < B; ++b) {
+            const long last = (seg_lim[b] < (long)seg_pos[b] + T ? seg_lim[b] : (long)seg_pos[b] + T) - 1;      // last position that is not zero padding
+            if (last < seg_pos[b]) continue;
+            const long j0 = (long)seg_pos[b] + o->seg_moff[b], j1 = last + o->seg_moff[b];
+            if (o->seg_moff[b] < 0 || j0 / LAST_SCALE < 1 || j1 / LAST_SCALE + 1 >= o->mel_rows) {
+                set_err("segment %d: positions %ld..%ld of the last up-sampling stage reach outside its %d input rows", b, j0, j1, o->mel_rows);
+                return WRNN_ERR_ARG;
+            }
+        }
+        // out(q) = sum_j w[j] rep(q + j - s), rep(u) = in[u / s]: with q = s a + ph the taps j < s - ph fall on row a - 1, the next s on
+        // row a, the last ph + 1 on row a + 1
+        float coef[3 * LAST_SCALE];
+        for (int ph = 0; ph < LAST_SCALE; ++ph) {
+            double c0 = 0, c1 = 0, c2 = 0;
+            for (int j = 0; j <= 2 * LAST_SCALE; ++j) {
+                const double w = o->mel_taps[j];
+                if (j < LAST_SCALE - ph) c0 += w; else if (j < 2 * LAST_SCALE - ph) c1 += w; else c2 += w;
+            }
+            coef[3 * ph] = (float)c0; coef[3 * ph + 1] = (float)c1; coef[3 * ph + 2] = (float)c2;
+        }
+        HIPCHK(hipMemcpyAsync(ws + l.segs + (size_t)2 * B * sizeof(int), o->seg_moff, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ws + l.melc, coef, sizeof coef, hipMemcpyHostToDevice, stream));
+    }
     if (pl.kind == K_GENERIC) {
         GenArgs g;
         memset(&g, 0, sizeof g);
@@ -701,6 +733,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     a.Nall = B;
     a.xcc_tab = (unsigned *)(ws + l.xcc);
     a.mels_up = mels_up; a.aux_fr = aux; a.I_cT = p->I_cT; a.I_b = p->I_b;
+    a.mel_stage = o->mel_stage; a.seg_moff = d_pos + 2 * B; a.mel_coef = (const float *)(ws + l.melc);
     hop_magic(hop, &a.hop_magic, &a.hop_shift);
 
     wrnn_run_info info;

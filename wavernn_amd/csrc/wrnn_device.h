@@ -30,6 +30,7 @@ constexpr int H = 512;        // rnn_dims == fc_dims (this build)
 constexpr int MEL = 80;       // feat_dims
 constexpr int AUX = 32;       // aux_dims = res_out_dims / 4
 constexpr int KCOND = MEL + AUX;   // conditioning inputs of the I layer (112)
+constexpr int LAST_SCALE = 11;     // stretch factor of the last up-sampling stage when wrnn_duo_kernel forms it in the loop (hparams.py: voc_upsample_factors[2])
 constexpr int SEG = 16;       // segments per persistent launch group (= MFMA N)
 constexpr int LDA = 516;      // padded row stride (floats) of the LDS activation tiles
 constexpr int NGRAN = 5;      // granule buffers: h1, h2, y1, y2, (RAW) logits
@@ -100,6 +101,12 @@ struct LoopArgs {
     int hop_shift;
     const float *mels_up, *aux_fr;      // [L][MEL], [NF][4 AUX]: the conditioning itself (wrnn_duo.hip forms cI(t) in the loop: SURVEY.md 8 row f1)
     const float *I_cT, *I_b;            // [KCOND][H] transposed I.weight[:, 1:], [H] I.bias
+    // the LAST up-sampling stage (Stretch2d(11) + its 23-tap conv + the crop, fatchord_version.py:73-80, :86-88) formed in the loop too:
+    // mel_stage != 0: `mels_up` is that stage's INPUT [rows][MEL]; step t of segment b sits at un-cropped position j = seg_pos[b] + t +
+    // seg_moff[b], and mel(j) = c[ph][0] row(j/11 - 1) + c[ph][1] row(j/11) + c[ph][2] row(j/11 + 1), ph = j % 11, c = mel_coef[11][3]
+    int mel_stage;
+    const int *seg_moff;                // [Btot]
+    const float *mel_coef;              // [LAST_SCALE][3]: sums of the conv taps that fall on each of the three rows
     int tab_fps, tab_t0;                // wrnn_duo.hip: c2f / c3f / c4f are per-SEGMENT tables of the slab that starts at step tab_t0: row
                                         // (segment index in the call) * tab_fps + frame - (seg_pos + tab_t0) / hop; zero row = Nall * tab_fps
     unsigned *xcc_tab;                  // [MAXCL * 128] zeroed before every launch: XCC id + 1 of every workgroup (placement handshake)

@@ -76,11 +76,19 @@ constexpr int DAHEAD_IH = 2;                 // re-arm distance (steps) of the l
 constexpr int DAHEAD_HH = 3;                 // ... of the layers an hh workgroup publishes
 constexpr int DGHRING = 2;                   // ring entries of the tagged gh words (no sentinel, no re-arm: two suffice)
 constexpr int DNWGC = 4 * LNJ;               // workgroups per cluster (128)
-constexpr size_t DXBUF_FLOATS = (size_t)LMAXG * MAXCL * DNX * DRING * XT;      // [slot][cluster][layer][ring][XT]
+// One 32 KB entry of padding behind every layer's ring.  With 128 KB per layer every (slot, layer) ring starts 0 or 128 KB into a 256 KB
+// window -- the span of one way of the 4 MB / 16-way L2 -- and the entries an XCD keeps alive at depth 4 (80-96 of them) pile 20 deep onto
+// two eighths of the sets while two eighths stay empty: more lines than ways, touched cyclically = LRU's worst case, and the dirty lines
+// of the XCD-local layers are written back every step.  At 160 KB per layer the same entries land 10-12 deep on every eighth.
+#ifndef DUO_LAYER_PAD
+#define DUO_LAYER_PAD 1
+#endif
+constexpr int DLAYER_ENTRIES = DRING + DUO_LAYER_PAD;
+constexpr size_t DXBUF_FLOATS = (size_t)LMAXG * MAXCL * DNX * DLAYER_ENTRIES * XT;      // [slot][cluster][layer][ring (+ pad)][XT]
 constexpr int DLOGS = 36;                    // as LOGS of wrnn_loop.hip
 constexpr int DPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][tile 0..2][lane][4]
 constexpr int XTB = XT * 4;                  // bytes of one layer entry (32 KB)
-constexpr int DLAYERB = DRING * XTB;         // bytes of one layer's ring
+constexpr int DLAYERB = DLAYER_ENTRIES * XTB; // bytes of one layer's ring (+ pad)
 constexpr int DSLOTB = DNX * DLAYERB;        // bytes of one (slot, cluster)
 static_assert((size_t)LMAXG * MAXCL * DSLOTB < 0x7FFFFFFFull, "32-bit buffer offsets");
 // saved state of an ih workgroup's slot in global memory (the slot layout of wrnn_loop.hip, LGRP floats): [0, 768) gh(t1) of the
@@ -569,7 +577,8 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     const float *const forcex = a.force_x, *const noise_pre = a.noise_pre, *const fc3f = a.fc3f, *const noise_raw = a.noise;
     constexpr bool MOL = MODE == 1;
     const int Tall = a.T, noise_t0 = a.noise_t0;
-    const float *const mels_up = a.mels_up, *const aux_fr = a.aux_fr;
+    const float *const mels_up = a.mels_up, *const aux_fr = a.aux_fr, *const mel_coef = a.mel_coef;
+    const int mel_stage = a.mel_stage;
     const int hop = a.hop;
     const unsigned magic = a.hop_magic;
     const int mshift = a.hop_shift;
@@ -609,6 +618,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             const int sc = a.rb0 + b0 + (tid < nb ? tid : nb - 1);
             SEGT[i * 48 + tid] = a.seg_pos[sc];
             SEGT[i * 48 + SEG + tid] = a.seg_lim[sc];
+            SEGT[i * 48 + 2 * SEG + tid] = a.mel_stage ? a.seg_moff[sc] : 0;      // (the ih workgroups keep their table-row bases here)
         }
     }
     __syncthreads();
@@ -700,7 +710,12 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
                 const int p = SEGT[i * 48 + fi] + tt;
                 const bool valid = fi < slot_nb(i) && p < SEGT[i * 48 + SEG + fi];
                 const int fr = magic ? (int)(__umulhi((unsigned)p, magic) >> mshift) : p / hop;
-                const f32x4 v = cond_tile(ct, mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane);
+                f32x4 v;
+                if (mel_stage) {                        // the last up-sampling stage here too: three rows of its input, this position's tap sums
+                    const int j = p + SEGT[i * 48 + 2 * SEG + fi];
+                    const int row = j / LAST_SCALE;
+                    v = cond_tile_rows(ct, mels_up + (size_t)(row - 1) * MEL, mel_coef + 3 * (j - row * LAST_SCALE), aux_fr + (size_t)fr * (4 * AUX), valid, lane);
+                } else v = cond_tile(ct, mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane);
                 const u32x4 q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                 const int so = cbase + i * (MAXCL * DSLOTB) + 4 * DLAYERB + (tt & (DRING - 1)) * XTB;
                 if (loc_h) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 0);
@@ -1058,7 +1073,7 @@ __global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
 }
 
 size_t duo_lds_bytes(int G) { return (size_t)duo_lds(G).total * sizeof(float); }
-size_t duo_xbuf_bytes(int G) { return (size_t)G * MAXCL * DNX * DRING * XT * sizeof(float); }     // the slots a launch with depth G touches: a prefix
+size_t duo_xbuf_bytes(int G) { return (size_t)G * MAXCL * DNX * DLAYER_ENTRIES * XT * sizeof(float); }     // the slots a launch with depth G touches: a prefix
 size_t duo_xbuf_bytes_max() { return DXBUF_FLOATS * sizeof(float); }
 int duo_max_depth() { return LMAXG; }
 

@@ -304,8 +304,9 @@ extern "C" size_t wrnn_pre_workspace_bytes(const wrnn_pre *p, int32_t n_frames)
     return (nf * p->scales[0] + nf * p->scales[0] * p->scales[1]) * PFEAT * sizeof(float) + 512;
 }
 
-extern "C" int wrnn_pre_upsample(const wrnn_pre *p, const float *mel, int32_t n_frames, float *mels_up, float *aux,
-                                 void *workspace, size_t workspace_bytes, void *stream_)
+// rows_only: stop in front of the last stage and write its input as [row][channel] (wrnn_pre_upsample_rows)
+static int pre_run(const wrnn_pre *p, const float *mel, int32_t n_frames, float *mels_up, float *aux,
+                   void *workspace, size_t workspace_bytes, void *stream_, bool rows_only)
 {
     if (!p || !mel || !mels_up || !aux || !workspace) PRE_FAIL(WRNN_ERR_ARG, "NULL argument");
     if (n_frames < 1 || (double)n_frames * p->total_scale > 2.0e9) PRE_FAIL(WRNN_ERR_ARG, "bad n_frames %d", n_frames);
@@ -326,7 +327,16 @@ extern "C" int wrnn_pre_upsample(const wrnn_pre *p, const float *mel, int32_t n_
     const unsigned g1 = grid((long)nf * p->scales[0] * PFEAT), g2 = grid((long)nf * p->scales[0] * p->scales[1] * PFEAT);
     const unsigned g3 = grid((long)n_frames * p->total_scale * 4);      // one 64-sample x 80-channel tile per workgroup and trip
     const int n2 = nf * p->scales[0], n3 = n2 * p->scales[1], indent = PPAD * p->total_scale;
-    if (shipped) {
+    if (rows_only) {
+        // (LAST = true with indent 0: no crop, the [sample][channel] transpose only)
+        if (shipped) {
+            hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 5>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, 5, PPAD, 0);
+            hipLaunchKernelGGL((wrnn_upstage_kernel<false, true, 5>), dim3(g2), dim3(256), 0, stream, s1, mels_up, p->taps[1], n2, 5, 0, 0);
+        } else {
+            hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 0>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, p->scales[0], PPAD, 0);
+            hipLaunchKernelGGL((wrnn_upstage_kernel<false, true, 0>), dim3(g2), dim3(256), 0, stream, s1, mels_up, p->taps[1], n2, p->scales[1], 0, 0);
+        }
+    } else if (shipped) {
         hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 5>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, 5, PPAD, 0);
         hipLaunchKernelGGL((wrnn_upstage_kernel<false, false, 5>), dim3(g2), dim3(256), 0, stream, s1, s2, p->taps[1], n2, 5, 0, 0);
         hipLaunchKernelGGL((wrnn_upstage_last_kernel<11>), dim3(g3), dim3(256), 0, stream, s2, mels_up, p->taps[2], n3, 11, indent);
@@ -337,4 +347,16 @@ extern "C" int wrnn_pre_upsample(const wrnn_pre *p, const float *mel, int32_t n_
     }
     PRE_HIP(hipGetLastError());
     return WRNN_OK;
+}
+
+extern "C" int wrnn_pre_upsample(const wrnn_pre *p, const float *mel, int32_t n_frames, float *mels_up, float *aux,
+                                 void *workspace, size_t workspace_bytes, void *stream)
+{
+    return pre_run(p, mel, n_frames, mels_up, aux, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int wrnn_pre_upsample_rows(const wrnn_pre *p, const float *mel, int32_t n_frames, float *mel_rows, float *aux,
+                                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    return pre_run(p, mel, n_frames, mel_rows, aux, workspace, workspace_bytes, stream, true);
 }

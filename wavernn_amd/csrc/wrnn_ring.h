@@ -269,6 +269,43 @@ __device__ __forceinline__ f32x4 cond_tile(const CondTile &c, const float *mel_r
     return a0 + a1;
 }
 
+// The same tile with the mel row formed from the three rows of the last up-sampling stage's input that its 2 s + 1 taps reach
+// (s = LAST_SCALE): rows r0 (= row j / s - 1), r0 + MEL, r0 + 2 MEL; co = the three tap sums of this lane's phase j % s.
+__device__ __forceinline__ f32x4 cond_tile_rows(const CondTile &c, const float *r0, const float *co, const float *aux_row, bool valid, int lane)
+{
+    const int kq = lane >> 4;
+    float4 v[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+        if (kq == 3) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] = *reinterpret_cast<const float4 *>(aux_row + 4 + 4 * j);
+        } else {
+            const float c0 = co[0], c1 = co[1], c2 = co[2];
+            const float *lo = r0 + CK * kq;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                if (j == 6 && kq == 2) { v[j] = *reinterpret_cast<const float4 *>(aux_row); continue; }
+                const float4 a = *reinterpret_cast<const float4 *>(lo + 4 * j);
+                const float4 b = *reinterpret_cast<const float4 *>(lo + MEL + 4 * j);
+                const float4 d = *reinterpret_cast<const float4 *>(lo + 2 * MEL + 4 * j);
+                v[j] = make_float4(fmaf(c2, d.x, fmaf(c1, b.x, c0 * a.x)), fmaf(c2, d.y, fmaf(c1, b.y, c0 * a.y)),
+                                   fmaf(c2, d.z, fmaf(c1, b.z, c0 * a.z)), fmaf(c2, d.w, fmaf(c1, b.w, c0 * a.w)));
+            }
+        }
+    }
+    f32x4 a0 = {c.bias[0], c.bias[1], c.bias[2], c.bias[3]}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w[4 * j + 0], v[j].x, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w[4 * j + 1], v[j].y, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w[4 * j + 2], v[j].z, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w[4 * j + 3], v[j].w, a1, 0, 0, 0);
+    }
+    return a0 + a1;
+}
+
 // GRU pointwise math with the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each) instead of the library's expf, tanhf
 // and IEEE divisions: ~25 VALU instead of ~120 on the critical back half of every gate stage.  Same algebra as gru_update
 // (wrnn_device.h); absolute error ~1e-7 per value, the size of the fp32 rounding already present (MoL tolerance 1e-5: tests).

@@ -14,6 +14,29 @@ LOOP_KEYS = dict(I_w='I.weight', I_b='I.bias', w_ih1='rnn1.weight_ih_l0', w_hh1=
                  fc2_w='fc2.weight', fc2_b='fc2.bias', fc3_w='fc3.weight', fc3_b='fc3.bias')
 
 
+class MelRows:
+    """The conditioning mel handed to the loop ONE up-sampling stage short (`wrnn_options.mel_stage = 1`, wrnn_duo_kernel only): the
+    kernel forms the last Stretch2d + conv stage and the crop (reference models/fatchord_version.py:73-80, :86-88) itself, so the
+    [L, feat] up-sampled mel is never written.
+
+    rows      (n_rows, feat) float32 CUDA tensor: `PreEngine.upsample_rows` output (several utterances: their blocks one after the other)
+    L         length of the cropped time line the segment table refers to (what `mels_up.shape[0]` would have been)
+    scale     stretch factor of the last stage; taps: its 2 * scale + 1 conv taps (host)
+    seg_off   un-cropped position of step t of segment b = seg_pos[b] + t + seg_off[b]: one int, or one per segment
+              (utterance k of a concatenation: indent * (2 k + 1), indent = pad * hop)"""
+
+    def __init__(self, rows, L, scale, taps, seg_off):
+        self.rows, self.L, self.scale = rows, int(L), int(scale)
+        self.taps = np.ascontiguousarray(taps, dtype=np.float32).reshape(-1)
+        self.seg_off = seg_off
+        if self.taps.shape[0] != 2 * self.scale + 1:
+            raise ValueError('the last stage has 2 * scale + 1 taps')
+
+    @property
+    def shape(self):
+        return self.rows.shape
+
+
 def _as_host_f32(v):
     if isinstance(v, torch.Tensor):
         v = v.detach().to('cpu', torch.float32).numpy()
@@ -85,7 +108,7 @@ class LoopEngine:
     def run(self, mels_up, aux, B, T, stride, noise, hop, **kw):
         """One utterance: segment b reads conditioning position b*stride + t (`fold_with_overlap` geometry,
         reference :293-340; unbatched: B=1, T=L, stride=0).  See `run_segments`."""
-        L = mels_up.shape[0]
+        L = mels_up.L if isinstance(mels_up, MelRows) else mels_up.shape[0]
         seg_pos = np.arange(B, dtype=np.int32) * np.int32(stride)
         seg_lim = np.full(B, L, dtype=np.int32)
         return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, **kw)
@@ -123,6 +146,9 @@ class LoopEngine:
         rows of [t0, t1) only) -- how long RAW runs draw their noise in chunks instead of T*B*C floats at once.
         progress: optional `f(steps_done, T, n_segments)` called from a HIP runtime thread when the device has finished each
         conditioning slab (wrnn_options.progress; must not touch the device)."""
+        rows_in = mels_up if isinstance(mels_up, MelRows) else None
+        if rows_in is not None:
+            mels_up = rows_in.rows
         for name, t_ in (('mels_up', mels_up), ('aux', aux), ('noise', noise)):
             if not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()):
                 raise ValueError(f'{name} must be a contiguous float32 CUDA tensor')
@@ -131,7 +157,7 @@ class LoopEngine:
         B = int(seg_pos.shape[0])
         if seg_lim.shape != (B,) or B < 1:
             raise ValueError('seg_pos / seg_lim must be 1-D int32 arrays of equal, non-zero length')
-        L = mels_up.shape[0]
+        L = rows_in.L if rows_in is not None else mels_up.shape[0]
         if mels_up.shape[1] != self.feat_dims or aux.shape[1] != 4 * self.aux_dims:
             raise ValueError('conditioning shape mismatch')
         t0, t1 = (0, T) if t_range is None else (int(t_range[0]), int(t_range[1]))
@@ -170,6 +196,10 @@ class LoopEngine:
             o.progress = ctypes.cast(thunk, ctypes.c_void_p)
         o.timer = self._timer
         o.info = ctypes.pointer(self._info)
+        if rows_in is not None:           # (host arrays read during the call only)
+            seg_moff = np.ascontiguousarray(np.broadcast_to(np.asarray(rows_in.seg_off, dtype=np.int32), (B,)))
+            o.mel_stage, o.mel_rows, o.mel_scale = 1, int(mels_up.shape[0]), rows_in.scale
+            o.mel_taps, o.seg_moff = rows_in.taps.ctypes.data, seg_moff.ctypes.data
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.wrnn_generate_segments(self._pack, B, T, seg_pos.ctypes.data, seg_lim.ctypes.data, L, hop, n_frames,
                                              mels_up.data_ptr(), aux.data_ptr(), noise.data_ptr(), out.data_ptr(),
@@ -180,6 +210,8 @@ class LoopEngine:
             # continuations are pinned to it) -> the stream kernel (any device, no inter-workgroup traffic; whole calls only)
             import warnings
             why = self.lib.wrnn_last_error().decode()
+            if rows_in is not None:       # the other kernels read the up-sampled mel: the caller, who has the mel, redoes the conditioning
+                raise _lib.ResidencyError('cooperative launch refused (' + why + ')')
             planned = _lib.RunInfo()
             self.lib.wrnn_plan_segments(self._pack, B, T, ctypes.byref(o), ctypes.byref(planned))
             if algo == 'auto' and (planned.kernel or b'') == b'wrnn_duo_kernel':

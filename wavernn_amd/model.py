@@ -134,6 +134,10 @@ class WaveRNN(nn.Module):
         #: 'native' = the HIP pre-loop kernels (MFMA MelResNet + box-filter up-sampling, wrnn_pre_*);
         #: 'torch' = the nn.Modules below through PyTorch-ROCm (MIOpen)
         self.pre_algo = 'native'
+        #: True = when the call runs on wrnn_duo_kernel (and the pre-loop stage is 'native' with a last stretch factor of 11), the LAST
+        #: up-sampling stage and the crop are formed inside the loop from that stage's input (`engine.MelRows`): the [L, feat]
+        #: up-sampled mel is never written.  False = always materialise it (what every other loop kernel reads).
+        self.mel_in_loop = True
         #: 'native' = cross-fade / unfold / mu-law / tail fade on the device in float64 (wrnn_post_unfold);
         #: 'numpy' = the host helpers of fold.py
         self.post_algo = 'native'
@@ -209,12 +213,31 @@ class WaveRNN(nn.Module):
             raise RuntimeError('wavernn_amd.WaveRNN.generate needs the model on a HIP device (model.to("cuda")); '
                                'there is no CPU path in this package')
 
-    def conditioning(self, mels):
+    def mel_rows_ok(self, eng, n_segments, T):
+        """Whether a run over this many segments takes the mel one up-sampling stage short (`mel_in_loop`): it runs on wrnn_duo_kernel and
+        the HIP pre-loop stage ends with the stretch factor that kernel is built for."""
+        device = next(self.parameters()).device
+        if not (self.mel_in_loop and self.pre_algo == 'native' and device.type == 'cuda'):
+            return False
+        if eng.plan(n_segments, T, algo=self.loop_algo)['kernel'] != 'wrnn_duo_kernel':
+            return False
+        try:
+            return self._pre_engine().scales[2] == 11
+        except _lib.WrnnError:
+            return False
+
+    def conditioning(self, mels, rows=False):
         """Pre-loop stage (reference :183-186) without the Stretch2d repeat of aux and without the fold:
-        returns mels_up (L, feat), aux frames (N, res_out), wave_len."""
+        returns mels_up (L, feat), aux frames (N, res_out), wave_len.  rows=True (see `mel_rows_ok`): an `engine.MelRows` -- the input of
+        the last up-sampling stage -- in place of mels_up."""
         device = next(self.parameters()).device
         mels = torch.as_tensor(mels, device=device)
         wave_len = (mels.size(-1) - 1) * self.hop_length
+        if rows:
+            from .engine import MelRows
+            pre = self._pre_engine()
+            mel_rows, aux = pre.upsample_rows(mels.float())
+            return MelRows(mel_rows, mels.size(-1) * self.hop_length, pre.scales[2], pre.last_taps, self.pad * self.hop_length), aux, wave_len
         if self.pre_algo == 'native' and device.type == 'cuda':
             try:
                 mels_up, aux = self._pre_engine().upsample(mels.float())
@@ -241,14 +264,16 @@ class WaveRNN(nn.Module):
         mu_law = mu_law if self.mode == 'RAW' else False
 
         with torch.no_grad():
-            mels_up, aux, wave_len = self.conditioning(mels)
-            L = mels_up.size(0)
+            L = int(torch.as_tensor(mels).size(-1)) * self.hop_length
             if batched:
                 B, _ = _fold.fold_geometry(L, target, overlap)
                 T, stride = target + 2 * overlap, target + overlap
             else:
                 B, T, stride = 1, L, 0
             eng = self._loop_engine()
+            rows = self.mel_rows_ok(eng, B, T)
+            mels_up, aux, wave_len = self.conditioning(mels, rows=rows)
+            assert (mels_up.L if rows else mels_up.size(0)) == L
             burn_ctor_draws(self.rnn_dims, self.aux_dims, self.noise_source)
             # the sampling noise is drawn and uploaded in slices of steps (RAW: B * n_classes floats per step), each slice
             # continuing the loop where the previous one stopped (wrnn_options.t_begin / t_end)
@@ -256,18 +281,31 @@ class WaveRNN(nn.Module):
             resumable = eng.plan(B, T, algo=self.loop_algo)['kernel'] in ('wrnn_loop_kernel', 'wrnn_duo_kernel')
             chunk = max(1, min(T, self.noise_chunk_bytes // per_step)) if resumable else T
             chunk = -(-T // (-(-T // chunk)))                # equal slices (no short tail slice with its own launches)
-            rng_state = torch.get_rng_state() if (self.noise_source == 'cpu' and chunk < T) else None
+            rng_state = torch.get_rng_state() if (self.noise_source == 'cpu' and (chunk < T or rows)) else None
             algo = self.loop_algo
+            import warnings
             try:
                 out = self._run_sliced(eng, mels_up, aux, B, T, stride, chunk, algo, device)
             except _lib.ResidencyError as e:
-                # `auto` picked the persistent kernel but its cooperative launch was refused (CU masking, a smaller partition,
-                # another cooperative kernel): redo the call UNSLICED on the stream kernel, from the same point of the noise stream
-                import warnings
-                warnings.warn(f'wavernn_amd: {e}; using the stream kernel')
+                # `auto` picked a persistent kernel but its cooperative launch was refused (CU masking, a smaller partition, another
+                # cooperative kernel).  From the same point of the noise stream: with the mel one stage short (only wrnn_duo_kernel reads
+                # that) redo the conditioning in full and let the engine degrade as usual (one workgroup per CU, then the stream kernel);
+                # otherwise -- the refusal struck the first slice of a sliced run -- redo the call UNSLICED on the stream kernel
                 if rng_state is not None:
                     torch.set_rng_state(rng_state)
-                out = self._run_sliced(eng, mels_up, aux, B, T, stride, T, 'stream', device)
+                if rows:
+                    warnings.warn(f'wavernn_amd: {e}; up-sampling the mel in full for the other loop kernels')
+                    mels_up, aux, _ = self.conditioning(mels)
+                    try:
+                        out = self._run_sliced(eng, mels_up, aux, B, T, stride, chunk, algo, device)
+                        e = None
+                    except _lib.ResidencyError as e2:
+                        e = e2
+                        if rng_state is not None:
+                            torch.set_rng_state(rng_state)
+                if e is not None:
+                    warnings.warn(f'wavernn_amd: {e}; using the stream kernel')
+                    out = self._run_sliced(eng, mels_up, aux, B, T, stride, T, 'stream', device)
             self.last_loop_ms = eng.last_loop_ms()
             self.last_loop_kernel = eng.last_loop_kernel()
 

@@ -47,6 +47,7 @@ class PreEngine:
         for name, arr in host.items():
             setattr(w, name, arr.ctypes.data)
         self.feat_dims, self.res_out_dims = int(feat), int(conv_out_w.shape[0])
+        self.pad, self.scales, self.last_taps = int(w.pad), [int(s_) for s_ in scales], ups[2].copy()
         pre = ctypes.c_void_p()
         rc = self.lib.wrnn_pre_create(ctypes.byref(w), (self.device.index if self.device.index is not None else torch.cuda.current_device()), ctypes.byref(pre))
         if rc != 0:
@@ -63,7 +64,16 @@ class PreEngine:
         except Exception:
             pass
 
-    def upsample(self, mel, mels_up=None, aux=None):
+    def upsample_rows(self, mel, rows=None, aux=None):
+        """The same, one stage short (`wrnn_pre_upsample_rows`): (rows [(N + 2 pad) * s0 * s1, feat] = the input of the last Stretch2d +
+        conv stage, aux [N, res_out]) -- what `LoopEngine.run*` takes wrapped in `engine.MelRows`; wrnn_duo_kernel forms the last stage
+        and the crop inside the loop."""
+        return self.upsample(mel, mels_up=rows, aux=aux, _rows=True)
+
+    def rows_of(self, n_frames):
+        return (int(n_frames) + 2 * self.pad) * self.scales[0] * self.scales[1]
+
+    def upsample(self, mel, mels_up=None, aux=None, _rows=False):
         """mel: (feat, N) or (1, feat, N) float32 CUDA tensor -> (mels_up [N*hop, feat], aux [N, res_out]) CUDA tensors.
         `mels_up` / `aux` may be preallocated views (several utterances into one concatenated buffer)."""
         if mel.dim() == 3:
@@ -72,17 +82,18 @@ class PreEngine:
         n = int(mel.shape[1])
         if mel.shape[0] != self.feat_dims:
             raise ValueError(f'Expected a mel shaped ({self.feat_dims}, n_hops), but got {tuple(mel.shape)}!')
+        n_out = self.rows_of(n) if _rows else n * self.hop
         if mels_up is None:
-            mels_up = torch.empty(n * self.hop, self.feat_dims, dtype=torch.float32, device=self.device)
+            mels_up = torch.empty(n_out, self.feat_dims, dtype=torch.float32, device=self.device)
         if aux is None:
             aux = torch.empty(n, self.res_out_dims, dtype=torch.float32, device=self.device)
-        assert mels_up.is_contiguous() and aux.is_contiguous() and mels_up.shape == (n * self.hop, self.feat_dims)
+        assert mels_up.is_contiguous() and aux.is_contiguous() and mels_up.shape == (n_out, self.feat_dims)
         nbytes = int(self.lib.wrnn_pre_workspace_bytes(self._pre, n))
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self.lib.wrnn_pre_upsample(self._pre, mel.data_ptr(), n, mels_up.data_ptr(), aux.data_ptr(), self._ws.data_ptr(),
-                                        self._ws.numel(), stream)
+        fn = self.lib.wrnn_pre_upsample_rows if _rows else self.lib.wrnn_pre_upsample
+        rc = fn(self._pre, mel.data_ptr(), n, mels_up.data_ptr(), aux.data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream)
         if rc != 0:
             raise _lib.WrnnError(f'wrnn_pre_upsample failed (rc={rc}): {self.lib.wrnn_pre_last_error().decode()}')
         return mels_up, aux
