@@ -362,7 +362,7 @@ def test_mel_rows_loop_equals_the_materialised_mel(gpu, mode):
         eng.run_segments(mr, aux, plan.seg_pos, plan.seg_lim, T, noise, hop, algo='loop')
     # ... and so is a segment whose rows would lie outside the buffer
     with pytest.raises(_lib.WrnnError, match='input rows'):
-        eng.run_segments(MelRows(rows[:-30].contiguous(), mels_up.shape[0], 11, pre.last_taps, seg_off), aux, plan.seg_pos, plan.seg_lim, T, noise, hop, **kw)
+        eng.run_segments(MelRows(rows[:-60].contiguous(), mels_up.shape[0], 11, pre.last_taps, seg_off), aux, plan.seg_pos, plan.seg_lim, T, noise, hop, **kw)
 
 
 @pytest.mark.parametrize('mode,mu_law,batched', [('RAW', True, True), ('RAW', False, True), ('MOL', False, True), ('RAW', True, False)])

@@ -76,12 +76,13 @@ constexpr int DAHEAD_IH = 2;                 // re-arm distance (steps) of the l
 constexpr int DAHEAD_HH = 3;                 // ... of the layers an hh workgroup publishes
 constexpr int DGHRING = 2;                   // ring entries of the tagged gh words (no sentinel, no re-arm: two suffice)
 constexpr int DNWGC = 4 * LNJ;               // workgroups per cluster (128)
-// One 32 KB entry of padding behind every layer's ring.  With 128 KB per layer every (slot, layer) ring starts 0 or 128 KB into a 256 KB
-// window -- the span of one way of the 4 MB / 16-way L2 -- and the entries an XCD keeps alive at depth 4 (80-96 of them) pile 20 deep onto
-// two eighths of the sets while two eighths stay empty: more lines than ways, touched cyclically = LRU's worst case, and the dirty lines
-// of the XCD-local layers are written back every step.  At 160 KB per layer the same entries land 10-12 deep on every eighth.
+// DUO_LAYER_PAD = 1: one 32 KB entry of padding behind every layer's ring.  With 128 KB per layer every (slot, layer) ring starts 0 or
+// 128 KB into a 256 KB window -- the span of one way of the 4 MB / 16-way L2 -- so, IF the L2 indexed its sets by plain address bits, the
+// entries an XCD keeps alive at depth 4 would pile 20 deep onto two eighths of the sets (more lines than ways, touched cyclically), and
+// 10-12 deep on every eighth with the pad.  Measured (profiles/r04j_traffic.log, r04j_probe_*.json): no difference in WRITE_SIZE /
+// FETCH_SIZE or in step time -- the sets are evidently hashed -- so the pad is off.
 #ifndef DUO_LAYER_PAD
-#define DUO_LAYER_PAD 1
+#define DUO_LAYER_PAD 0
 #endif
 constexpr int DLAYER_ENTRIES = DRING + DUO_LAYER_PAD;
 constexpr size_t DXBUF_FLOATS = (size_t)LMAXG * MAXCL * DNX * DLAYER_ENTRIES * XT;      // [slot][cluster][layer][ring (+ pad)][XT]
