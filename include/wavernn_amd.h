@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define WRNN_ABI_VERSION 6   /* v5 (round 4): WRNN_ALGO_DUO runs RAW too; `auto` never degrades inside the library (WRNN_ERR_RESIDENCY: the caller re-plans); tuning bits per kernel */
+#define WRNN_ABI_VERSION 6   /* v6 (round 4): wrnn_options.mel_stage & co + wrnn_pre_upsample_rows -- the last up-sampling stage formed inside wrnn_duo_kernel.  v5 (round 4): WRNN_ALGO_DUO runs RAW too; `auto` never degrades inside the library (WRNN_ERR_RESIDENCY: the caller re-plans); tuning bits per kernel */
 
 enum {
     WRNN_OK = 0,
