@@ -46,10 +46,15 @@
 //     needed it); the wave drains its stores at the top of step t + 1, before it publishes anything of that step; the entry is polled
 //     for step t + 2 by consumers that have consumed this wave's step t + 1 data: the re-arm is visible before the poll.  (Re-arming
 //     data of step t - 1 instead would race an hh workgroup that is a step behind.)
-//   * layers an hh workgroup publishes (cI, x_t, RAW logits; DAHEAD_HH = 3): at step t (cI: at the top of the step; x_t, logits: once
-//     this step's y2 is there) a wave drains, then re-arms its words of entry (t + 3) % 4 -- data of step t - 1: cI(t - 1) and
-//     x_t / logits of step t - 1 were consumed before h(t - 1) / y2(t) could exist; the next drain is at step t + 1, and a consumer that
-//     polls the entry for step t + 3 has seen something this wave published in step t + 2.
+//   * layers an hh workgroup publishes with a sentinel (x_t, RAW logits; DAHEAD_HH = 3): once this step's y2 is there a wave drains, then
+//     re-arms its words of entry (t + 3) % 4 -- data of step t - 1, consumed before the y2(t) the wave has just polled could exist; the
+//     next drain is at step t + 1, and a consumer that polls the entry for step t + 3 has seen something this wave published in step t + 2.
+//   * cI (layer 4) carries NO sentinel inside a launch and is never re-armed: rnn1's hh workgroup forms cI(t + 2) at the top of its step t
+//     (the entry held cI(t - 2): the workgroup has polled h1(t - 1) of every ih workgroup, so every reader is past it) and drains before it
+//     publishes anything of that step.  An ih workgroup reads cI(s) after its fc stage of step s - 1, whose x2(s - 1) needed x1(s - 1) of
+//     EVERY ih workgroup, each of which needed gh1(s - 1) of its hh workgroup -- published in that workgroup's step s - 2, behind the drain
+//     of cI(s): the value is there, no poll.  Only the first two steps of a launch lack that chain (their gh comes from the saved
+//     state): a launch leaves the sentinel in the entries of its T1 and T1 + 1, and the next launch's ih workgroups poll those as usual.
 //   * the gh words {r, z, n, tag = consuming step + 1} carry a tag instead of relying on a sentinel: no re-arm, and two ring entries
 //     suffice (the hh workgroup cannot start gh(t+3) before the ih workgroup has consumed gh(t+1): it needs h(t+2), which needs gh(t+2)).
 // A launch ends with every entry in the state the next step expects (kernel end drains everything): continuations need no refill.
@@ -724,16 +729,21 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             }
         }
     };
-    // ring hygiene of layer 4 (see the header), once per step and wave, at the top of the step: drain, then re-arm this wave's slots' blocks of entry (t + 3) % 4
-    auto cond_rearm = [&](int tt) {
+    // layer 4 carries no sentinel inside a launch (see the header: cI is formed two steps ahead and drained before this workgroup's next gh
+    // publication, which every reader's inputs depend on).  The first two steps of a launch have no such dependency (their gh comes from
+    // the saved state): the launch that ends at T1 leaves the sentinel in the entries of steps T1 and T1 + 1 -- nobody reads them any more --
+    // and the next launch's ih workgroups poll them like any other layer.
+    auto cond_leave = [&]() {
         if constexpr (LA) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const u32x4 q = {SENT, SENT, SENT, SENT};
 #pragma unroll 1
             for (int i = w; i < nact; i += NW) {
-                const int so = cbase + i * (MAXCL * DSLOTB) + 4 * DLAYERB + ((tt + DAHEAD_HH) & (DRING - 1)) * XTB;
-                if (loc_h) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 16 /* sc1 */);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int so = cbase + i * (MAXCL * DSLOTB) + 4 * DLAYERB + ((T1 + e) & (DRING - 1)) * XTB;
+                    if (loc_h) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 16 /* sc1 */);
+                }
             }
         }
     };
@@ -969,10 +979,13 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     using BGH = std::integral_constant<int, BK_GH>;
     using BLG = std::integral_constant<int, BK_LG>;
     using BANY = std::integral_constant<int, BK_ANY>;
-    cond_step(T0);                                      // (the step a launch starts with; every later one is formed a step ahead)
+    cond_step(T0);                                      // (the two steps a launch starts with; every later one is formed two steps ahead)
+    if (T0 + 1 < T1) cond_step(T0 + 1);
     for (; t < T1; ++t) {
-        cond_rearm(t);
-        if (t + 1 < T1) cond_step(t + 1);
+        if constexpr (LA) {
+            if (t + 2 < T1) cond_step(t + 2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // ... and out before anything of this step is published
+        }
         stage(K1{}, BANY{}, 0);
 #pragma unroll 1
         for (int i = 1; i < nact; ++i) stage(K1{}, BGH{}, i);
@@ -990,6 +1003,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     if (pend == BK_GH) back_gh(cy);
     else if (pend == BK_SAMPLE) { if constexpr (!LA && MOL) back_sample(cy); }
     else if (pend == BK_LG) { if constexpr (!LA && !MOL) back_lg(cy); }
+    cond_leave();
     if (PROF && tid == 0 && profp) {
         for (int k = 0; k < 16; ++k) profp[(size_t)(blockIdx.x & 255) * 32 + 16 + k] += PROFL[k];
     }
