@@ -1,0 +1,204 @@
+"""A discrete-event MODEL of wrnn_duo_kernel's exchange as it stands after round 4 (csrc/wrnn_duo.hip, header "Ring discipline"): four roles
+per unit block -- rnn1 / rnn2 x {ih, hh} --, several slots (groups of segments) in flight, a ring of FOUR entries per layer, and three
+different ways a consumer learns that a value is there:
+
+* sentinel layers (h, x = residual sum, y; x_t): every word is the sentinel until its step's value lands; the producer re-arms its own
+  words -- ih workgroups TWO steps ahead, after the last poll of their step, with the drain at the top of the NEXT step; the sampler
+  THREE ahead with the drain in front of the re-arm;
+* gh: one tagged word per (unit block, slot), two ring entries, never re-armed;
+* cI: NO sentinel and no re-arm inside a launch -- rnn1's hh workgroup forms cI(t + 2) at the top of its step t and drains before it
+  publishes anything of that step; the readers' own inputs already depend on that publication.  (The first two steps of a launch are
+  polled: the buffer starts sentinel-filled.)
+
+The arguments for those distances are statements about how far workgroups can drift apart.  Here they are checked under adversarial
+timing instead: stores become visible after random delays, out of program order, now and then later than several whole steps (only a
+drain waits for them); every stage takes a random time.  Checked: whatever a consumer accepts carries the tag of ITS step in every word,
+a re-arm never lands on data that is still to be read or that is newer than the turn it was issued for (a dead-lock, also caught as "no
+progress"), nobody overwrites a gh word that is still to be read, everybody finishes.  The broken variants at the end show that the model
+is not vacuous: each of the shortcuts the header argues against is caught for some timing.  A model of the protocol, not of the HIP code
+-- tests/test_gpu_parity.py covers that."""
+import heapq
+import random
+
+RING, GHRING = 4, 2
+SENT = None
+
+
+class DuoSim:
+    def __init__(self, seed, n_wg=3, slots=2, steps=24, ahead_ih=2, ahead_hh=3, cond_ahead=2, cond_drain=True, ih_drain=True,
+                 ih_drain_at_rearm=False):
+        assert slots <= n_wg                                # rnn2's hh workgroup j samples slot j
+        self.rng = random.Random(seed)
+        self.n_wg, self.G, self.steps = n_wg, slots, steps
+        self.ahead_ih, self.ahead_hh, self.cond_ahead, self.cond_drain = ahead_ih, ahead_hh, cond_ahead, cond_drain
+        self.ih_drain, self.ih_drain_at_rearm = ih_drain, ih_drain_at_rearm
+        ring = lambda n: [[[SENT] * n_wg for _ in range(n)] for _ in range(slots)]          # [slot][entry][producer]
+        self.mem = {l: ring(RING) for l in ('h1', 'x1', 'y1', 'h2', 'x2', 'y2', 'cI')}
+        self.mem['gh1'], self.mem['gh2'] = ring(GHRING), ring(GHRING)
+        self.mem['xt'] = [[[SENT] for _ in range(RING)] for _ in range(slots)]              # one producer: the slot's sampler
+        self.now, self.events, self.seq = 0.0, [], 0
+        self.pending, self.violations, self.done = {}, [], 0
+        self.rearm_turn = {}
+
+    def at(self, dt, fn):
+        self.seq += 1
+        heapq.heappush(self.events, (self.now + dt, self.seq, fn))
+
+    def store(self, who, layer, slot, entry, j, value, rearm_turn=None):
+        self.pending[who] = self.pending.get(who, 0) + 1
+
+        def land():
+            old = self.mem[layer][slot][entry][j]
+            if value is SENT and old is not SENT and old >= rearm_turn:
+                self.violations.append(f're-arm of {layer}[{slot}][{entry}][{j}] (for step {rearm_turn}) landed on data of step {old}')
+            self.mem[layer][slot][entry][j] = value
+            self.pending[who] -= 1
+        # (now and then an acknowledgement that takes longer than ten whole steps: only a drain makes that harmless)
+        self.at(self.rng.uniform(300.0, 600.0) if self.rng.random() < 0.006 else self.rng.choice([0.1, 0.5, 1.0, 3.0, 8.0]), land)
+
+    def run(self):
+        procs = [self.program(role, j) for role in ('Aih', 'Ahh', 'Bih', 'Bhh') for j in range(self.n_wg)]
+        for p in procs:
+            self.resume(p)
+        while self.events and self.now < 60000.0:             # (a dead-locked model polls for ever: the clock is the limit)
+            self.now, _, fn = heapq.heappop(self.events)
+            fn()
+        if self.done != len(procs):
+            self.violations.append(f'no progress: {self.done} of {len(procs)} workgroups finished')
+        return self.violations
+
+    def resume(self, p):
+        try:
+            kind, arg = next(p)
+        except StopIteration:
+            self.done += 1
+            return
+        if kind == 'work':
+            self.at(self.rng.choice([0.2, 1.0, 2.0, 6.0]) * arg, lambda: self.resume(p))
+        elif kind == 'poll':                                 # sentinel layer: re-read until no word is the sentinel, then every word must be step t's
+            layer, slot, t = arg
+
+            def poll():
+                words = self.mem[layer][slot][t % RING]
+                if any(wd is SENT for wd in words):
+                    self.at(0.5, poll)
+                    return
+                for j, wd in enumerate(words):
+                    if wd != t:
+                        self.violations.append(f'{layer}[{slot}][{j}] read as step {wd} while polling for step {t}')
+                self.resume(p)
+            poll()
+        elif kind == 'tag':                                  # gh: re-read the one word until it carries step t's tag
+            layer, slot, j, t = arg
+
+            def poll():
+                wd = self.mem[layer][slot][t % GHRING][j]
+                if wd is not SENT and wd > t:
+                    self.violations.append(f'{layer}[{slot}][{j}] of step {t} was overwritten by step {wd} before it was read')
+                    self.resume(p)
+                elif wd != t:
+                    self.at(0.5, poll)
+                else:
+                    self.resume(p)
+            poll()
+        elif kind == 'drain':
+            who = arg
+
+            def drain():
+                if self.pending.get(who, 0) > 0:
+                    self.at(0.2, drain)
+                else:
+                    self.resume(p)
+            drain()
+
+    def program(self, role, j):
+        who, G, n = (role, j), self.G, self.n_wg
+
+        def publish(layer, i, t):
+            self.store(who, layer, i, t % RING, j if layer != 'xt' else 0, t)
+
+        def rearm(layers, t, ahead, slots):
+            for layer in layers:
+                for i in slots:
+                    self.store(who, layer, i, (t + ahead) % RING, j if layer != 'xt' else 0, SENT, rearm_turn=t + ahead - RING + 1)
+
+        if role in ('Aih', 'Bih'):
+            a = role == 'Aih'
+            operand, gh, mine = ('cI', 'gh1', ('h1', 'x1', 'y1')) if a else ('x1', 'gh2', ('h2', 'x2', 'y2'))
+            for t in range(self.steps):
+                for i in range(G):                           # gate stages
+                    yield ('poll', (operand, i, t))          # (cI: a poll finds no sentinel from step 2 on -- the words must then be step t's)
+                    if i == 0 and self.ih_drain and not self.ih_drain_at_rearm:
+                        yield ('drain', who)                 # last step's re-arm stores are out before anything of this step is published
+                    yield ('work', 1.0)
+                    if t > 0:
+                        yield ('tag', (gh, i, j, t))
+                        if a:
+                            yield ('poll', ('xt', i, t - 1))
+                    publish(mine[1], i, t); publish(mine[0], i, t)
+                for i in range(G):                           # fc stages
+                    yield ('poll', ('x2' if a else 'y1', i, t))
+                    if i == G - 1:                           # after the last poll of the step: re-arm, all slots
+                        if self.ih_drain and self.ih_drain_at_rearm:
+                            yield ('drain', who)
+                        rearm(mine, t, self.ahead_ih, range(G))
+                    yield ('work', 0.4)
+                    publish(mine[2], i, t)
+        elif role == 'Ahh':
+            def form(tt):
+                if tt < self.steps:
+                    for i in range(G):
+                        self.store(who, 'cI', i, tt % RING, j, tt)
+            for tt in range(self.cond_ahead):
+                form(tt)
+            for t in range(self.steps):
+                form(t + self.cond_ahead)
+                if self.cond_drain:
+                    yield ('drain', who)
+                for i in range(G):
+                    yield ('poll', ('h1', i, t)); yield ('work', 1.0)
+                    if t + 1 < self.steps:
+                        self.store(who, 'gh1', i, (t + 1) % GHRING, j, t + 1)
+        else:
+            for t in range(self.steps):
+                for i in range(G):
+                    yield ('poll', ('h2', i, t)); yield ('work', 1.0)
+                    if t + 1 < self.steps:
+                        self.store(who, 'gh2', i, (t + 1) % GHRING, j, t + 1)
+                if j < G:                                    # the sampler of slot j
+                    yield ('poll', ('y2', j, t))
+                    yield ('drain', who)
+                    rearm(('xt',), t, self.ahead_hh, [j])
+                    yield ('work', 0.6)
+                    publish('xt', j, t)
+
+
+def test_duo_exchange_is_safe_under_adversarial_timing():
+    for seed in range(40):
+        for slots in (1, 2, 3):
+            v = DuoSim(seed, n_wg=3, slots=slots, steps=24).run()
+            assert not v, (seed, slots, v[:3])
+
+
+def test_other_safe_distances():
+    """Also safe (not what the kernel does): ih layers re-armed three ahead -- the re-arm site lies behind the fc stage's poll of the
+    other layer's residual sum, which needed every hh workgroup's gh of this step, i.e. every reader is past the data of step t - 1 -- with
+    the drain at either place; the sampler's x_t two ahead (its drain precedes its publication in every step)."""
+    for seed in range(25):
+        for kw in (dict(ahead_ih=3), dict(ahead_ih=3, ih_drain_at_rearm=True), dict(ahead_hh=2)):
+            v = DuoSim(seed, steps=24, **kw).run()
+            assert not v, (seed, kw, v[:3])
+
+
+def test_duo_model_detects_the_shortcuts():
+    def broken(**kw):
+        return any(DuoSim(seed, steps=30, **kw).run() for seed in range(60))
+    # ih layers two ahead but drained only at the re-arm site (round 3's place): a consumer of step t + 2 may not see the re-arm yet
+    assert broken(ih_drain_at_rearm=True)
+    assert broken(ih_drain=False)
+    assert broken(ahead_ih=1)
+    # cI without a sentinel needs the two steps of lead AND the drain before the step's publications
+    assert broken(cond_ahead=1)
+    assert broken(cond_drain=False)
+    # the sampler's x_t one ahead: its publication of this step can overtake the re-arm
+    assert broken(ahead_hh=1)
