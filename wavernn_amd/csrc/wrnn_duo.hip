@@ -1,4 +1,4 @@
-// wrnn_duo.hip -- the TWO-WORKGROUPS-PER-CU form of the persistent WaveRNN loop kernel (MOL) for MI355X (gfx950 / CDNA4).
+// wrnn_duo.hip -- the TWO-WORKGROUPS-PER-CU form of the persistent WaveRNN loop kernel (MOL and 9-bit RAW) for MI355X (gfx950 / CDNA4).
 //
 // Same path and the same tag-free sentinel exchange in MFMA-fragment order as wrnn_loop.hip (reference
 // models/fatchord_version.py:201-241); every role of wrnn_loop.hip is cut in two along the line between its critical and its
@@ -7,9 +7,13 @@
 //
 //     A-ih : rnn1 W_ih (3 gate tiles) + fc1 (1 tile) = 128 weight registers   stages P0 (gates -> h1, x1 = xi + h1), P2 (fc1 -> y1)
 //     B-ih : rnn2 W_ih (3 gate tiles) + fc2 (1 tile) = 128                    stages P0 (gates -> h2, x2 = x1 + h2), P2 (fc2 -> y2)
-//     A-hh : rnn1 W_hh (3 gate tiles)                =  96                    stage  P1 (gh1(t+1) = W_hh1 . h1(t) + b_hh)
-//     B-hh : rnn2 W_hh (3 gate tiles)                =  96                    stage  P1 (gh2(t+1)); workgroup J < groups in flight also runs
-//                                                                             fc3 + the MoL sampling of slot J (fc3 fragments from L2)
+//     A-hh : rnn1 W_hh (3 gate tiles)                =  96 (+ 32: its rows of stage  P1 (gh1(t+1) = W_hh1 . h1(t) + b_hh); forms cI(t+2) of its 16 rows for
+//            I.weight[:, 1:])                                                 every slot -- from the mel (or, wrnn_options.mel_stage, from the x25
+//                                                                             signal: the last up-sampling stage too) and the frame's aux row
+//     B-hh : rnn2 W_hh (3 gate tiles)                =  96 (RAW: + 32, its    stage  P1 (gh2(t+1)); MOL: workgroup J < groups in flight also runs fc3 +
+//            16 rows of fc3)                                                  the sampling of slot J (first fc3 tile in LDS, second from L2); RAW: every
+//                                                                             workgroup computes its 16 logit rows of every slot (ring layer 16),
+//                                                                             workgroup J gathers the 512 logits of slot J and samples in the reference's order
 //
 // Round 4 -- the LEAN form.  Round 3's phase clocks (profiles/r03ab_*, r03ag_*) showed the ih workgroup's serial instruction stream
 // -- 16.7 k cycles per group-step at depth 4 AND at depth 8, 5.2 k of them MFMA -- bounding the step while the hh workgroup idled
@@ -20,7 +24,7 @@
 //     operand as it comes from memory, and the x_{t-1} term -- one FMA per gate with the pack's pre-multiplied vector
 //     u1 = W_ih1 . I.weight[:,0] -- moves into the gates' pointwise half.  x_{t-1} is therefore needed AFTER the gate tiles, not
 //     before them: the sampling -> rnn1 hop of a slot's chain is shorter by one MFMA block.  (fp32 rounding differs from the
-//     reference's order by ~1e-7 relative: this kernel is MoL only, tolerance 1e-5; the bit-exact RAW mode runs on wrnn_loop_kernel.)
+//     reference's order by ~1e-7 relative: MoL tolerance 1e-5; the RAW class indices still agree bit for bit on every golden and sweep.)
 //   * the residual input of the owned units (xi / x1 for the published sums x1 = xi + h1, x2 = x1 + h2) is one 4-byte load per
 //     thread from the layer the stage consumes anyway, not an LDS slice written by one wave behind eight compares;
 //   * stage kinds are compile-time at every call site (a step is: gates of slot 0 | gates of the others | fc of slot 0 | fc of the
@@ -44,8 +48,10 @@
 //   * layers an ih workgroup publishes (h, y, residual sum; DAHEAD_IH = 2): after the last poll of its step t a wave re-arms its own
 //     words of entry (t + 2) % 4 -- data of step t - 2, consumed by every hh workgroup (above) and by every ih workgroup (x(t - 1)
 //     needed it); the wave drains its stores at the top of step t + 1, before it publishes anything of that step; the entry is polled
-//     for step t + 2 by consumers that have consumed this wave's step t + 1 data: the re-arm is visible before the poll.  (Re-arming
-//     data of step t - 1 instead would race an hh workgroup that is a step behind.)
+//     for step t + 2 by consumers that have consumed this wave's step t + 1 data: the re-arm is visible before the poll (with the drain
+//     at the re-arm site it need not be).  (Three ahead would be safe too -- the re-arm site lies behind the fc stage's poll, which needed
+//     every hh workgroup's gh of this step -- two ahead keeps a step of margin on both sides.)  tests/test_duo_exchange_model.py runs
+//     these rules as a discrete-event model under adversarial timing.
 //   * layers an hh workgroup publishes with a sentinel (x_t, RAW logits; DAHEAD_HH = 3): once this step's y2 is there a wave drains, then
 //     re-arms its words of entry (t + 3) % 4 -- data of step t - 1, consumed before the y2(t) the wave has just polled could exist; the
 //     next drain is at step t + 1, and a consumer that polls the entry for step t + 3 has seen something this wave published in step t + 2.
