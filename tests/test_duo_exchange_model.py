@@ -5,7 +5,8 @@ different ways a consumer learns that a value is there:
 * sentinel layers (h, x = residual sum, y; x_t): every word is the sentinel until its step's value lands; the producer re-arms its own
   words -- ih workgroups TWO steps ahead, after the last poll of their step, with the drain at the top of the NEXT step; the sampler
   THREE ahead with the drain in front of the re-arm;
-* gh: one tagged word per (unit block, slot), two ring entries, never re-armed;
+* gh: one tagged word per (unit block, slot), two ring entries, never re-armed; an hh workgroup runs the gh stage of the LAST slot at the
+  top of the next step (behind its sampling stage: `gh_shift`);
 * cI: NO sentinel and no re-arm inside a launch -- rnn1's hh workgroup forms cI(t + 2) at the top of its step t and drains before it
   publishes anything of that step; the readers' own inputs already depend on that publication.  (The first two steps of a launch are
   polled: the buffer starts sentinel-filled.)
@@ -26,12 +27,13 @@ SENT = None
 
 class DuoSim:
     def __init__(self, seed, n_wg=3, slots=2, steps=24, ahead_ih=2, ahead_hh=3, cond_ahead=2, cond_drain=True, ih_drain=True,
-                 ih_drain_at_rearm=False):
+                 ih_drain_at_rearm=False, gh_shift=True):
         assert slots <= n_wg                                # rnn2's hh workgroup j samples slot j
         self.rng = random.Random(seed)
         self.n_wg, self.G, self.steps = n_wg, slots, steps
         self.ahead_ih, self.ahead_hh, self.cond_ahead, self.cond_drain = ahead_ih, ahead_hh, cond_ahead, cond_drain
         self.ih_drain, self.ih_drain_at_rearm = ih_drain, ih_drain_at_rearm
+        self.gh_shift = gh_shift and slots >= 2             # hh workgroups: the last slot's gh stage runs at the top of the next step
         ring = lambda n: [[[SENT] * n_wg for _ in range(n)] for _ in range(slots)]          # [slot][entry][producer]
         self.mem = {l: ring(RING) for l in ('h1', 'x1', 'y1', 'h2', 'x2', 'y2', 'cI')}
         self.mem['gh1'], self.mem['gh2'] = ring(GHRING), ring(GHRING)
@@ -151,20 +153,31 @@ class DuoSim:
                         self.store(who, 'cI', i, tt % RING, j, tt)
             for tt in range(self.cond_ahead):
                 form(tt)
-            for t in range(self.steps):
-                form(t + self.cond_ahead)
-                if self.cond_drain:
-                    yield ('drain', who)
-                for i in range(G):
-                    yield ('poll', ('h1', i, t)); yield ('work', 1.0)
-                    if t + 1 < self.steps:
-                        self.store(who, 'gh1', i, (t + 1) % GHRING, j, t + 1)
+            def gh_stages(t):                                # (slot, step) of the gh stages of iteration t
+                if not self.gh_shift:
+                    return [(i, t) for i in range(G)] if t < self.steps else []
+                return ([(G - 1, t - 1)] if t > 0 else []) + ([(i, t) for i in range(G - 1)] if t < self.steps else [])
+            for t in range(self.steps + 1):
+                if t < self.steps:
+                    form(t + self.cond_ahead)
+                    if self.cond_drain:
+                        yield ('drain', who)
+                for i, tt in gh_stages(t):
+                    yield ('poll', ('h1', i, tt)); yield ('work', 1.0)
+                    if tt + 1 < self.steps:
+                        self.store(who, 'gh1', i, (tt + 1) % GHRING, j, tt + 1)
         else:
-            for t in range(self.steps):
-                for i in range(G):
-                    yield ('poll', ('h2', i, t)); yield ('work', 1.0)
-                    if t + 1 < self.steps:
-                        self.store(who, 'gh2', i, (t + 1) % GHRING, j, t + 1)
+            def gh_stages(t):
+                if not self.gh_shift:
+                    return [(i, t) for i in range(G)] if t < self.steps else []
+                return ([(G - 1, t - 1)] if t > 0 else []) + ([(i, t) for i in range(G - 1)] if t < self.steps else [])
+            for t in range(self.steps + 1):
+                for i, tt in gh_stages(t):
+                    yield ('poll', ('h2', i, tt)); yield ('work', 1.0)
+                    if tt + 1 < self.steps:
+                        self.store(who, 'gh2', i, (tt + 1) % GHRING, j, tt + 1)
+                if t == self.steps:
+                    break
                 if j < G:                                    # the sampler of slot j
                     yield ('poll', ('y2', j, t))
                     yield ('drain', who)
@@ -185,7 +198,7 @@ def test_other_safe_distances():
     other layer's residual sum, which needed every hh workgroup's gh of this step, i.e. every reader is past the data of step t - 1 -- with
     the drain at either place; the sampler's x_t two ahead (its drain precedes its publication in every step)."""
     for seed in range(25):
-        for kw in (dict(ahead_ih=3), dict(ahead_ih=3, ih_drain_at_rearm=True), dict(ahead_hh=2)):
+        for kw in (dict(ahead_ih=3), dict(ahead_ih=3, ih_drain_at_rearm=True), dict(ahead_hh=2), dict(gh_shift=False)):
             v = DuoSim(seed, steps=24, **kw).run()
             assert not v, (seed, kw, v[:3])
 
@@ -197,8 +210,9 @@ def test_duo_model_detects_the_shortcuts():
     assert broken(ih_drain_at_rearm=True)
     assert broken(ih_drain=False)
     assert broken(ahead_ih=1)
-    # cI without a sentinel needs the two steps of lead AND the drain before the step's publications
-    assert broken(cond_ahead=1)
+    # cI without a sentinel needs the two steps of lead (with one slot in flight: the deferred gh stage of a deeper pipeline happens to
+    # cover one step of it) AND the drain before the step's publications
+    assert broken(cond_ahead=1, slots=1)
     assert broken(cond_drain=False)
     # the sampler's x_t one ahead: its publication of this step can overtake the re-arm
     assert broken(ahead_hh=1)

@@ -92,6 +92,9 @@ constexpr int DNWGC = 4 * LNJ;               // workgroups per cluster (128)
 // entries an XCD keeps alive at depth 4 would pile 20 deep onto two eighths of the sets (more lines than ways, touched cyclically), and
 // 10-12 deep on every eighth with the pad.  Measured (profiles/r04j_traffic.log, r04j_probe_*.json): no difference in WRITE_SIZE /
 // FETCH_SIZE or in step time -- the sets are evidently hashed -- so the pad is off.
+#ifndef DUO_GH_SHIFT
+#define DUO_GH_SHIFT 1                        // hh workgroups: the gh stage of the last slot runs at the top of the next step (see duo_hh's step loop)
+#endif
 #ifndef DUO_LAYER_PAD
 #define DUO_LAYER_PAD 0
 #endif
@@ -755,6 +758,8 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     };
     enum { BK_NONE = 0, BK_GH = 1, BK_SAMPLE = 2, BK_ANY = 3, BK_LG = 4 };
     int pend = BK_NONE;                                 // run-time kind of the pending half, read only where two kinds can meet (BK_ANY sites)
+    int last_here = nact - 1;                           // the last gh stage in front of a step's other stages (see the step loop)
+    bool deferred = false;                              // the running gh stage is the deferred one of the previous step
 
     // kind 1: gh stage of slot i (polls h(t)); kind 3: MOL sampling stage of my_slot (polls y2(t)); RAW: kind 2: logits stage of slot i (polls y2(t)),
     // kind 4: sampling stage of my_slot (polls the 512 logits)
@@ -837,7 +842,8 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             xahead = false;
             if (kind == 1 || kind == 2) {
                 int so = -1;
-                if (i + 1 < nact) so = sbase + MAXCL * DSLOTB + (kind == 1 ? L_H : 3) * DLAYERB + ring * XTB;
+                if (kind == 1 && deferred) so = -1;                                                                         // (the next stage belongs to the next step)
+                else if (i < (kind == 1 ? last_here : nact - 1)) so = sbase + MAXCL * DSLOTB + (kind == 1 ? L_H : 3) * DLAYERB + ring * XTB;
                 else if (kind == 1 && !LA && !MOL) so = cbase + 3 * DLAYERB + ring * XTB;                                   // RAW: the logits stage of slot 0
                 else if (sampler) so = cbase + my_slot * (MAXCL * DSLOTB) + (MOL ? 3 : 16) * DLAYERB + ring * XTB;      // the sampling stage
                 if (so >= 0) {
@@ -987,14 +993,29 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     using BANY = std::integral_constant<int, BK_ANY>;
     cond_step(T0);                                      // (the two steps a launch starts with; every later one is formed two steps ahead)
     if (T0 + 1 < T1) cond_step(T0 + 1);
-    for (; t < T1; ++t) {
+    // Order of a step's stages.  The gh stages are off every chain (their output is read a step later); the stages behind them -- the MOL
+    // sampling of this workgroup's slot, RAW's logits -- are ON their slot's chain, and with the plain order gh(0) .. gh(n-1) | sample the gh
+    // stage of the LAST slot (whose h2 arrives last) sits right in front of them: y2 of slot 0 is there ~one stage earlier than this
+    // workgroup is free.  So the last slot's gh stage is deferred to the top of the NEXT step (its product, gh(t+1) of that slot, is needed
+    // late in that step): gh(n-1)@t-1 | gh(0) .. gh(n-2) | sample ...  -- the same two call sites (every call site of `stage` is a full
+    // inlined copy), one more loop iteration at the end of a launch for the last deferred stage.
+    const bool shift = DUO_GH_SHIFT && nact >= 2;
+    last_here = shift ? nact - 2 : nact - 1;
+    for (; t <= T1; ++t) {
+        const bool late = shift && t > T0;              // this iteration starts with the deferred stage of step t - 1
+        if (t == T1 && !late) break;
         if constexpr (LA) {
             if (t + 2 < T1) cond_step(t + 2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // ... and out before anything of this step is published
         }
-        stage(K1{}, BANY{}, 0);
+        deferred = late;
+        if (late) --t;
+        stage(K1{}, BANY{}, late ? nact - 1 : 0);
+        if (late) ++t;
+        deferred = false;
+        if (t == T1) break;
 #pragma unroll 1
-        for (int i = 1; i < nact; ++i) stage(K1{}, BGH{}, i);
+        for (int i = late ? 0 : 1; i <= last_here; ++i) stage(K1{}, BGH{}, i);
         if constexpr (!LA && MOL) {
             if (sampler) stage(K3{}, BGH{}, my_slot);
         }
