@@ -7,7 +7,6 @@ every slot).  rnn1's hh workgroups are off every chain and left out.
 
     python scripts/sim_stage_order.py            # prints us per step for depth 1..8 and a few orders
 """
-import itertools
 
 HOP = 1.2            # publish -> the consumer's poll sees it (us)
 A_G_MFMA, A_G_BACK = 2.35, 1.15      # rnn1 gates: front (issue, cI load, 96 MFMAs + partial tiles) | back half (reduce, pointwise, publish x1, h1)
@@ -101,7 +100,9 @@ def interleaved(G, lag):
 
 
 if __name__ == '__main__':
-    print('depth: us per step (model) for the kernel\'s order | sampler samples before its last gh stage | ih stages interleaved with lag 1, 2, 3')
+    # (the kernel's order since the end of round 4 is the second column: the last slot's gh stage deferred behind the sampling stage;
+    # measured: 24.8 -> 23.7 us at depth 4, 41.2 -> 40.5 at depth 8, profiles/r04p_probe.json)
+    print('depth: us per step (model) for gh(0..n-1) | sample | the last gh stage behind the sampling stage | ih stages interleaved with lag 1, 2, 3')
     for G in range(1, 9):
         base = simulate(G)
         early = simulate(G, s_order=sampler_early)
