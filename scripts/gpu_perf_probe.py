@@ -38,7 +38,7 @@ VARS = {'auto': dict(algo='auto'), 'stream': dict(algo='stream'), 'g1': dict(alg
         'g3': dict(algo='loop', depth=3), 'g4': dict(algo='loop', depth=4), 'g6': dict(algo='loop', depth=6), 'g8': dict(algo='loop', depth=8),
         'c1g1': dict(algo='loop', clusters=1, depth=1), 'c2g1': dict(algo='loop', clusters=2, depth=1), 'c1g2': dict(algo='loop', clusters=1, depth=2),
         'nola': dict(algo='loop', tuning=1), 'fence': dict(algo='loop', tuning=2), 'nola-fence': dict(algo='loop', tuning=3),
-        's1': dict(algo='sparse', depth=1), 's2': dict(algo='sparse', depth=2),
+        's1': dict(algo='sparse'), 'swt': dict(algo='sparse', tuning=256),       # wrnn_sparse_kernel (needs --prune); swt: every layer written through
         # wrnn_duo_kernel (round 4): tuning bit 0 = loads first, bit 1 = publish first (default: by depth), bit 8 = every layer written through
         # (no XCD-local plain stores), bit 2 = ring re-filled before every launch
         'd1': dict(algo='duo', depth=1), 'd2': dict(algo='duo', depth=2), 'd3': dict(algo='duo', depth=3), 'd4': dict(algo='duo', depth=4),

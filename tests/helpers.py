@@ -107,3 +107,73 @@ def oracle_stage2_rows(sd, mel, pad=2, scales=(5, 5)):
             y += w[j] * xp[:, j:j + x.shape[1]]
         x = y.astype(np.float32)
     return np.ascontiguousarray(x.T)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Full-size oracle references, one utterance at a time, with an on-disk cache (tests/_cache/, git-ignored, filled in the build container
+# by scripts/make_oracle_cache.py; it travels to the GPU box with the snapshot).  TEST INFRASTRUCTURE: nothing under wavernn_amd/ reads it.
+# ---------------------------------------------------------------------------------------------------------------------------------
+CACHE = os.path.join(ROOT, 'tests', '_cache')
+
+
+def _oracle_src_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ('wrnn_oracle.c', 'wavernn_oracle.py'):
+        h.update(open(os.path.join(ROOT, 'oracle', name), 'rb').read())
+    return h.hexdigest()[:12]
+
+
+def pruned_state_dict(mode, wseed, prune):
+    from wavernn_amd.synthetic import random_state_dict
+    sd = random_state_dict(wseed, mode=mode)
+    if prune > 0:
+        from wavernn_amd.prune import block_prune_state_dict
+        sd, _ = block_prune_state_dict(sd, prune, (16, 1))
+    return sd
+
+
+def oracle_utterance(mode, wseed, prune, mel_seed, noise_seed, frames, target=11000, overlap=550, nthreads=8, want_cond=True, sd=None):
+    """The C oracle's loop output for ONE utterance generated the reference's way (random mel `mel_seed` of `frames` frames, weights
+    `random_state_dict(wseed)` block-pruned to `prune`, batched fold, `torch.manual_seed(noise_seed)` noise stream): dict(ref = [B, T]
+    float32 -- RAW: 2 idx / (C - 1) - 1 --, and with want_cond the oracle-side conditioning: mels_up [L, 80], aux [frames, 128], noise in
+    the launch layout).  `ref` comes from tests/_cache when an entry made by the same oracle sources exists."""
+    from oracle import c_oracle as C, wavernn_oracle as O
+    from wavernn_amd.synthetic import random_mel
+    key = f'{mode}_w{wseed}_p{int(round(prune * 1000))}_m{mel_seed}_n{noise_seed}_f{frames}_t{target}_o{overlap}_{_oracle_src_sha()}'
+    path = os.path.join(CACHE, key + '.npz')
+    sd = pruned_state_dict(mode, wseed, prune) if sd is None else sd
+    mel = random_mel(mel_seed, frames)
+    res = {}
+    ref = None
+    if os.path.exists(path):
+        z = np.load(path)
+        ref = z['idx'].astype(np.float32) * np.float32(2) / np.float32(z['classes'] - 1) - np.float32(1) if mode == 'RAW' else z['ref']
+    if ref is None or want_cond:
+        mels_f, aux_f, _ = O.conditioning(sd, mel, True, target, overlap)
+        B, T = mels_f.shape[:2]
+        if mode == 'RAW':                  # (torch's CPU generator: the stream the oracle's numpy model restates, 20x faster for 10^8 draws)
+            import torch
+            from wavernn_amd.rng import draw_noise
+            nz = draw_noise('RAW', B, T, 512, 512, 32, 'cpu', 'cpu', generator=torch.Generator(device='cpu').manual_seed(noise_seed)).numpy()
+        else:
+            nz = O.draw_noise(noise_seed, mode, B, T)
+        if ref is None:
+            C.build()
+            ref = C.loop(sd, mode, mels_f, aux_f, nz, nthreads=nthreads)
+            os.makedirs(CACHE, exist_ok=True)
+            tmp = path + f'.{os.getpid()}.tmp.npz'
+            if mode == 'RAW':
+                idx = np.rint((ref.astype(np.float64) + 1.0) * 511.0 / 2.0).astype(np.int16)
+                assert np.array_equal(idx.astype(np.float32) * np.float32(2) / np.float32(511) - np.float32(1), ref)
+                np.savez_compressed(tmp, idx=idx, classes=512)
+            else:
+                np.savez(tmp, ref=ref)
+            os.replace(tmp, path)
+        if want_cond:
+            m = O.pad_tensor(mel.T[None], 2, 'both')[0].T
+            mu, au = O.upsample_network(sd, m)
+            res.update(mels_up=mu, aux=np.ascontiguousarray(au[::275]),
+                       noise=nz if mode == 'RAW' else np.concatenate([nz[0].reshape(T, -1), nz[1].reshape(T, -1)], axis=1))
+    res['ref'] = ref
+    return res

@@ -225,24 +225,81 @@ def test_corpus_slice_matches_per_utterance_oracle(gpu):
 
 
 def test_block_sparse_kernel_full_length_matches_oracle(gpu):
-    """BASELINE config 5 at T = 12,100: two 641-frame utterances (32 segments) on 95 %-block-pruned GRU weights through
-    `wrnn_sparse_kernel` vs the C oracle on the same masked dense weights."""
+    """BASELINE config 5 at T = 12,100: two 641-frame utterances (32 segments = 2 clusters) on 95 %-block-pruned GRU weights through
+    `wrnn_sparse_kernel` (`auto` for such a pack; oracle-side conditioning, materialised mel) vs the C oracle on the same masked dense
+    weights -- and the dense wrnn_duo_kernel on the same masked weights, same bar."""
     from wavernn_amd.engine import LoopEngine
     from wavernn_amd.prune import block_prune_state_dict
     from wavernn_amd.synthetic import random_state_dict
     sd, _ = block_prune_state_dict(random_state_dict(0, mode='MOL'), 0.95, (16, 1))
     plan, mels_up, aux, flat, refs = _corpus_inputs(sd, 'MOL', [641, 641], [1234, 1235], [77, 78])
     eng = LoopEngine(sd, 'MOL', device=gpu)
-    out = eng.run_segments(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), plan.seg_pos, plan.seg_lim, plan.T,
-                           torch.from_numpy(flat).to(gpu), HOP, algo='sparse').cpu().numpy()
-    assert eng.last_loop_kernel() == 'wrnn_sparse_kernel'
+    for algo, kernel in (('auto', 'wrnn_sparse_kernel'), ('duo', 'wrnn_duo_kernel')):
+        out = eng.run_segments(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), plan.seg_pos, plan.seg_lim, plan.T,
+                               torch.from_numpy(flat).to(gpu), HOP, algo=algo).cpu().numpy()
+        assert eng.last_loop_kernel() == kernel
+        for u, ref in enumerate(refs):
+            got = out[plan.first[u]:plan.first[u] + plan.folds[u]]
+            assert np.abs(got - ref).max() <= MOL_TOL, (algo, u, np.abs(got - ref).max())
+
+
+def test_config5_256_segments_matches_oracle(gpu):
+    """BASELINE config 5 AS BENCHMARKED (`bench.py` `config.config5`): the GRU matrices 95 % block-sparse (16x1 blocks), 16 x 641-frame
+    utterances = 256 segments x 12,100 steps through `generate_corpus` -- HIP pre-loop kernels, the last up-sampling stage formed inside
+    the loop (wrnn_options.mel_stage = 1), `algo = auto` -> wrnn_sparse_kernel: all 16 clusters, one group each, one round --, parity
+    noise, against the C oracle on the masked dense weights per utterance (round-4 verdict: 256 segments, was 32).  The loop's
+    workspace must not depend on T."""
+    from helpers import oracle_utterance, pruned_state_dict
+    from wavernn_amd.batch import generate_corpus
+    from wavernn_amd.synthetic import random_mel
+    sd = pruned_state_dict('MOL', 0, 0.95)
+    model = _model(sd, 'MOL', gpu)
+    NU = 16
+    mels = [torch.from_numpy(random_mel(1234 + u, 641)).unsqueeze(0) for u in range(NU)]
+    segs, plan = generate_corpus(model, mels, TARGET, OVERLAP, True, [77 + u for u in range(NU)], return_segments=True)
+    eng = model._loop_engine()
+    info = eng.last_run_info()
+    print(f'config 5: {info} {eng.last_loop_ms():.1f} ms')
+    assert plan.n_segments == 256 and plan.T == 12100
+    assert info['kernel'] == 'wrnn_sparse_kernel' and (info['clusters'], info['depth'], info['rounds']) == (16, 1, 1)
+    assert model.mel_rows_ok(eng, 256, plan.T)
+    ws = [eng.workspace_bytes(256, T, 16 * 641) for T in (12100, 121000)]
+    assert ws[0] == ws[1] and ws[0] < 300e6, ws
+    refs = _pool_map(lambda u: oracle_utterance('MOL', 0, 0.95, 1234 + u, 77 + u, 641, want_cond=False, sd=sd)['ref'], list(range(NU)))
     for u, ref in enumerate(refs):
-        got = out[plan.first[u]:plan.first[u] + plan.folds[u]]
+        got = segs[plan.first[u]:plan.first[u] + plan.folds[u]].astype(np.float32)
         assert np.abs(got - ref).max() <= MOL_TOL, (u, np.abs(got - ref).max())
-    # round 4: `auto` runs a block-sparse pack on the (faster) dense wrnn_duo_kernel; same weights, same bar
-    out = eng.run_segments(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), plan.seg_pos, plan.seg_lim, plan.T,
-                           torch.from_numpy(flat).to(gpu), HOP, algo='auto').cpu().numpy()
-    assert eng.last_loop_kernel() == 'wrnn_duo_kernel'
+
+
+@pytest.mark.parametrize('mode', ['RAW', 'MOL'])
+def test_bench_legs_as_benchmarked_match_oracle(gpu, mode):
+    """The bench's RAW and MoL legs AS BENCHMARKED (round-4 verdict, "What's weak" 1): 16 x 641-frame utterances = 256 segments x
+    12,100 steps through `generate_corpus` -- HIP pre-loop kernels, `mel_in_loop` on, so the loop kernel forms the last up-sampling
+    stage itself (wrnn_options.mel_stage = 1) --, `algo = auto` (wrnn_duo_kernel, 4 clusters x 4 groups in flight), parity noise
+    (per-utterance MT19937 streams, seeds 77 + u) drawn and uploaded in step slices, against the C oracle per utterance.
+    RAW: the class indices are BIT-IDENTICAL (3.1 M segment-steps, free-running); MoL: <= MOL_TOL."""
+    from helpers import oracle_utterance
+    from wavernn_amd.batch import generate_corpus
+    from wavernn_amd.synthetic import random_state_dict, random_mel
+    sd = random_state_dict(0, mode=mode)
+    model = _model(sd, mode, gpu)
+    assert model.pre_algo == 'native' and model.mel_in_loop and model.loop_algo == 'auto'
+    NU = 16
+    mels = [torch.from_numpy(random_mel(1234 + u, 641)).unsqueeze(0) for u in range(NU)]
+    segs, plan = generate_corpus(model, mels, TARGET, OVERLAP, True, [77 + u for u in range(NU)], return_segments=True)
+    eng = model._loop_engine()
+    info = eng.last_run_info()
+    print(f'bench leg [{mode}]: {info}, mel rows in loop: {model.mel_rows_ok(eng, 256, plan.T)}')
+    assert plan.n_segments == 256 and plan.T == 12100
+    assert info['kernel'] == 'wrnn_duo_kernel' and (info['clusters'], info['depth'], info['rounds']) == (4, 4, 1)
+    assert model.mel_rows_ok(eng, 256, plan.T)                    # the call above ran with the mel one up-sampling stage short
+    if mode == 'RAW':
+        assert info['launches'] > 8                               # the noise went up in several step slices (continued launches)
+    refs = _pool_map(lambda u: oracle_utterance(mode, 0, 0.0, 1234 + u, 77 + u, 641, want_cond=False, sd=sd)['ref'], list(range(NU)))
     for u, ref in enumerate(refs):
-        got = out[plan.first[u]:plan.first[u] + plan.folds[u]]
-        assert np.abs(got - ref).max() <= MOL_TOL, (u, np.abs(got - ref).max())
+        got = segs[plan.first[u]:plan.first[u] + plan.folds[u]].astype(np.float32)
+        if mode == 'RAW':
+            bad = np.argwhere(got != ref)
+            assert bad.size == 0, f'utterance {u}: {len(bad)} samples differ, first at (segment, step) = {bad[0]}'
+        else:
+            assert np.abs(got - ref).max() <= MOL_TOL, (u, np.abs(got - ref).max())

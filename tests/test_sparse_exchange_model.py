@@ -1,0 +1,113 @@
+"""A discrete-event MODEL of wrnn_sparse_kernel's exchange (csrc/wrnn_sparse.hip, round 5): one workgroup per CU, 8 rnn1 + 8 rnn2 workgroups
+per cluster (here: n + n), ONE group per cluster, every stage in one instruction stream per workgroup:
+
+    rnn1 j:  drain | x_{t-1} (tagged) -> cell -> publish x1, h1 | poll h1(t) -> gh (registers) | poll x2(t) -> publish y1 | poll y1(t),
+             RE-ARM own words of entry t + 2, publish y2 | poll cI(t + 1) -> W_ih . cI | form cI(t + 2)
+    rnn2 j:  drain | poll x1(t) -> cell -> publish x2, h2 | poll x2(t) -> publish y1 | poll h2(t) -> gh | poll y1(t), RE-ARM, publish y2 |
+             j = 0: poll y2(t) -> sample -> x_t as a tagged word in entry t % 2
+
+Sentinel layers (h1 x1 h2 x2 y1 y2): four ring entries, re-armed two steps ahead after the last poll of the step, drained at the top of the
+next step.  cI: no sentinel inside a launch, formed one step ahead of its use at the END of a step and covered by the same drain.  x_t: a
+tagged word, two entries, never re-armed.  Checked under adversarial timing (the engine of tests/test_duo_exchange_model.py: stores land
+after random delays, out of order, now and then later than ten whole steps -- only a drain waits for them): whatever a consumer accepts
+carries ITS step in every word, no re-arm lands on data still to be read, no tagged word is overwritten before it was read, everybody
+finishes.  The broken variants show the model is not vacuous.  A model of the protocol, not of the HIP code (tests/test_gpu_parity.py)."""
+from test_duo_exchange_model import DuoSim, RING, SENT
+
+
+class SparseSim(DuoSim):
+    def __init__(self, seed, n=3, steps=24, ahead=2, drain=True, rearm_site='fc2', cond_lead=1):
+        super().__init__(seed, n_wg=n, slots=1, steps=steps)
+        self.n, self.ahead, self.drain, self.rearm_site, self.cond_lead = n, ahead, drain, rearm_site, cond_lead
+        ring = lambda producers, entries: [[[SENT] * producers for _ in range(entries)]]          # [slot 0][entry][producer]
+        self.mem = {l: ring(n, RING) for l in ('h1', 'x1', 'h2', 'x2', 'cI')}
+        self.mem['y1'], self.mem['y2'] = ring(2 * n, RING), ring(2 * n, RING)
+        self.mem['xt'] = ring(1, 2)
+
+    def run(self):
+        procs = [self.program(role, j) for role in ('A', 'B') for j in range(self.n)]
+        for p in procs:
+            self.resume(p)
+        import heapq
+        while self.events and self.now < 60000.0:
+            self.now, _, fn = heapq.heappop(self.events)
+            fn()
+        if self.done != len(procs):
+            self.violations.append(f'no progress: {self.done} of {len(procs)} workgroups finished')
+        return self.violations
+
+    def program(self, role, j):
+        who, n, steps = (role, j), self.n, self.steps
+        a = role == 'A'
+        yj = j if a else n + j                                # this workgroup's words of the y layers
+        mine = ('h1', 'x1') if a else ('h2', 'x2')
+
+        def publish(layer, t, idx):
+            self.store(who, layer, 0, t % RING, idx, t)
+
+        def rearm(t):
+            for layer, idx in ((mine[0], j), (mine[1], j), ('y1', yj), ('y2', yj)):
+                self.store(who, layer, 0, (t + self.ahead) % RING, idx, SENT, rearm_turn=t + self.ahead - RING + 1)
+
+        def form(tt):
+            if a and tt < steps:
+                self.store(who, 'cI', 0, tt % RING, j, tt)
+
+        if a:
+            form(0); form(1)
+            yield ('poll', ('cI', 0, 0)); yield ('work', 0.5)                     # front half of step 0
+        for t in range(steps):
+            if self.drain:
+                yield ('drain', who)
+            if self.rearm_site == 'top':
+                rearm(t)
+            if a:
+                if t > 0:
+                    yield ('tag', ('xt', 0, 0, t - 1))
+                yield ('work', 0.3)
+                publish('x1', t, j); publish('h1', t, j)
+                yield ('poll', ('h1', 0, t)); yield ('work', 0.5)                  # gh(t + 1), kept in registers
+                yield ('poll', ('x2', 0, t)); yield ('work', 0.4); publish('y1', t, yj)
+                yield ('poll', ('y1', 0, t))
+                if self.rearm_site == 'fc2':
+                    rearm(t)
+                yield ('work', 0.4); publish('y2', t, yj)
+                if t + 1 < steps:
+                    yield ('poll', ('cI', 0, t + 1)); yield ('work', 0.5)          # (no sentinel from step 2 on: the words must be step t + 1's)
+                form(t + 1 + self.cond_lead)
+            else:
+                yield ('poll', ('x1', 0, t)); yield ('work', 0.6)
+                publish('x2', t, j); publish('h2', t, j)
+                yield ('poll', ('x2', 0, t)); yield ('work', 0.4); publish('y1', t, yj)
+                yield ('poll', ('h2', 0, t)); yield ('work', 0.5)
+                yield ('poll', ('y1', 0, t))
+                if self.rearm_site == 'fc2':
+                    rearm(t)
+                yield ('work', 0.4); publish('y2', t, yj)
+                if j == 0:
+                    yield ('poll', ('y2', 0, t)); yield ('work', 0.8)
+                    self.store(who, 'xt', 0, t % 2, 0, t)
+
+
+def test_sparse_exchange_is_safe_under_adversarial_timing():
+    for seed in range(60):
+        for n in (1, 2, 3):
+            v = SparseSim(seed, n=n, steps=24).run()
+            assert not v, (seed, n, v[:3])
+
+
+def test_sparse_model_detects_the_shortcuts():
+    def broken(**kw):
+        return any(SparseSim(seed, steps=30, **kw).run() for seed in range(80))
+    assert broken(drain=False)                # a late re-arm (or a late cI) lands on / hides newer data
+    assert broken(ahead=1)                    # re-armed one ahead: the publication of the next step can overtake the re-arm
+    assert broken(cond_lead=0)                # cI formed only when it is needed: the readers (no sentinel to poll) take the entry's old content
+
+
+def test_other_safe_distances():
+    """Also safe (not what the kernel does): three ahead, or the re-arm at the top of the step -- every workgroup polls x2 and y1 of EVERY
+    workgroup in every step, so when one has finished step t - 1 nobody still reads data of step t - 2."""
+    for seed in range(30):
+        for kw in (dict(ahead=3), dict(rearm_site='top')):
+            v = SparseSim(seed, steps=24, **kw).run()
+            assert not v, (seed, kw, v[:3])

@@ -14,7 +14,7 @@ SO_PATH = os.path.join(CSRC, 'libwavernn_amd.so')
 WRNN_OK = 0
 ERR_RESIDENCY = -6          # WRNN_ERR_RESIDENCY: the persistent grid cannot be co-resident on this device
 MODE_RAW, MODE_MOL = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 ALGO_AUTO, ALGO_STREAM, ALGO_LOOP, ALGO_SPARSE, ALGO_DUO = 0, 1, 2, 5, 6
 ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'loop': ALGO_LOOP, 'sparse': ALGO_SPARSE, 'duo': ALGO_DUO}
 

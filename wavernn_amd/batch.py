@@ -75,14 +75,16 @@ def shard_bounds(n_segments: int, world: int):
     return [((r * n_segments) // world, ((r + 1) * n_segments) // world) for r in range(world)]
 
 
-def pack_noise(mode: str, plan: Plan, per_utt, lo: int = 0, hi: Optional[int] = None):
+def pack_noise(mode: str, plan: Plan, per_utt, lo: int = 0, hi: Optional[int] = None, steps: Optional[int] = None):
     """Arrange per-utterance noise into the layout `wrnn_generate_segments` reads for segments [lo, hi).
 
     per_utt[u] is utterance u's noise exactly as the reference draws it for that utterance alone: MOL
     (T, 11*B_u) = per step 10*B_u mixture uniforms (segment-major) then B_u logistic uniforms; RAW (T, B_u, C).
     Entries for utterances without a segment in [lo, hi) may be None.  numpy in -> numpy out, torch in -> torch out.
+    steps: the rows are a slice of `steps` consecutive loop steps instead of all plan.T (a step-sliced run).
     """
     hi = plan.n_segments if hi is None else hi
+    T = plan.T if steps is None else int(steps)
     n = hi - lo
     utts = [u for u in range(len(plan.lengths)) if plan.first[u] < hi and plan.first[u] + plan.folds[u] > lo]
     sample = per_utt[utts[0]]
@@ -94,13 +96,13 @@ def pack_noise(mode: str, plan: Plan, per_utt, lo: int = 0, hi: Optional[int] = 
         a, b = max(lo, f0) - f0, min(hi, f0 + Bu) - f0          # this utterance's segments [a, b) are in the block
         z = per_utt[u]
         if mode == 'MOL':
-            z = z.reshape(plan.T, 11 * Bu)
+            z = z.reshape(T, 11 * Bu)
             mix.append(z[:, 10 * a:10 * b])
             logi.append(z[:, 10 * Bu + a:10 * Bu + b])
         else:
-            raw.append(z.reshape(plan.T, Bu, -1)[:, a:b])
+            raw.append(z.reshape(T, Bu, -1)[:, a:b])
     out = cat(mix + logi, 1) if mode == 'MOL' else cat(raw, 1)
-    assert out.shape[0] == plan.T and (out.shape[1] == 11 * n if mode == 'MOL' else out.shape[1] == n)
+    assert out.shape[0] == T and (out.shape[1] == 11 * n if mode == 'MOL' else out.shape[1] == n)
     return out.contiguous() if is_torch else np.ascontiguousarray(out)
 
 
@@ -149,7 +151,7 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
     stand-in to exercise the sharding / gather logic under gloo); the default is the model's LoopEngine.
     """
     import torch.distributed as dist
-    from .rng import draw_noise, draw_steps
+    from .rng import draw_steps
     if noise_source == 'cpu' and seeds is None:
         raise ValueError("noise_source='cpu' (parity noise) needs `seeds` (one per utterance); "
                          "pass noise_source='device' to draw from the device generator instead")
@@ -211,53 +213,72 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
                 return torch.cat(ups).contiguous(), torch.cat(auxs).contiguous()
             rows = eng is not None and native_pre and model.mel_rows_ok(eng, n_seg, T)
             mels_up, aux = conditioning(rows)
-            if noise_source == 'cpu':
-                for u in utts:
-                    g = torch.Generator(device='cpu').manual_seed(int(seeds[u]))
-                    noise[u] = draw_noise(mode, int(plan.folds[u]), plan.T, model.n_classes, model.rnn_dims, model.aux_dims,
-                                          'cpu', 'cpu', generator=g)
             # this chunk's segment table, rebased onto the conditioning of the utterances it touches
             rebase = np.array([local_off[int(u)] - int(plan.offsets[int(u)]) for u in plan.seg_utt[clo:chi]], dtype=np.int64)
             seg_pos = (plan.seg_pos[clo:chi].astype(np.int64) + rebase).astype(np.int32)
             seg_lim = (plan.seg_lim[clo:chi].astype(np.int64) + rebase).astype(np.int32)
             out_view = out_local[clo - lo:chi - lo]
+            # the reference's per-utterance CPU streams (parity noise): one private generator per utterance, the GRUCell constructor
+            # draws burnt once, then the loop's draws in step order -- so a slice of steps continues every stream where the last stopped
+            gens, pool = {}, None
             if noise_source == 'cpu':
-                nz = pack_noise(mode, plan, noise, clo, chi).to(device)
-            elif eng is not None and eng.plan(n_seg, T, algo=model.loop_algo)['kernel'] in ('wrnn_loop_kernel', 'wrnn_duo_kernel'):
-                # device noise in slices of steps (RAW is n_classes floats per segment-step): each slice continues the loop; at most
-                # `model.noise_chunk_bytes` of noise are resident (the same bound WaveRNN.generate() keeps)
-                from ._lib import ResidencyError
+                if len(utts) > 1 and mode == 'RAW':       # (MoL: 11 draws per segment-step -- not worth a thread)
+                    import os
+                    from concurrent.futures import ThreadPoolExecutor
+                    pool = ThreadPoolExecutor(max(1, min(len(utts), (os.cpu_count() or 2) // 2)))
+                from .rng import burn_ctor_draws
+                for u in utts:
+                    gens[u] = torch.Generator(device='cpu').manual_seed(int(seeds[u]))
+                    burn_ctor_draws(model.rnn_dims, model.aux_dims, 'cpu', gens[u])
+
+            def draw(steps_):
+                """noise rows of the next `steps_` loop steps of this chunk's segments, on the device"""
+                if noise_source != 'cpu':
+                    return draw_steps(mode, n_seg, steps_, model.n_classes, device, 'device')
+                def one(u):        # (ATen releases the GIL inside the fill: the utterances' independent streams are drawn side by side)
+                    noise[u] = draw_steps(mode, int(plan.folds[u]), steps_, model.n_classes, 'cpu', 'cpu', generator=gens[u])
+                if pool is None:
+                    for u in utts:
+                        one(u)
+                else:
+                    list(pool.map(one, utts))
+                return pack_noise(mode, plan, noise, clo, chi, steps=steps_).to(device)
+
+            if loop_fn is not None:
+                out_view[:] = loop_fn(mels_up, aux, seg_pos, seg_lim, T, draw(T), hop)
+                if pool is not None:
+                    pool.shutdown()
+                continue
+            from ._lib import ResidencyError
+            from .engine import RESUMABLE_KERNELS
+            # the persistent loop kernels continue a call (wrnn_options.t_begin / t_end): the noise -- RAW: n_classes floats per
+            # segment-step -- is drawn and uploaded in slices of steps, at most `model.noise_chunk_bytes` of it resident (the bound
+            # WaveRNN.generate() keeps); any other kernel takes the whole call's noise at once
+            steps = T
+            if eng.plan(n_seg, T, algo=model.loop_algo)['kernel'] in RESUMABLE_KERNELS:
                 per_step = n_seg * (11 if mode == 'MOL' else model.n_classes) * 4
                 steps = max(1, min(T, getattr(model, 'noise_chunk_bytes', 128 << 20) // per_step))
                 steps = -(-T // (-(-T // steps)))            # equal slices (no short tail slice with its own launches)
-                try:
-                    for t0 in range(0, T, steps):
-                        t1 = min(T, t0 + steps)
-                        nz = draw_steps(mode, n_seg, t1 - t0, model.n_classes, device, 'device')
-                        eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo=model.loop_algo, check=check, out=out_view,
-                                         t_range=None if (t0 == 0 and t1 == T) else (t0, t1))
-                    continue
-                except ResidencyError as e:     # the persistent grid was refused on the first slice: the whole chunk on the stream kernel
-                    import warnings
-                    warnings.warn(f'wavernn_amd: {e}; using the stream kernel')
-                    if rows:
-                        mels_up, aux = conditioning(False)
-                    nz = draw_noise(mode, n_seg, T, model.n_classes, model.rnn_dims, model.aux_dims, device, 'device')
-                    eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo='stream', check=check, out=out_view)
-                    continue
-            else:
-                nz = draw_noise(mode, n_seg, T, model.n_classes, model.rnn_dims, model.aux_dims, device, 'device')
-            if loop_fn is None:
-                from ._lib import ResidencyError
-                try:
-                    eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo=model.loop_algo, check=check, out=out_view)
-                except ResidencyError:
-                    if not rows:
-                        raise
-                    mels_up, aux = conditioning(False)      # (the other loop kernels read the up-sampled mel; the engine degrades as usual)
-                    eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, nz, hop, algo=model.loop_algo, check=check, out=out_view)
-            else:
-                out_view[:] = loop_fn(mels_up, aux, seg_pos, seg_lim, T, nz, hop)
+            try:
+                for t0 in range(0, T, steps):
+                    t1 = min(T, t0 + steps)
+                    eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, draw(t1 - t0), hop, algo=model.loop_algo, check=check, out=out_view,
+                                     t_range=None if (t0 == 0 and t1 == T) else (t0, t1))
+            except ResidencyError as e:
+                # the persistent grid was refused (on the first slice: a continuation cannot change kernels).  The other loop kernels read
+                # the up-sampled mel in full; the engine then degrades as usual on an unsliced call (one workgroup per CU, then the
+                # stream kernel), from the start of every utterance's noise stream
+                import warnings
+                warnings.warn(f'wavernn_amd: {e}; redoing the chunk unsliced on the next kernel')
+                if rows:
+                    mels_up, aux = conditioning(False)
+                for u in gens:
+                    gens[u].manual_seed(int(seeds[u]))
+                    burn_ctor_draws(model.rnn_dims, model.aux_dims, 'cpu', gens[u])
+                eng.run_segments(mels_up, aux, seg_pos, seg_lim, T, draw(T), hop, algo=model.loop_algo, check=check, out=out_view)
+            finally:
+                if pool is not None:
+                    pool.shutdown()
     # ---- the ONE collective of the path: an all-gather of the finished audio, asynchronous so that the utterances lying entirely in
     #      this rank's block are unfolded (post-loop stage) while the other ranks' segments are still on their way over xGMI
     n_utt = len(frames)

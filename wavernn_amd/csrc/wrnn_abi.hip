@@ -29,8 +29,11 @@ int duo_clusters(int n_cus);
 int duo_max_depth();
 size_t duo_xbuf_bytes(int G);
 size_t duo_xbuf_bytes_max();
-hipError_t launch_sparse(const LoopArgs &args, int G, int ncl, int nbp, hipStream_t stream);
+hipError_t launch_sparse(const LoopArgs &args, int nbp, hipStream_t stream);
 int sparse_clusters(int n_cus);
+size_t sparse_state_floats();
+size_t sparse_xbuf_bytes();
+hipError_t launch_put_floats(float *dst, const float *src, int n, hipStream_t stream);
 int selftest_mfma(char *msg, size_t n);
 int selftest_allgather(int n_cus, char *msg, size_t n, float *us_per_round);
 int selftest_tanh(char *msg, size_t n);
@@ -388,7 +391,7 @@ struct Plan {
 
 struct WsLayout {
     size_t status, xcc, segs, melc, c2f, c3f, c4f;
-    size_t gran, cI, npre;              // stream / sparse kernels: granules, whole-T conditioning, derived MOL noise
+    size_t gran, cI, npre;              // stream kernel: granules, whole-T conditioning; persistent kernels: one slab of derived MOL noise
     size_t xbuf, state, cIf;            // loop kernel: exchange buffer, per-round state, conditioning slab
     size_t total;
 };
@@ -407,7 +410,9 @@ const wrnn_options *norm_options(const wrnn_options *opt, wrnn_options *tmp)
     return tmp;
 }
 
-// kernel choice: sparse if the pack qualifies, else the loop kernel (RAW with 512 classes or MOL, >= 64 CUs), else stream
+// kernel choice: the block-sparse kernel if the pack qualifies (MOL, every 16-row block row of the GRU matrices keeps <= 64 columns) on a
+// 256-CU device, else the two-workgroups-per-CU loop kernel (RAW with 512 classes or MOL, >= 128 CUs), else the one-per-CU loop kernel,
+// else stream
 int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
 {
     const bool shape_ok = (p->mode == WRNN_MODE_MOL) || (p->C == H);
@@ -430,20 +435,27 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
         pl->kind = K_GENERIC;
         return WRNN_OK;
     }
-    // (round 4: `auto` no longer picks wrnn_sparse_kernel for a block-sparse pack -- the dense wrnn_duo_kernel is faster than that
-    // round-1 design at every batch size measured (9.3 vs 7.7 M samples/s at 256 segments); it stays available as WRNN_ALGO_SPARSE)
-    if (algo == WRNN_ALGO_SPARSE) {
-        const int scl = sparse_clusters(p->n_cus);
-        if (!p->sp_nbp || scl < 1) {
-            set_err("block-sparse kernel needs MOL, >= 32 CUs and GRU matrices with <= 64 surviving 16x1 blocks per block row "
-                    "(this pack: up to %d)", p->sp_max_blocks);
-            return WRNN_ERR_ARG;
-        }
-        int g = o->depth;
-        if (g < 1 || g > SPG) g = groups > scl ? 2 : 1;
-        pl->kind = K_SPARSE; pl->ncl = scl; pl->G = g;
-        pl->rounds = (groups + scl * g - 1) / (scl * g);
-        if ((double)pl->rounds * T >= 4.0e9) { set_err("too many steps"); return WRNN_ERR_ARG; }
+    // a block-sparse pack runs on wrnn_sparse_kernel (round 5: 16 clusters of 16 CUs, one group of 16 segments each -- the step is the
+    // latency of one chain, and sixteen chains run side by side): `auto` picks it whenever the pack and the device qualify
+    const int scl = sparse_clusters(p->n_cus);
+    if (algo == WRNN_ALGO_SPARSE && (!p->sp_nbp || scl < 1)) {
+        set_err("block-sparse kernel needs MOL, >= 256 CUs and GRU matrices with <= 64 surviving 16x1 blocks per block row "
+                "(this pack: up to %d; device: %d CUs)", p->sp_max_blocks, p->n_cus);
+        return (!p->sp_nbp) ? WRNN_ERR_ARG : WRNN_ERR_RESIDENCY;
+    }
+    if (algo == WRNN_ALGO_SPARSE || (algo == WRNN_ALGO_AUTO && p->sp_nbp && scl >= 1)) {
+        pl->kind = K_SPARSE; pl->ncl = scl; pl->G = 1;
+        pl->rounds = (groups + scl - 1) / scl;
+        pl->per_round = (B + pl->rounds - 1) / pl->rounds;
+        pl->ngr_max = (pl->per_round + SEG - 1) / SEG;
+        if (pl->ngr_max > scl) { pl->rounds += 1; pl->per_round = (B + pl->rounds - 1) / pl->rounds; pl->ngr_max = (pl->per_round + SEG - 1) / SEG; }
+        int slab = o->slab_steps;
+        if (slab < 1) slab = (int)((32u << 20) / ((size_t)pl->per_round * 11 * sizeof(float) * pl->rounds));      // one slab of derived noise
+        if (slab < 16) slab = 16;
+        if (slab > 4096) slab = 4096;
+        if (slab > T) slab = T;
+        pl->slab = slab;
+        pl->tab_fps = DUO_TAB_FPS;
     } else if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_LOOP || algo == WRNN_ALGO_DUO) {
         int ncl = loop_clusters(p->n_cus);
         if (algo == WRNN_ALGO_DUO && (!shape_ok || duo_clusters(p->n_cus) < 1)) {
@@ -494,8 +506,8 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
             return WRNN_ERR_RESIDENCY;
         }
     }
-    if (pl->kind != K_LOOP && pl->kind != K_DUO && (pl->t0 != 0 || pl->t1 != T)) {
-        set_err("a partial step range [%d, %d) needs the loop kernel", pl->t0, pl->t1);
+    if (pl->kind != K_LOOP && pl->kind != K_DUO && pl->kind != K_SPARSE && (pl->t0 != 0 || pl->t1 != T)) {
+        set_err("a partial step range [%d, %d) needs a persistent loop kernel", pl->t0, pl->t1);
         return WRNN_ERR_ARG;
     }
     return WRNN_OK;
@@ -513,20 +525,21 @@ WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frame
     if (pl.kind == K_GENERIC) { l.total = o; return l; }
     // per-frame aux tables: one row per frame of the call's conditioning (+ the zero row) -- or, for wrnn_duo_kernel, per SEGMENT and
     // slab: (slab - 1) / hop + 2 rows per segment (+ the zero row), refilled for every slab: independent of the corpus' length
-    const size_t tab_rows = pl.kind == K_DUO ? (size_t)B * pl.tab_fps + 1 : (size_t)n_frames + 1;
+    const bool slabbed = pl.kind == K_DUO || pl.kind == K_SPARSE;       // conditioning formed in the loop, per-segment aux tables per slab
+    const size_t tab_rows = slabbed ? (size_t)B * pl.tab_fps + 1 : (size_t)n_frames + 1;
     l.c2f = o;    o = al(o + tab_rows * 3 * H * sizeof(float));
     l.c3f = o;    o = al(o + tab_rows * H * sizeof(float));
     l.c4f = o;    o = al(o + tab_rows * H * sizeof(float));
     const bool mol = p->mode == WRNN_MODE_MOL;
-    if (pl.kind == K_LOOP || pl.kind == K_DUO) {
-        l.xbuf = o;  o = al(o + (pl.kind == K_DUO ? duo_xbuf_bytes_max() : XBUF_FLOATS * sizeof(float)));
-        l.state = o; o = al(o + (size_t)pl.rounds * loop_state_floats(pl.G) * sizeof(float));
+    if (pl.kind == K_LOOP || slabbed) {
+        l.xbuf = o;  o = al(o + (slabbed ? duo_xbuf_bytes_max() : XBUF_FLOATS * sizeof(float)));
+        l.state = o; o = al(o + (size_t)pl.rounds * (pl.kind == K_SPARSE ? sparse_state_floats() : loop_state_floats(pl.G)) * sizeof(float));
         l.cIf = o;   if (pl.kind == K_LOOP) o = al(o + (size_t)pl.slab * pl.ngr_max * SEG * H * sizeof(float));      // (the duo kernel forms cI in the loop)
         l.npre = o;  if (mol) o = al(o + (size_t)pl.slab * 11 * B * sizeof(float));      // derived MOL noise of one slab
     } else {
         l.gran = o;  o = al(o + GRAN_BYTES);
         l.cI = o;    o = al(o + (size_t)T * B * H * sizeof(float));
-        l.npre = o;  if (mol && pl.kind == K_SPARSE) o = al(o + (size_t)T * 11 * B * sizeof(float));
+        l.npre = o;
     }
     l.total = o;
     return l;
@@ -633,7 +646,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
         pl.t0 = o->t_begin; pl.t1 = o->t_end;
         if (pl.t0 == 0 && pl.t1 == 0) pl.t1 = T;
         if (pl.t0 < 0 || pl.t1 > T || pl.t0 >= pl.t1) { set_err("bad step range [%d, %d) of T=%d", pl.t0, pl.t1, T); return WRNN_ERR_ARG; }
-        if (pl.kind != K_LOOP && pl.kind != K_DUO && (pl.t0 != 0 || pl.t1 != T)) { set_err("a partial step range needs the loop kernel"); return WRNN_ERR_ARG; }
+        if (pl.kind != K_LOOP && pl.kind != K_DUO && pl.kind != K_SPARSE && (pl.t0 != 0 || pl.t1 != T)) { set_err("a partial step range needs a persistent loop kernel"); return WRNN_ERR_ARG; }
     }
     const WsLayout l = ws_layout(p, pl, B, T, n_frames);
     if (workspace_bytes < l.total) { set_err("workspace %zu < required %zu", workspace_bytes, l.total); return WRNN_ERR_WORKSPACE; }
@@ -655,7 +668,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     if (o->mel_stage) {
         // the last up-sampling stage inside the loop: `mels_up` is that stage's input.  Everything is checked here, on the host: the
         // kernel reads rows j / s - 1 .. j / s + 1 without a bound.
-        if (pl.kind != K_DUO) { set_err("wrnn_options.mel_stage: only wrnn_duo_kernel forms the last up-sampling stage (this call runs on another kernel)"); return WRNN_ERR_ARG; }
+        if (pl.kind != K_DUO && pl.kind != K_SPARSE) { set_err("wrnn_options.mel_stage: only wrnn_duo_kernel / wrnn_sparse_kernel form the last up-sampling stage (this call runs on another kernel)"); return WRNN_ERR_ARG; }
         if (o->mel_stage != 1 || o->mel_scale != LAST_SCALE || !o->mel_taps || !o->seg_moff || o->mel_rows < 3) {
             set_err("wrnn_options.mel_stage=%d: needs mel_scale == %d (got %d), mel_taps, seg_moff, mel_rows >= 3", o->mel_stage, LAST_SCALE, o->mel_scale);
             return WRNN_ERR_ARG;
@@ -681,7 +694,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
             coef[3 * ph] = (float)c0; coef[3 * ph + 1] = (float)c1; coef[3 * ph + 2] = (float)c2;
         }
         HIPCHK(hipMemcpyAsync(ws + l.segs + (size_t)2 * B * sizeof(int), o->seg_moff, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ws + l.melc, coef, sizeof coef, hipMemcpyHostToDevice, stream));
+        HIPCHK(launch_put_floats((float *)(ws + l.melc), coef, 3 * LAST_SCALE, stream));       // (by value, as kernel arguments: `coef` is a stack array)
     }
     if (pl.kind == K_GENERIC) {
         GenArgs g;
@@ -709,10 +722,16 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     c.c2f = (float *)(ws + l.c2f); c.c3f = (float *)(ws + l.c3f); c.c4f = (float *)(ws + l.c4f);
     c.seg_pos = d_pos; c.seg_lim = d_lim;
     c.B = B; c.T = T; c.hop = hop; c.NF = n_frames;
-    if (pl.kind == K_DUO) {
+    const bool slabbed = pl.kind == K_DUO || pl.kind == K_SPARSE;
+    if (slabbed) {
         // the aux tables are per segment and slab (filled in the slab loop): a slab may not span more than tab_fps - 2 whole hops
         const long eff = (long)(pl.tab_fps - 2) * hop + 1;
         if (pl.slab > eff) pl.slab = (int)eff;
+        // (the kernels index the tables with 32-bit byte offsets inside one buffer resource)
+        if (((size_t)B * pl.tab_fps + 1) * 3 * H * sizeof(float) >= 0x7FFFF000ull) {
+            set_err("%d segments in one call: the per-slab aux tables exceed a 2 GB buffer resource; split the call (generate_corpus caps a launch at 4096 segments)", B);
+            return WRNN_ERR_ARG;
+        }
     } else HIPCHK(launch_cond_frames(c, stream));
 
     LoopArgs a;
@@ -740,10 +759,11 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     memset(&info, 0, sizeof info);
     info.clusters = pl.ncl; info.depth = pl.G; info.rounds = pl.rounds; info.slab_steps = pl.slab;
 
-    if (pl.kind == K_LOOP || pl.kind == K_DUO) {
-        // ---- role-split loop kernels: for every slab of steps { derived noise; for every round { conditioning slab; loop } } ----
-        const bool duo = pl.kind == K_DUO;
-        info.kernel = duo ? "wrnn_duo_kernel" : "wrnn_loop_kernel"; info.units_per_wg = 16;
+    if (pl.kind == K_LOOP || slabbed) {
+        // ---- persistent loop kernels: for every slab of steps { derived noise; for every round { conditioning slab; loop } } ----
+        const bool duo = slabbed, sparse = pl.kind == K_SPARSE;      // (duo: the conditioning is formed in the loop -- wrnn_duo_kernel and wrnn_sparse_kernel)
+        info.kernel = sparse ? "wrnn_sparse_kernel" : (duo ? "wrnn_duo_kernel" : "wrnn_loop_kernel"); info.units_per_wg = sparse ? 64 : 16;
+        a.sp_vals = p->sp_vals; a.sp_cols = p->sp_cols;
         const bool mol = p->mode == WRNN_MODE_MOL;
         a.xbuf = (float *)(ws + l.xbuf);
         a.cIf = (const float *)(ws + l.cIf);
@@ -774,13 +794,13 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                 // (every step re-arms the entries it will write two or three steps later), so it needs the fill only where a round starts: the first
                 // launch of a call that starts at step 0, or any launch when several rounds share the buffer
                 if (!duo) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, XBUF_FLOATS * sizeof(float), stream));
-                else if (s0 == 0 || pl.rounds > 1 || (o->tuning & 4)) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, duo_xbuf_bytes(pl.G), stream));
+                else if (s0 == 0 || pl.rounds > 1 || (o->tuning & 4)) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, sparse ? sparse_xbuf_bytes() : duo_xbuf_bytes(pl.G), stream));
                 if (duo) HIPCHK(hipMemsetAsync(ws + l.xcc, 0, XCC_WORDS * sizeof(unsigned), stream));      // placement handshake of this launch
-                a.state = (float *)(ws + l.state) + (size_t)r * loop_state_floats(pl.G);
+                a.state = (float *)(ws + l.state) + (size_t)r * (sparse ? sparse_state_floats() : loop_state_floats(pl.G));
                 a.t0 = s0; a.t1 = s1; a.cI_t0 = s0; a.rb0 = rb0; a.Btot = nr; a.NG = ngr; a.resume = s0 > 0 ? 1 : 0;
-                a.kind_tag = duo ? 2 : 1;
+                a.kind_tag = sparse ? 3 : (duo ? 2 : 1);
                 if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
-                hipError_t e = duo ? launch_duo(a, pl.ncl, p->mode, stream) : launch_loop(a, pl.ncl, p->mode, stream);
+                hipError_t e = sparse ? launch_sparse(a, p->sp_nbp, stream) : (duo ? launch_duo(a, pl.ncl, p->mode, stream) : launch_loop(a, pl.ncl, p->mode, stream));
                 // (two workgroups per CU not co-resident right now: WRNN_ERR_RESIDENCY -- the caller re-plans with WRNN_ALGO_LOOP, whose
                 // workspace layout is another one: wavernn_amd/engine.py does)
                 if (e != hipSuccess) {
@@ -794,33 +814,16 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
             if ((rc = enqueue_progress(o, s1, T, B, stream)) != WRNN_OK) return rc;
         }
     } else {
-        // ---- stream / block-sparse kernels: whole-T conditioning in [t][segment][H] order, one launch --------------------
+        // ---- stream kernel: whole-T conditioning in [t][segment][H] order, one launch --------------------
         c.cI = (float *)(ws + l.cI);
         a.cI = c.cI;
         a.gran = (u64 *)(ws + l.gran);
         HIPCHK(launch_cond(c, p->n_cus, o->cond_valu != 0, stream));
-        if (pl.kind == K_SPARSE) {
-            info.kernel = "wrnn_sparse_kernel"; info.units_per_wg = 16;
-            const long ng = (long)pl.rounds * pl.ncl * pl.G;
-            a.NG = ng < B ? (int)ng : B;
-            a.sp_vals = p->sp_vals; a.sp_cols = p->sp_cols;
-            HIPCHK(launch_noise_mol(noise, (float *)(ws + l.npre), (long)T * 11 * B, B, p->n_cus, stream));
-            a.noise_pre = (const float *)(ws + l.npre);
-            HIPCHK(hipMemsetAsync(ws + l.gran, 0, GRAN_BYTES, stream));
-            if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
-            hipError_t e = launch_sparse(a, pl.G, pl.ncl, p->sp_nbp, stream);
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                set_err("block-sparse cooperative launch failed: %s", hipGetErrorString(e));
-                return e == hipErrorCooperativeLaunchTooLarge ? WRNN_ERR_RESIDENCY : WRNN_ERR_HIP;
-            }
-        } else {
-            info.kernel = "wrnn_stream_kernel";
-            a.b0 = 0;
-            a.nb = B;
-            if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
-            HIPCHK(launch_stream(a, p->mode, stream));
-        }
+        info.kernel = "wrnn_stream_kernel";
+        a.b0 = 0;
+        a.nb = B;
+        if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
+        HIPCHK(launch_stream(a, p->mode, stream));
         if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
         info.launches = 1;
         if ((rc = enqueue_progress(o, T, T, B, stream)) != WRNN_OK) return rc;

@@ -293,6 +293,22 @@ hipError_t launch_cond_frames_slab(const CondArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
+// up to 64 floats handed over BY VALUE (kernel arguments are copied when the launch is enqueued): for small host arrays that live on
+// the caller's stack -- an asynchronous copy from them would rely on the runtime staging pageable sources before it returns
+struct PutFloats { float v[64]; };
+__global__ void wrnn_put_floats_kernel(float *dst, PutFloats src, int n)
+{
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = src.v[threadIdx.x];
+}
+hipError_t launch_put_floats(float *dst, const float *src, int n, hipStream_t stream)
+{
+    if (n < 1 || n > 64) return hipErrorInvalidValue;
+    PutFloats p;
+    for (int i = 0; i < 64; ++i) p.v[i] = i < n ? src[i] : 0.f;
+    hipLaunchKernelGGL(wrnn_put_floats_kernel, dim3(1), dim3(64), 0, stream, dst, p, n);
+    return hipGetLastError();
+}
+
 // one slab [a.t0, a.t1) of one round (a.rb0, a.B segments, a.NG groups) of cI in fragment order -> a.cI
 hipError_t launch_cond_frag(const CondArgs &a, int n_cus, hipStream_t stream)
 {

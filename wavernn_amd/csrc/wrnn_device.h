@@ -36,8 +36,7 @@ constexpr int LDA = 516;      // padded row stride (floats) of the LDS activatio
 constexpr int NGRAN = 5;      // granule buffers: h1, h2, y1, y2, (RAW) logits
 constexpr int MAXCL = 4;      // cluster kernels: at most 4 independent clusters per chip
 constexpr int MAXG = 3;       // pipelined kernel: at most 3 groups in flight per cluster
-constexpr int SPCL = 8;       // block-sparse kernel: 8 clusters (one per XCD)
-constexpr int SPG = 2;        // ... with up to 2 groups in flight each
+constexpr int SPCL = 8, SPG = 2;      // (sizing of the stream kernel's granule workspace; the round-1 block-sparse kernel's split)
 constexpr int GRAN_WORDS = SPCL * SPG * NGRAN * SEG * H;     // u64 granules in the workspace (>= MAXCL * MAXG * ...)
 static_assert(SPCL * SPG >= MAXCL * MAXG, "granule workspace");
 // role-split loop kernel (wrnn_loop.hip): tag-free exchange buffer [cluster][slot][layer h1 h2 y1 y2 lg x1 x2][ring][SEG*H floats]
@@ -70,7 +69,7 @@ struct LoopArgs {
     const float *c2f, *c3f, *c4f;       // [NF+1][3H], [NF+1][H], [NF+1][H]  per-frame aux projections + bias
     const float *noise;                 // MOL [T][11*Btot]; RAW [T][Btot][C]
     const float *noise_pre;             // MOL, pipelined kernel: [T][11*Btot] derived variates (wrnn_noise_mol_kernel)
-    // block-sparse GRU pack (wrnn_sparse.hip): matrix m in {ih1,hh1,ih2,hh2}, block row (workgroup wg, gate g), NBP padded blocks
+    // block-sparse GRU pack (wrnn_sparse.hip): matrix m in {ih1,hh1,ih2,hh2}, block row (16-row block rb, gate g), NBP padded blocks
     const float *sp_vals;               // [4][32][3][NBP][16]  block values (16 rows of one column)
     const int *sp_cols;                 // [4][32][3][NBP]      their column indices (padding: column 0, zero values)
     const float *force_x;               // optional [Btot][T]
@@ -110,7 +109,7 @@ struct LoopArgs {
     int tab_fps, tab_t0;                // wrnn_duo.hip: c2f / c3f / c4f are per-SEGMENT tables of the slab that starts at step tab_t0: row
                                         // (segment index in the call) * tab_fps + frame - (seg_pos + tab_t0) / hop; zero row = Nall * tab_fps
     unsigned *xcc_tab;                  // [MAXCL * 128] zeroed before every launch: XCC id + 1 of every workgroup (placement handshake)
-    int kind_tag;                       // 1 wrnn_loop_kernel, 2 wrnn_duo_kernel: recorded in status[8] by the launch that starts a call at step 0,
+    int kind_tag;                       // 1 wrnn_loop_kernel, 2 wrnn_duo_kernel, 3 wrnn_sparse_kernel: recorded in status[8] by the launch that starts a call at step 0,
                                         // checked by every continuing launch (the two kernels keep different state / ring layouts)
 };
 

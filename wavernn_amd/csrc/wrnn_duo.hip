@@ -70,10 +70,7 @@
 
 namespace wrnn {
 
-// A/B build switches (measured: profiles/r04c_*)
-#ifndef DUO_POLL_SLEEP
-#define DUO_POLL_SLEEP 1                     // s_sleep(n) between two polls of a layer; 0 = none
-#endif
+// A/B build switches (measured: profiles/r04c_*, r04g_*, r04p_*)
 #ifndef DUO_RAW_LOCK
 #define DUO_RAW_LOCK 4                       // RAW sampler: segments of a wave handled in lock step (4 = all of them: 13 VGPR spills in that role; 2: none?)
 #endif
@@ -81,31 +78,12 @@ namespace wrnn {
 #define DUO_XR_FIRST 1                       // 1 = the residual sum (on a slot's chain) is published before h (read a step later)
 #endif
 
-constexpr int DNX = 17;                      // layers: 0 h1  1 h2  2 y1  3 y2  4 cI  5 x1  6 x2  7 x_t  8-11 gh1  12-15 gh2 ([32 unit blocks][256 threads][r, z, n, tag])  16 RAW logits
-constexpr int DRING = 4;                     // ring entries per layer (by step)
-constexpr int DAHEAD_IH = 2;                 // re-arm distance (steps) of the layers an ih workgroup publishes, see above
-constexpr int DAHEAD_HH = 3;                 // ... of the layers an hh workgroup publishes
-constexpr int DGHRING = 2;                   // ring entries of the tagged gh words (no sentinel, no re-arm: two suffice)
 constexpr int DNWGC = 4 * LNJ;               // workgroups per cluster (128)
-// DUO_LAYER_PAD = 1: one 32 KB entry of padding behind every layer's ring.  With 128 KB per layer every (slot, layer) ring starts 0 or
-// 128 KB into a 256 KB window -- the span of one way of the 4 MB / 16-way L2 -- so, IF the L2 indexed its sets by plain address bits, the
-// entries an XCD keeps alive at depth 4 would pile 20 deep onto two eighths of the sets (more lines than ways, touched cyclically), and
-// 10-12 deep on every eighth with the pad.  Measured (profiles/r04j_traffic.log, r04j_probe_*.json): no difference in WRITE_SIZE /
-// FETCH_SIZE or in step time -- the sets are evidently hashed -- so the pad is off.
 #ifndef DUO_GH_SHIFT
 #define DUO_GH_SHIFT 1                        // hh workgroups: the gh stage of the last slot runs at the top of the next step (see duo_hh's step loop)
 #endif
-#ifndef DUO_LAYER_PAD
-#define DUO_LAYER_PAD 0
-#endif
-constexpr int DLAYER_ENTRIES = DRING + DUO_LAYER_PAD;
-constexpr size_t DXBUF_FLOATS = (size_t)LMAXG * MAXCL * DNX * DLAYER_ENTRIES * XT;      // [slot][cluster][layer][ring (+ pad)][XT]
 constexpr int DLOGS = 36;                    // as LOGS of wrnn_loop.hip
 constexpr int DPART = 2 * NW * 3 * 256;      // two ping-pong sets of [wave][tile 0..2][lane][4]
-constexpr int XTB = XT * 4;                  // bytes of one layer entry (32 KB)
-constexpr int DLAYERB = DLAYER_ENTRIES * XTB; // bytes of one layer's ring (+ pad)
-constexpr int DSLOTB = DNX * DLAYERB;        // bytes of one (slot, cluster)
-static_assert((size_t)LMAXG * MAXCL * DSLOTB < 0x7FFFFFFFull, "32-bit buffer offsets");
 // saved state of an ih workgroup's slot in global memory (the slot layout of wrnn_loop.hip, LGRP floats): [0, 768) gh(t1) of the
 // finished launch, [768, 1024) h, [1024, 1040) x_{t1-1} (A-ih), [1040, 1072) segment table
 static_assert(O_HOWN == 768 && O_XS == 1024 && O_SP == 1040, "saved state layout");
@@ -144,86 +122,6 @@ __device__ __forceinline__ void mfma3s(const float (&a0)[AF], const float (&a1)[
         c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[k], b[k], c2, 0, 0, 0);
     }
     o0 = c0; o1 = c1; o2 = c2;
-}
-
-// one fc3 tile with the A fragments already loaded (fragment order), B in registers; mfma_tile's order
-__device__ __forceinline__ f32x4 mfma1_frag(const float4 (&av)[8], const float (&b)[32])
-{
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-#pragma unroll
-    for (int r = 0; r < 8; r += 2) {
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].x, b[4 * r + 0], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].x, b[4 * r + 4], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].y, b[4 * r + 1], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].y, b[4 * r + 5], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].z, b[4 * r + 2], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].z, b[4 * r + 6], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].w, b[4 * r + 3], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].w, b[4 * r + 7], c1, 0, 0, 0);
-    }
-    return c0 + c1;
-}
-
-// the fragments of a wave as MFMA B operands
-__device__ __forceinline__ void frag_to_b(const u32x4 (&x)[8], float (&b)[32])
-{
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        b[4 * r + 0] = __uint_as_float(x[r].x);
-        b[4 * r + 1] = __uint_as_float(x[r].y);
-        b[4 * r + 2] = __uint_as_float(x[r].z);
-        b[4 * r + 3] = __uint_as_float(x[r].w);
-    }
-}
-// no word of the live segments' fragments is still the sentinel (wave-uniform; one compare of the running unsigned maximum)
-__device__ __forceinline__ bool frag_there(const u32x4 (&x)[8], bool live)
-{
-    unsigned m = 0u;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) m = max(max(m, max(x[r].x, x[r].y)), max(x[r].z, x[r].w));
-    return __all(m != SENT || !live);
-}
-
-// A bounded wait that does not fail the launch's control flow: `there()` (wave-uniform) is re-evaluated after every `reload()`; when
-// the spin limit expires or another workgroup has raised the abort flag the wave marks itself dead -- it skips every later wait and
-// runs on with whatever the buffers hold (its barrier sequence is unchanged, nothing hangs, wrnn_status() reports the failure).
-template <class There, class Reload>
-__device__ __forceinline__ void wait_for(There there, Reload reload, unsigned *status, bool &dead, unsigned code, int step)
-{
-    unsigned spins = 0;
-    while (!dead && !there()) {
-        if ((++spins & 255u) == 0u) {
-            if (ld_agent32(status) != 0u) { dead = true; break; }
-            if (spins > SPIN_LIMIT) { report_failure(status, code, blockIdx.x, step, threadIdx.x); dead = true; break; }
-        }
-        if (DUO_POLL_SLEEP) __builtin_amdgcn_s_sleep(DUO_POLL_SLEEP);
-        reload();
-    }
-}
-
-// the workgroup's 1 KB block of a layer: the four units of a quad gathered with DPP, ONE 16-byte store by the quad's first lane;
-// `local`: producer and consumers share an XCD (seen at run time) -> a plain write-back store that stays in its L2, else write-through
-__device__ __forceinline__ void publish4l(__amdgpu_buffer_rsrc_t rs, int soff, int tid, float v, bool on, bool local)
-{
-    const int iv = __builtin_bit_cast(int, v);
-    const int v0 = __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xF, 0xF, true);
-    const int v1 = __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xF, 0xF, true);
-    const int v2 = __builtin_amdgcn_update_dpp(0, iv, 0xAA, 0xF, 0xF, true);
-    const int v3 = __builtin_amdgcn_update_dpp(0, iv, 0xFF, 0xF, 0xF, true);
-    if (on && (tid & 3) == 0) {
-        const u32x4 q = {(unsigned)v0, (unsigned)v1, (unsigned)v2, (unsigned)v3};
-        if (local) __builtin_amdgcn_raw_buffer_store_b128(q, rs, (tid & ~3) * 4, soff, 0);
-        else __builtin_amdgcn_raw_buffer_store_b128(q, rs, (tid & ~3) * 4, soff, 16 /* sc1 */);
-    }
-}
-
-// row of the slab's per-segment aux tables for position p of a segment whose conditioning ends at lim: its frame (Stretch2d: constant
-// over a hop) relative to the segment's first frame of the slab (tbase = segment * rows per segment - that frame); the fold's zero pad
-// -> the zero row
-__device__ __forceinline__ int table_row(int p, int lim, int tbase, unsigned magic, int shift, int hop, int zrow)
-{
-    const int q = magic ? (int)(__umulhi((unsigned)p, magic) >> shift) : p / hop;
-    return p < lim ? tbase + q : zrow;
 }
 
 #define DPARTOF(q) (PART + (q) * (NW * 3 * 256))

@@ -319,4 +319,101 @@ __device__ __forceinline__ float gru_update_fast(float gi_r, float gi_z, float g
     return (h - n) * z + n;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Exchange-buffer geometry and wave-level helpers shared by the two-workgroups-per-CU kernels (wrnn_duo.hip: dense, 4 clusters x <= 8
+// slots; wrnn_sparse.hip: block-sparse GRUs, 16 clusters x 1 slot): a REGION of the buffer belongs to one (slot, cluster) pair of the
+// dense kernel / one cluster of the sparse kernel and holds DNX layers x DRING ring entries (by step) of XT floats each.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int DNX = 17;                      // layers: 0 h1  1 h2  2 y1  3 y2  4 cI  5 x1  6 x2  7 x_t  8-11 gh1  12-15 gh2 ([32 unit blocks][256 threads][r, z, n, tag])  16 RAW logits
+constexpr int DRING = 4;                     // ring entries per layer (by step)
+constexpr int DAHEAD_IH = 2;                 // re-arm distance (steps) of the sentinel layers (wrnn_duo.hip: those an ih workgroup publishes; header there)
+constexpr int DAHEAD_HH = 3;                 // ... of the layers an hh workgroup publishes
+constexpr int DGHRING = 2;                   // ring entries of the tagged gh words (no sentinel, no re-arm: two suffice)
+constexpr int DLAYER_ENTRIES = DRING;         // (a pad entry behind every layer ring was measured: no change in traffic or step time, profiles/r04j_traffic.log)
+constexpr size_t DXBUF_FLOATS = (size_t)LMAXG * MAXCL * DNX * DLAYER_ENTRIES * XT;      // [slot][cluster][layer][ring (+ pad)][XT]
+constexpr int XTB = XT * 4;                  // bytes of one layer entry (32 KB)
+constexpr int DLAYERB = DLAYER_ENTRIES * XTB; // bytes of one layer's ring
+constexpr int DSLOTB = DNX * DLAYERB;        // bytes of one region
+static_assert((size_t)LMAXG * MAXCL * DSLOTB < 0x7FFFFFFFull, "32-bit buffer offsets");
+
+// one fc3 tile with the A fragments already loaded (fragment order), B in registers; mfma_tile's order
+__device__ __forceinline__ f32x4 mfma1_frag(const float4 (&av)[8], const float (&b)[32])
+{
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].x, b[4 * r + 0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].x, b[4 * r + 4], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].y, b[4 * r + 1], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].y, b[4 * r + 5], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].z, b[4 * r + 2], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].z, b[4 * r + 6], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].w, b[4 * r + 3], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + 1].w, b[4 * r + 7], c1, 0, 0, 0);
+    }
+    return c0 + c1;
+}
+
+// the fragments of a wave as MFMA B operands
+__device__ __forceinline__ void frag_to_b(const u32x4 (&x)[8], float (&b)[32])
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        b[4 * r + 0] = __uint_as_float(x[r].x);
+        b[4 * r + 1] = __uint_as_float(x[r].y);
+        b[4 * r + 2] = __uint_as_float(x[r].z);
+        b[4 * r + 3] = __uint_as_float(x[r].w);
+    }
+}
+// no word of the live segments' fragments is still the sentinel (wave-uniform; one compare of the running unsigned maximum)
+__device__ __forceinline__ bool frag_there(const u32x4 (&x)[8], bool live)
+{
+    unsigned m = 0u;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) m = max(max(m, max(x[r].x, x[r].y)), max(x[r].z, x[r].w));
+    return __all(m != SENT || !live);
+}
+
+// A bounded wait that does not fail the launch's control flow: `there()` (wave-uniform) is re-evaluated after every `reload()`; when
+// the spin limit expires or another workgroup has raised the abort flag the wave marks itself dead -- it skips every later wait and
+// runs on with whatever the buffers hold (its barrier sequence is unchanged, nothing hangs, wrnn_status() reports the failure).
+template <class There, class Reload>
+__device__ __forceinline__ void wait_for(There there, Reload reload, unsigned *status, bool &dead, unsigned code, int step)
+{
+    unsigned spins = 0;
+    while (!dead && !there()) {
+        if ((++spins & 255u) == 0u) {
+            if (ld_agent32(status) != 0u) { dead = true; break; }
+            if (spins > SPIN_LIMIT) { report_failure(status, code, blockIdx.x, step, threadIdx.x); dead = true; break; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+        reload();
+    }
+}
+
+// the workgroup's 1 KB block of a layer: the four units of a quad gathered with DPP, ONE 16-byte store by the quad's first lane;
+// `local`: producer and consumers share an XCD (seen at run time) -> a plain write-back store that stays in its L2, else write-through
+__device__ __forceinline__ void publish4l(__amdgpu_buffer_rsrc_t rs, int soff, int tid, float v, bool on, bool local)
+{
+    const int iv = __builtin_bit_cast(int, v);
+    const int v0 = __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xF, 0xF, true);
+    const int v1 = __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xF, 0xF, true);
+    const int v2 = __builtin_amdgcn_update_dpp(0, iv, 0xAA, 0xF, 0xF, true);
+    const int v3 = __builtin_amdgcn_update_dpp(0, iv, 0xFF, 0xF, 0xF, true);
+    if (on && (tid & 3) == 0) {
+        const u32x4 q = {(unsigned)v0, (unsigned)v1, (unsigned)v2, (unsigned)v3};
+        if (local) __builtin_amdgcn_raw_buffer_store_b128(q, rs, (tid & ~3) * 4, soff, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(q, rs, (tid & ~3) * 4, soff, 16 /* sc1 */);
+    }
+}
+
+// row of the slab's per-segment aux tables for position p of a segment whose conditioning ends at lim: its frame (Stretch2d: constant
+// over a hop) relative to the segment's first frame of the slab (tbase = segment * rows per segment - that frame); the fold's zero pad
+// -> the zero row
+__device__ __forceinline__ int table_row(int p, int lim, int tbase, unsigned magic, int shift, int hop, int zrow)
+{
+    const int q = magic ? (int)(__umulhi((unsigned)p, magic) >> shift) : p / hop;
+    return p < lim ? tbase + q : zrow;
+}
+
 }  // namespace wrnn

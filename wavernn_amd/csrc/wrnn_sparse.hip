@@ -1,438 +1,557 @@
-// wrnn_sparse.hip -- pipelined clustered persistent WaveRNN loop kernel for BLOCK-SPARSE GRU weights (MOL), MI355X.
+// wrnn_sparse.hip -- persistent WaveRNN loop kernel for BLOCK-SPARSE GRU weights (MOL) on MI355X (gfx950 / CDNA4); round 5 rebuild.
 //
-// BASELINE config 5: the four GRU matrices pruned per gate to ~5 % density in 16x1 blocks (wavernn_amd/prune.py; the
-// reference's "Pruning - Scratchpad" rule applied to block magnitudes).  Same loop, exchange protocol and stage pipeline as
-// wrnn_pipe.hip (reference models/fatchord_version.py:201-241), but:
-//   * a workgroup owns 16 consecutive hidden units, so the 16 rows of one MFMA tile ARE one block row of a gate: the tile
-//     multiplies only the block row's surviving columns (~26 of 512, padded to NBP).  A fragments = the packed block
-//     values, B fragments = GATHERED activations act[segment][col[k]] (ds_read_b32 with per-lane column indices).  The GRU
-//     MFMA work drops from 128 to NBP/4 = 12-16 MFMAs per block row; fc1/fc2 stay dense (one 16-row tile each).
-//   * the whole weight set of a workgroup is ~160 registers, so a full copy of the model fits 32 workgroups: the chip runs
-//     EIGHT independent clusters, one per XCD (block b -> XCD b % 8), each with G = 2 groups of 16 segments in flight --
-//     256 segments per round -- and every all-gather stays inside one XCD's L2.
-//   * fc3: workgroup r < 30 of the cluster computes logit row r (VALU dot over the gathered y2), 5th tiny all-gather.
-// Skipping exact zeros does not change any partial sum; the summation ORDER differs from the dense kernels (surviving
-// columns in ascending order, split in four contiguous runs over the waves), so parity is to the MoL tolerance.
-#include "wrnn_tiles.h"
+// BASELINE config 5: the four GRU matrices pruned per gate to ~5 % density in 16x1 blocks (wavernn_amd/prune.py: the rule of the
+// reference's "Pruning - Scratchpad" notebook, JSON :40-186, applied to block magnitudes); the loop it runs is the reference's
+// models/fatchord_version.py:201-241.  With 95 % of the gate weights gone a step is no longer matrix work (2.7 us of f32 MFMA for 256
+// segments on the whole chip) but the LATENCY of its five dependent stages: x_{t-1} -> h1 -> h2 -> fc1 -> fc2 -> sample.  So the chip
+// runs SIXTEEN independent chains side by side instead of sixteen groups through four deep pipelines (wrnn_duo.hip):
+//
+//   * 16 clusters of 16 CUs (half an XCD: every exchanged layer stays inside one L2), ONE workgroup of 4 waves per CU (one wave per
+//     SIMD: 512 registers per lane -- every weight of the workgroup is register-resident, nothing spills), ONE group of <= 16 segments per
+//     cluster: the step IS the chain, no software pipeline, every stage is straight-line code in one instruction stream per wave.
+//   * a workgroup owns 64 hidden units of ONE GRU -- CUs 0-7 of a cluster: rnn1, CUs 8-15: rnn2 -- with BOTH halves of the cell: its rows
+//     of W_ih (on the chain) and of W_hh (gh(t+1) = W_hh . h(t) + b_hh, needed a step later: it stays in the wave's registers, no exchange).
+//     rnn1 workgroups also form the I-layer conditioning cI of their 64 rows (from the mel / the x25 signal and the frame's aux row, as
+//     wrnn_duo.hip) and multiply it through W_ih ahead of time: when x_{t-1} arrives only the x u1 term and the cell are left;
+//     rnn2's workgroup 0 runs fc3 + the mixture-of-logistics sampling (utils/distribution.py:87-123; both fc3 tiles in LDS).
+//     EVERY workgroup owns 32 rows of fc1 and 32 rows of fc2 (registers): the two dense layers are the duo kernel's fc stage (K split
+//     over the 4 waves, partial tiles through LDS, one barrier) spread over all 64 waves of the cluster.
+//   * gate stage, no K split: wave w of a workgroup owns the 16-row block 4 ub + w of all three gates over the whole COMPACTED K
+//     (NBP <= 48 / 64 surviving columns, the pack's sp_vals / sp_cols): NBP / 4 MFMAs per gate, A = the packed block values, B = the
+//     activations GATHERED from the fragment-order layer (element (k, n) of a layer sits at float (k >> 2) * 64 + 4 n + (k & 3)): one
+//     4-byte sc1 load per lane and MFMA, every word its own arrival flag (the sentinel).  The accumulators ARE the gate pre-activations
+//     of 4 consecutive units x 1 segment per lane: no partial tiles, no LDS, no barrier; the GRU cell runs in the accumulator registers
+//     and the lane's four new h / residual values are ONE 16-byte store straight into fragment order.
+//   * exchange: the duo kernel's buffer geometry and ring rules (wrnn_ring.h; wrnn_duo.hip "Ring discipline"): sentinel layers h1 h2 x1
+//     x2 y1 y2 with 4 ring entries, re-armed TWO steps ahead by the wave that publishes the words, after its last poll of the step (y1, in
+//     the fc2 stage) and drained at the top of its next step; cI without a sentinel inside a launch (formed one step ahead of its use,
+//     drained before the workgroup publishes anything of the next step; the first two steps of a launch are polled); x_t as tagged
+//     8-byte words {x, step + 1} in two entries (no re-arm at all).  The skew argument is simpler than the duo kernel's: every
+//     workgroup polls x2(t) and y1(t) of EVERY workgroup in every step, so nobody is ever more than one stage ahead of anybody.
+//     tests/test_sparse_exchange_model.py runs these rules as a discrete-event model under adversarial timing.
+//   * the conditioning is the duo kernel's: cI and (wrnn_options.mel_stage) the last up-sampling stage formed inside the loop, per-segment
+//     aux tables per slab of <= 1,651 steps, a launch per slab, 16 floats of state per (unit, segment) between launches: the workspace
+//     depends on neither T nor the corpus.
+// Skipping exact zeros changes no partial sum; the summation ORDER differs from the dense kernels (surviving columns ascending, four
+// at a time), so parity is to the MoL tolerance (tests/test_gpu_parity.py, tests/test_gpu_fullsize.py).
+#include <type_traits>
+
+#include "wrnn_ring.h"
 
 namespace wrnn {
 
-constexpr int SU = 16;                // hidden units per workgroup = one 16x1 block row per gate
-constexpr int SNWGC = H / SU;         // workgroups per cluster (32)
-constexpr int SGR = 3 * SU;           // GRU gate rows per workgroup (48 = 3 block rows)
-constexpr int SNSLOT = 6;             // partial-tile slots per wave: 0-2 input-to-hidden gates, 3-5 hidden-to-hidden gates
+constexpr int SPCLUSTERS = 16;               // clusters of 16 CUs per chip
+constexpr int SPWG = 16;                     // workgroups per cluster (one per CU)
+constexpr int SPLOGS = 36;                   // LDS row stride of the 30 logits of a segment
+constexpr int SPPART = 2 * NW * 2 * 256;     // two ping-pong sets of [wave][tile 0..1][lane][4]
+constexpr int SPSTATE_WG = NT * 16 + SEG;    // saved state of a workgroup: per thread {h[4], gh_r[4], gh_z[4], gh_n[4]}, then x_{t1-1} (rnn1)
+constexpr int SPSTATE_CL = SPWG * SPSTATE_WG; // ... of a cluster
+static_assert(SPCLUSTERS <= LMAXG * MAXCL, "one exchange-buffer region per cluster");
+static_assert(SPCLUSTERS * SPWG <= XCC_WORDS, "placement table");
 
-template <int G>
-struct SparseCfg {
-    static constexpr int TILE = SEG * LDC;
-    static constexpr int GRP = 2 * SGR * SEG + 2 * SU * SEG + 3 * SEG;   // GH1 GH2 HOWN1 HOWN2 XS POS LIM
-    static constexpr int OFF_HS = 0;
-    static constexpr int OFF_ACT = OFF_HS + TILE;
-    static constexpr int OFF_PART = OFF_ACT + G * TILE;                  // [NW][SNSLOT][16][16]
-    static constexpr int OFF_GRP = OFF_PART + NW * SNSLOT * 256;
-    static constexpr int OFF_LOG = OFF_GRP + G * GRP;
-    static constexpr int OFF_WI0 = OFF_LOG + SEG * 32;
-    static constexpr int OFF_W3R = OFF_WI0 + H;
-    static constexpr int OFF_SCR = OFF_W3R + H;
-    static constexpr int OFF_BI1 = OFF_SCR + 16 * SEG;
-    static constexpr int OFF_BH1 = OFF_BI1 + SGR;
-    static constexpr int OFF_BH2 = OFF_BH1 + SGR;
-    static constexpr int OFF_GEO = OFF_BH2 + SGR;
-    static constexpr int LDS_FLOATS = ((OFF_GEO + 2 * SPG + 3) / 4) * 4;
-    static_assert(G >= 1 && G <= SPG, "G in 1..SPG");
-    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
-    static_assert(OFF_PART % 4 == 0 && OFF_GRP % 4 == 0 && OFF_WI0 % 4 == 0 && GRP % 4 == 0, "alignment");
+struct SpLds {
+    int off_seg, off_part, off_log, off_misc, off_f3, total;
 };
+__host__ __device__ inline SpLds sp_lds()
+{
+    SpLds l;
+    int o = 0;
+    l.off_seg = o;  o += 64;                 // ints: 16 positions | 16 limits | 16 table-row bases of this slab | 16 mel offsets
+    l.off_part = o; o += SPPART;
+    l.off_log = o;  o += SEG * SPLOGS;
+    l.off_misc = o; o += 64;                 // placement table of the cluster (ints)
+    o = (o + 3) & ~3;
+    l.off_f3 = o;   o += 2 * XT;             // the sampling workgroup: fc3 (30 x 512 = two 16-row tiles) in A-fragment order
+    l.total = o;
+    return l;
+}
 
-// one block row: MPW dependent MFMAs of this wave's run of surviving blocks; B = act[segment fi][col]
+// The 16-row block of the three gates of one pruned matrix that a wave owns: MPW = NBP / 4 MFMAs per gate.  MFMA i of gate g contracts
+// the surviving blocks 4 i .. 4 i + 3 of the block row: lane (fi = lane & 15, kq = lane >> 4) holds the value of row fi in block 4 i + kq
+// (A operand) and gathers the activation of that block's COLUMN for segment fi (B operand) from byte offset off[g][i] of a layer entry.
 template <int MPW>
-__device__ __forceinline__ void sp_tiles3(const float (&A)[3][MPW], const int (&C)[3][MPW], const float *act_row,
-                                          f32x4 &o0, f32x4 &o1, f32x4 &o2)
+struct GateTiles {
+    float a[3][MPW];
+    int off[3][MPW];
+};
+template <int MPW>
+__device__ __forceinline__ void gate_tiles_init(GateTiles<MPW> &gt, const float *sp_vals, const int *sp_cols, int m, int rb, int lane)
 {
-    float b[3][MPW];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int i = 0; i < MPW; ++i) b[g][i] = act_row[C[g][i]];
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f}, c2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < MPW; ++i) {                                    // three independent chains interleaved
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[0][i], b[0][i], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[1][i], b[1][i], c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[2][i], b[2][i], c2, 0, 0, 0);
-    }
-    o0 = c0; o1 = c1; o2 = c2;
-}
-
-__device__ __forceinline__ int sp_frame(const float *GP, int j, int t, int hop, int NF)
-{
-    const int *SP = reinterpret_cast<const int *>(GP + 2 * SGR * SEG + 2 * SU * SEG + SEG);
-    const int p = SP[j] + t;
-    return (p < SP[SEG + j]) ? (p / hop) : NF;
-}
-
-// G: groups in flight per cluster.  NBP: padded surviving blocks per block row (48 or 64).
-template <int G, int NBP>
-__global__ __launch_bounds__(NT, 1) void wrnn_sparse_kernel(const LoopArgs a)
-{
-    using K = SparseCfg<G>;
-    constexpr int MPW = NBP / 16;                      // MFMAs per wave per block row
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *HS = smem + K::OFF_HS, *PART = smem + K::OFF_PART, *LOG = smem + K::OFF_LOG, *WI0 = smem + K::OFF_WI0;
-    float *W3R = smem + K::OFF_W3R, *SCR = smem + K::OFF_SCR;
-    float *BI1 = smem + K::OFF_BI1, *BH1 = smem + K::OFF_BH1, *BH2 = smem + K::OFF_BH2;
-    int *GEO = reinterpret_cast<int *>(smem + K::OFF_GEO);
-    float touch = 0.f;
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ncl = gridDim.x / SNWGC;
-    int cl, wg;
-    if (ncl == 8 && gridDim.x % 8 == 0) { cl = blockIdx.x % 8; wg = blockIdx.x / 8; }      // one cluster per XCD
-    else { cl = blockIdx.x / SNWGC; wg = blockIdx.x % SNWGC; }
     const int fi = lane & 15, kq = lane >> 4;
-    const int kbase_lane = KCH * w + 4 * kq;
-    const int Btot = a.Btot, T = a.T, C = a.C, NG = a.NG;
-    const int er = tid >> 4, ec = tid & 15;
-    const int pu = tid >> 4, pj = tid & 15;             // pointwise role: (owned unit pu, segment pj), all 256 threads
-    const int prow = SU * wg + pu;
-    const bool fc3_wg = wg < 30;                        // this workgroup owns logit row `wg`
-
-    // ---- one-time: packed block rows -> registers.  Matrix m, gate g, this wave's MFMA i covers blocks 4*(MPW*w+i)+kq.
-    float A_ih1[3][MPW], A_hh1[3][MPW], A_ih2[3][MPW], A_hh2[3][MPW], A_fc1[AF], A_fc2[AF];
-    int C_ih1[3][MPW], C_hh1[3][MPW], C_ih2[3][MPW], C_hh2[3][MPW];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int i = 0; i < MPW; ++i) {
-            const int blk = 4 * (MPW * w + i) + kq;
-            const size_t r0 = ((size_t)(0 * SNWGC + wg) * 3 + g) * NBP + blk, r1 = ((size_t)(1 * SNWGC + wg) * 3 + g) * NBP + blk;
-            const size_t r2 = ((size_t)(2 * SNWGC + wg) * 3 + g) * NBP + blk, r3 = ((size_t)(3 * SNWGC + wg) * 3 + g) * NBP + blk;
-            A_ih1[g][i] = a.sp_vals[r0 * 16 + fi]; C_ih1[g][i] = a.sp_cols[r0];
-            A_hh1[g][i] = a.sp_vals[r1 * 16 + fi]; C_hh1[g][i] = a.sp_cols[r1];
-            A_ih2[g][i] = a.sp_vals[r2 * 16 + fi]; C_ih2[g][i] = a.sp_cols[r2];
-            A_hh2[g][i] = a.sp_vals[r3 * 16 + fi]; C_hh2[g][i] = a.sp_cols[r3];
+            const size_t r = ((size_t)(m * 32 + rb) * 3 + g) * (4 * MPW) + 4 * i + kq;
+            gt.a[g][i] = sp_vals[r * 16 + fi];
+            const int c = sp_cols[r];                       // (padding blocks: column 0 with zero values)
+            gt.off[g][i] = (c >> 2) * 256 + (c & 3) * 4 + fi * 16;
         }
-    load_afrag(A_fc1, a.fc1_w, H + AUX, SU * wg + fi, true, kbase_lane);
-    load_afrag(A_fc2, a.fc2_w, H + AUX, SU * wg + fi, true, kbase_lane);
-    for (int q = tid; q < K::LDS_FLOATS; q += NT) smem[q] = 0.f;
-    __syncthreads();
-    WI0[2 * tid] = a.I_w0[2 * tid];
-    WI0[2 * tid + 1] = a.I_w0[2 * tid + 1];
-    if (fc3_wg) { W3R[2 * tid] = a.fc3_w[(size_t)wg * H + 2 * tid]; W3R[2 * tid + 1] = a.fc3_w[(size_t)wg * H + 2 * tid + 1]; }
-    const float b3 = fc3_wg ? a.fc3_b[wg] : 0.f;
-    if (tid < SGR) {
-        const int grow = (tid / SU) * H + SU * wg + (tid % SU);
-        BI1[tid] = a.b_ih1[grow];
-        BH1[tid] = a.b_hh1[grow];
-        BH2[tid] = a.b_hh2[grow];
+}
+template <int MPW>
+__device__ __forceinline__ void gather_issue(__amdgpu_buffer_rsrc_t rs, int soff, const GateTiles<MPW> &gt, unsigned (&v)[3][MPW])
+{
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < MPW; ++i) v[g][i] = __builtin_amdgcn_raw_buffer_load_b32(rs, gt.off[g][i], soff, 16 /* sc1 */);
+}
+// no gathered word of a live segment's lane is still the sentinel (wave-uniform)
+template <int MPW>
+__device__ __forceinline__ bool gather_there(const unsigned (&v)[3][MPW], unsigned extra, bool live)
+{
+    unsigned m = extra;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < MPW; ++i) m = max(m, v[g][i]);
+    return __all(m != SENT || !live);
+}
+template <int MPW>
+__device__ __forceinline__ void gate_mfma(const GateTiles<MPW> &gt, const unsigned (&v)[3][MPW], f32x4 &o0, f32x4 &o1, f32x4 &o2)
+{
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {                          // three independent chains interleaved (96 cycles between dependent MFMAs)
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gt.a[0][i], __uint_as_float(v[0][i]), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gt.a[1][i], __uint_as_float(v[1][i]), c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gt.a[2][i], __uint_as_float(v[2][i]), c2, 0, 0, 0);
     }
-
-    const __amdgpu_buffer_rsrc_t grs = make_rsrc(a.gran, GRAN_WORDS * 8);
-    constexpr int LAYER_BYTES = SEG * H * 8;
-    constexpr int SLOT_BYTES = NGRAN * LAYER_BYTES;
-    const int soff_cl = cl * SPG * SLOT_BYTES;
-
-    unsigned tagbase = 0u;
-    for (int round = 0;; ++round, tagbase += (unsigned)T) {
-        const int gfirst = cl + ncl * (round * G);
-        if (gfirst >= NG) break;
-        int nact = 0;
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-            if (gfirst + ncl * i < NG) nact = i + 1;
-        __syncthreads();
-        if (tid < G) {
-            const int g = gfirst + ncl * tid;
-            int b0 = 0, nb = 0;
-            if (g < NG) {
-                b0 = (int)(((long)g * Btot) / NG);
-                nb = (int)(((long)(g + 1) * Btot) / NG) - b0;
-            }
-            GEO[2 * tid] = b0;
-            GEO[2 * tid + 1] = nb;
-        }
-        __syncthreads();
-        // ---- state init (fatchord_version.py:194-196): h = 0, x = 0, gh = b_hh ------------------------------------
-#pragma unroll 1
-        for (int i = 0; i < nact; ++i) {
-            float *GP = smem + K::OFF_GRP + i * K::GRP;
-            float *ACT = smem + K::OFF_ACT + i * K::TILE;
-            const int b0 = GEO[2 * i], nb = GEO[2 * i + 1];
-            for (int q = tid; q < SGR * SEG; q += NT) { GP[q] = BH1[q >> 4]; GP[SGR * SEG + q] = BH2[q >> 4]; }
-            for (int q = tid; q < 2 * SU * SEG; q += NT) GP[2 * SGR * SEG + q] = 0.f;           // HOWN1 + HOWN2
-            if (tid < SEG) {
-                GP[2 * SGR * SEG + 2 * SU * SEG + tid] = 0.f;                                    // XS
-                int *SP = reinterpret_cast<int *>(GP + 2 * SGR * SEG + 2 * SU * SEG + SEG);
-                const int sc = b0 + (tid < nb ? tid : nb - 1);
-                SP[tid] = a.seg_pos[sc];
-                SP[SEG + tid] = a.seg_lim[sc];
-            }
-            {
-                const int erc = er < nb ? er : nb - 1;
-                const float *crow = a.cI + ((size_t)0 * Btot + b0 + erc) * H + 2 * ec;
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    *reinterpret_cast<float2 *>(ACT + er * LDC + own_col(c, ec)) = *reinterpret_cast<const float2 *>(crow + 32 * c);
-                asm volatile("" ::"v"(touch));
-                const int line = (tid < 16 * nb) ? tid : 0;
-                touch = a.cI[((size_t)(T > 1 ? 1 : 0) * Btot + b0) * H + 32 * line];
-            }
-        }
-        __syncthreads();
-
-        for (int t = 0; t < T; ++t) {
-            const unsigned tag = tagbase + (unsigned)t + 1u;
-
-            // =========================== S1: GRU1 (fatchord_version.py:210) ===========================
-#pragma unroll 1
-            for (int i = 0; i < nact; ++i) {
-                const int nb = GEO[2 * i + 1];
-                float *GP = smem + K::OFF_GRP + i * K::GRP;
-                float *ACT = smem + K::OFF_ACT + i * K::TILE;
-                float *GH1 = GP, *HOWN1 = GP + 2 * SGR * SEG;
-                u64 *G1 = a.gran + (size_t)(cl * SPG + i) * NGRAN * SEG * H + 0 * SEG * H;
-                __syncthreads();
-                {
-                    f32x4 o0, o1, o2;
-                    sp_tiles3<MPW>(A_ih1, C_ih1, ACT + fi * LDC, o0, o1, o2);
-                    put_partial_rm<SNSLOT>(PART, w, 0, lane, o0);
-                    put_partial_rm<SNSLOT>(PART, w, 1, lane, o1);
-                    put_partial_rm<SNSLOT>(PART, w, 2, lane, o2);
-                }
-                __syncthreads();
-                if (pj < nb) {
-                    const float gir = get_partial_rm<SNSLOT>(PART, 0, 0 * SU + pu, pj) + BI1[0 * SU + pu];
-                    const float giz = get_partial_rm<SNSLOT>(PART, 0, 1 * SU + pu, pj) + BI1[1 * SU + pu];
-                    const float gin = get_partial_rm<SNSLOT>(PART, 0, 2 * SU + pu, pj) + BI1[2 * SU + pu];
-                    const float hn = gru_update(gir, giz, gin, GH1[(0 * SU + pu) * SEG + pj], GH1[(1 * SU + pu) * SEG + pj],
-                                                GH1[(2 * SU + pu) * SEG + pj], HOWN1[pu * SEG + pj]);
-                    HOWN1[pu * SEG + pj] = hn;
-                    publish(G1, tag, pj, prow, hn);
-                }
-            }
-
-            // =========================== S2: GRU2 (:212-214) ==========================================
-#pragma unroll 1
-            for (int i = 0; i < nact; ++i) {
-                const int nb = GEO[2 * i + 1];
-                float *GP = smem + K::OFF_GRP + i * K::GRP;
-                float *ACT = smem + K::OFF_ACT + i * K::TILE;
-                float *GH1 = GP, *GH2 = GP + SGR * SEG, *HOWN2 = GP + 2 * SGR * SEG + SU * SEG;
-                u64 *G2 = a.gran + (size_t)(cl * SPG + i) * NGRAN * SEG * H + 1 * SEG * H;
-                const int f2 = sp_frame(GP, pj, t, a.hop, a.NF);
-                const float c2r = a.c2f[(size_t)f2 * 3 * H + prow];
-                const float c2z = a.c2f[(size_t)f2 * 3 * H + H + prow];
-                const float c2n = a.c2f[(size_t)f2 * 3 * H + 2 * H + prow];
-                bool ok = sweep_layer<true, 16>(grs, soff_cl + i * SLOT_BYTES + 0 * LAYER_BYTES, tag, nb, tid, HS, ACT, a.status);   // h1 -> HS; ACT = xi + h1
-                if (!ok) report_failure(a.status, 0x400u | 1u, blockIdx.x, t, tid);
-                if (__syncthreads_or(!ok)) return;
-                {
-                    f32x4 o0, o1, o2;
-                    sp_tiles3<MPW>(A_ih2, C_ih2, ACT + fi * LDC, o0, o1, o2);
-                    put_partial_rm<SNSLOT>(PART, w, 0, lane, o0);
-                    put_partial_rm<SNSLOT>(PART, w, 1, lane, o1);
-                    put_partial_rm<SNSLOT>(PART, w, 2, lane, o2);
-                    sp_tiles3<MPW>(A_hh1, C_hh1, HS + fi * LDC, o0, o1, o2);           // gh1(t+1) = W_hh1 . h1(t)
-                    put_partial_rm<SNSLOT>(PART, w, 3, lane, o0);
-                    put_partial_rm<SNSLOT>(PART, w, 4, lane, o1);
-                    put_partial_rm<SNSLOT>(PART, w, 5, lane, o2);
-                }
-                __syncthreads();
-                if (pj < nb) {
-                    const float gir = get_partial_rm<SNSLOT>(PART, 0, 0 * SU + pu, pj) + c2r;
-                    const float giz = get_partial_rm<SNSLOT>(PART, 0, 1 * SU + pu, pj) + c2z;
-                    const float gin = get_partial_rm<SNSLOT>(PART, 0, 2 * SU + pu, pj) + c2n;
-                    const float hn = gru_update(gir, giz, gin, GH2[(0 * SU + pu) * SEG + pj], GH2[(1 * SU + pu) * SEG + pj],
-                                                GH2[(2 * SU + pu) * SEG + pj], HOWN2[pu * SEG + pj]);
-                    HOWN2[pu * SEG + pj] = hn;
-                    publish(G2, tag, pj, prow, hn);
-                }
-#pragma unroll
-                for (int q0 = 0; q0 < (SGR * SEG) / NT; ++q0) {
-                    const int q = tid + NT * q0;
-                    GH1[q] = get_partial_rm<SNSLOT>(PART, 3, q >> 4, q & 15) + BH1[q >> 4];
-                }
-            }
-
-            // =========================== S3: fc1 + relu (:216-218) ====================================
-#pragma unroll 1
-            for (int i = 0; i < nact; ++i) {
-                const int nb = GEO[2 * i + 1];
-                float *GP = smem + K::OFF_GRP + i * K::GRP;
-                float *ACT = smem + K::OFF_ACT + i * K::TILE;
-                float *GH2 = GP + SGR * SEG;
-                u64 *G3 = a.gran + (size_t)(cl * SPG + i) * NGRAN * SEG * H + 2 * SEG * H;
-                const float c3v = a.c3f[(size_t)sp_frame(GP, pj, t, a.hop, a.NF) * H + prow];
-                bool ok = sweep_layer<true, 16>(grs, soff_cl + i * SLOT_BYTES + 1 * LAYER_BYTES, tag, nb, tid, HS, ACT, a.status);   // h2 -> HS; ACT = x1 + h2
-                if (!ok) report_failure(a.status, 0x400u | 2u, blockIdx.x, t, tid);
-                if (__syncthreads_or(!ok)) return;
-                put_partial_rm<SNSLOT>(PART, w, 0, lane, mfma_tile_pre(A_fc1, ACT + fi * LDC + kbase_lane));
-                {
-                    f32x4 o0, o1, o2;
-                    sp_tiles3<MPW>(A_hh2, C_hh2, HS + fi * LDC, o0, o1, o2);           // gh2(t+1) = W_hh2 . h2(t)
-                    put_partial_rm<SNSLOT>(PART, w, 3, lane, o0);
-                    put_partial_rm<SNSLOT>(PART, w, 4, lane, o1);
-                    put_partial_rm<SNSLOT>(PART, w, 5, lane, o2);
-                }
-                __syncthreads();
-                if (pj < nb) publish(G3, tag, pj, prow, fmaxf(get_partial_rm<SNSLOT>(PART, 0, pu, pj) + c3v, 0.f));
-#pragma unroll
-                for (int q0 = 0; q0 < (SGR * SEG) / NT; ++q0) {
-                    const int q = tid + NT * q0;
-                    GH2[q] = get_partial_rm<SNSLOT>(PART, 3, q >> 4, q & 15) + BH2[q >> 4];
-                }
-            }
-
-            // =========================== S4: fc2 + relu (:220-221) ====================================
-#pragma unroll 1
-            for (int i = 0; i < nact; ++i) {
-                const int nb = GEO[2 * i + 1];
-                float *GP = smem + K::OFF_GRP + i * K::GRP;
-                float *ACT = smem + K::OFF_ACT + i * K::TILE;
-                u64 *G4 = a.gran + (size_t)(cl * SPG + i) * NGRAN * SEG * H + 3 * SEG * H;
-                const float c4v = a.c4f[(size_t)sp_frame(GP, pj, t, a.hop, a.NF) * H + prow];
-                bool ok = sweep_layer<false, 16>(grs, soff_cl + i * SLOT_BYTES + 2 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y1
-                if (!ok) report_failure(a.status, 0x400u | 3u, blockIdx.x, t, tid);
-                if (__syncthreads_or(!ok)) return;
-                put_partial_rm<SNSLOT>(PART, w, 0, lane, mfma_tile_pre(A_fc2, ACT + fi * LDC + kbase_lane));
-                __syncthreads();
-                if (pj < nb) publish(G4, tag, pj, prow, fmaxf(get_partial_rm<SNSLOT>(PART, 0, pu, pj) + c4v, 0.f));
-            }
-
-            // =========================== S5: fc3, one logit row per workgroup (:223) ==================
-            if (fc3_wg) {
-#pragma unroll 1
-                for (int i = 0; i < nact; ++i) {
-                    const int nb = GEO[2 * i + 1];
-                    float *ACT = smem + K::OFF_ACT + i * K::TILE;
-                    u64 *G5 = a.gran + (size_t)(cl * SPG + i) * NGRAN * SEG * H + 4 * SEG * H;
-                    bool ok = sweep_layer<false, 16>(grs, soff_cl + i * SLOT_BYTES + 3 * LAYER_BYTES, tag, nb, tid, ACT, nullptr, a.status);   // ACT <- y2
-                    if (!ok) report_failure(a.status, 0x400u | 4u, blockIdx.x, t, tid);
-                    if (__syncthreads_or(!ok)) return;
-                    {   // thread (segment pj, k-chunk pu): 32 terms of logit[wg][pj]
-                        const float *xr = ACT + pj * LDC + 32 * pu;
-                        const float *wr = W3R + 32 * pu;
-                        float s = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 32; k += 4) {
-                            const float4 x4 = *reinterpret_cast<const float4 *>(xr + k);
-                            const float4 w4 = *reinterpret_cast<const float4 *>(wr + k);
-                            s = fmaf(w4.x, x4.x, s); s = fmaf(w4.y, x4.y, s); s = fmaf(w4.z, x4.z, s); s = fmaf(w4.w, x4.w, s);
-                        }
-                        SCR[pu * SEG + pj] = s;
-                    }
-                    __syncthreads();
-                    if (tid < nb) {
-                        float s = SCR[tid];
-#pragma unroll
-                        for (int kc = 1; kc < 16; ++kc) s += SCR[kc * SEG + tid];
-                        publish(G5, tag, tid, wg, s + b3);
-                    }
-                }
-            }
-
-            // =========================== S6: sampling (utils/distribution.py:102-121) + xi(t+1) ========
-#pragma unroll 1
-            for (int i = 0; i < nact; ++i) {
-                float *GP = smem + K::OFF_GRP + i * K::GRP;
-                float *ACT = smem + K::OFF_ACT + i * K::TILE;
-                float *XS = GP + 2 * SGR * SEG + 2 * SU * SEG;
-                const int nb = GEO[2 * i + 1], b0 = GEO[2 * i];
-                const float *nrow = a.noise_pre + (size_t)t * 11 * Btot;       // log(-log u1) / log u2 - log(1-u2)
-                const int puc = pu < nb ? pu : nb - 1;
-                const float nz0 = nrow[(b0 + puc) * 10 + (pj < 10 ? pj : 9)];
-                const float nz1 = nrow[10 * Btot + b0 + puc];
-                {   // gather the 30 logits of every segment: thread (segment er, c = ec < 15) reads logits 2c, 2c+1
-                    bool ok = true;
-                    if (er < nb && ec < 15) {
-                        const int voff = er * (H * 8) + ec * 16;
-                        const int soff = soff_cl + i * SLOT_BYTES + 4 * LAYER_BYTES;
-                        unsigned spins = 0;
-                        u32x4 x;
-                        for (;;) {
-                            x = __builtin_amdgcn_raw_buffer_load_b128(grs, voff, soff, 16 /* sc1 */);
-                            if (x.y == tag && x.w == tag) break;
-                            ++spins;
-                            if ((spins & 255u) == 0u) {
-                                if (spins > SPIN_LIMIT || ld_agent32(a.status) != 0u) { ok = false; break; }
-                            }
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                        const float l0 = __uint_as_float(x.x), l1 = __uint_as_float(x.z);
-                        LOG[er * 32 + 2 * ec] = l0;
-                        LOG[er * 32 + 2 * ec + 1] = l1;
-                        if (a.dbg_logits && wg == 0 && ok) {
-                            a.dbg_logits[((size_t)t * Btot + b0 + er) * C + 2 * ec] = l0;
-                            a.dbg_logits[((size_t)t * Btot + b0 + er) * C + 2 * ec + 1] = l1;
-                        }
-                    }
-                    if (!ok) report_failure(a.status, 0x400u | 5u, blockIdx.x, t, tid);
-                    if (__syncthreads_or(!ok)) return;
-                }
-                float2 cn[16];
-                {   // cI(t+1) after the last poll of the group's step (vector loads return in order); rows touched a step ago
-                    const int tn = (t + 1 < T) ? t + 1 : t;
-                    const int erc = er < nb ? er : nb - 1;
-                    const float *crow = a.cI + ((size_t)tn * Btot + b0 + erc) * H + 2 * ec;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) cn[c] = *reinterpret_cast<const float2 *>(crow + 32 * c);
-                    asm volatile("" ::"v"(touch));
-                    const int tt = (t + 2 < T) ? t + 2 : T - 1;
-                    const int line = (tid < 16 * nb) ? tid : 0;
-                    touch = a.cI[((size_t)tt * Btot + b0) * H + 32 * line];
-                }
-                {   // 16-lane group = one segment (pu), lane pj = mixture
-                    float best = (pj < 10) ? mol_gumbel_pre(LOG[pu * 32 + pj], nz0) : -INFINITY;
-                    int bidx = pj;
-                    argmax_row16(best, bidx);
-                    if (pj == 0 && pu < nb) {
-                        float x = mol_sample_pre(LOG[pu * 32 + 10 + bidx], LOG[pu * 32 + 20 + bidx], nz1);
-                        if (wg == 0) a.out[(size_t)(b0 + pu) * T + t] = x;
-                        if (a.force_x) x = a.force_x[(size_t)(b0 + pu) * T + t];
-                        XS[pu] = x;
-                    }
-                }
-                __syncthreads();
-                {   // xi(t+1) = W_I[:,0] * x_t + cI(t+1)  (:208-209)
-                    const float xs = XS[er];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        const float2 wv = *reinterpret_cast<const float2 *>(WI0 + own_col(c, ec));
-                        *reinterpret_cast<float2 *>(ACT + er * LDC + own_col(c, ec)) = make_float2(fmaf(wv.x, xs, cn[c].x), fmaf(wv.y, xs, cn[c].y));
-                    }
-                }
-            }
-        }
-    }
-    asm volatile("" ::"v"(touch));
+    o0 = c0; o1 = c1; o2 = c2;
 }
 
-template <int G, int NBP>
-static hipError_t launch_sparse_t(const LoopArgs &args, int ncl, hipStream_t stream)
+__device__ __forceinline__ unsigned max4(const u32x4 &q) { return max(max(q.x, q.y), max(q.z, q.w)); }
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// two fc row tiles that share the activation operand (B fragments in registers); per tile mfma1's order (two chains by k-block parity)
+__device__ __forceinline__ void mfma2(const float (&a0)[AF], const float (&a1)[AF], const float (&b)[32], f32x4 &o0, f32x4 &o1)
 {
-    using K = SparseCfg<G>;
-    const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
-    hipError_t e = hipFuncSetAttribute((const void *)wrnn_sparse_kernel<G, NBP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + e], b[4 * r + e], c00, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + e], b[4 * r + e], c10, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + 4 + e], b[4 * r + 4 + e], c01, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + 4 + e], b[4 * r + 4 + e], c11, 0, 0, 0);
+        }
+    }
+    o0 = c00 + c01;
+    o1 = c10 + c11;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// One workgroup of a cluster: 64 units (unit block ub) of rnn1 (LA) or rnn2.  rg = the cluster's region of the exchange buffer, gid =
+// its group of the round, wgi = index in the cluster (fc rows [32 wgi, 32 wgi + 32) of fc1 and of fc2).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int NBP, bool LA>
+__device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const int rg, const int gid, const int ub, const int wgi, const bool loc)
+{
+    constexpr int MPW = NBP / 4;
+    const SpLds L = sp_lds();
+    float *PART = smem + L.off_part, *LOG = smem + L.off_log, *F3 = smem + L.off_f3;
+    int *SEGT = reinterpret_cast<int *>(smem + L.off_seg);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, kq = lane >> 4;           // MFMA coordinates: A row / B segment, k-quad; D: rows 4 kq + e, segment fi
+    const int rb = 4 * ub + w;                          // this wave's 16-unit block of the layer (gate stages)
+    const int u0 = LU * rb + 4 * kq;                    // ... this lane's four units u0 .. u0 + 3 (of segment fi)
+    const int kbase_lane = KCH * w + 4 * kq;            // fc stages: K split over the waves
+    const int pu = 4 * w + (tid & 3), pj = (tid >> 2) & 15;      // fc pointwise role: rows 32 wgi + pu and 32 wgi + 16 + pu, segment pj
+    const int T0 = a.t0, T1 = a.t1;
+    // (everything the stage lambdas need of the launch arguments as local values: see wrnn_duo.hip)
+    unsigned *const status = a.status;
+    const int hop = a.hop, resume = a.resume, Tall = a.T, Nall = a.Nall, noise_t0 = a.noise_t0, C = a.C;
+    const unsigned magic = a.hop_magic;
+    const int mshift = a.hop_shift;
+    const int zrow = a.Nall * a.tab_fps;
+    float *const outp = a.out, *const dbgl = a.dbg_logits;
+    const float *const forcex = a.force_x, *const noise_pre = a.noise_pre;
+    const float *const mels_up = a.mels_up, *const aux_fr = a.aux_fr, *const mel_coef = a.mel_coef;
+    const int mel_stage = a.mel_stage;
+    const int NR = a.Btot, NGR = a.NG;
+    const int b0 = (int)(((long)gid * NR) / NGR), nb = (int)(((long)(gid + 1) * NR) / NGR) - b0;
+    const int b0g = a.rb0 + b0;                         // first segment of the group in the call
+    constexpr int L_H = LA ? 0 : 1, L_XR = LA ? 5 : 6, L_IN = LA ? 4 : 5;
+    float *const state_wg = a.state + (size_t)gid * SPSTATE_CL + (size_t)wgi * SPSTATE_WG;
+    const bool sampler = !LA && ub == 0;
+
+    // ---- weights: the wave's gate tiles of W_ih and W_hh, the workgroup's two fc1 and two fc2 tiles
+    GateTiles<MPW> gi, gh;
+    gate_tiles_init(gi, a.sp_vals, a.sp_cols, LA ? 0 : 2, rb, lane);
+    gate_tiles_init(gh, a.sp_vals, a.sp_cols, LA ? 1 : 3, rb, lane);
+    float A_fc1[2][AF], A_fc2[2][AF];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        load_afrag(A_fc1[q], a.fc1_w, H + AUX, 2 * LU * wgi + LU * q + fi, true, kbase_lane);
+        load_afrag(A_fc2[q], a.fc2_w, H + AUX, 2 * LU * wgi + LU * q + fi, true, kbase_lane);
+    }
+    for (int q = tid; q < L.off_f3; q += NT) smem[q] = 0.f;
+    if (sampler) {                                      // fc3 -> LDS (fragment order as in the pack)
+        for (int q = tid; q < 2 * XT / 4; q += NT) reinterpret_cast<float4 *>(F3)[q] = reinterpret_cast<const float4 *>(a.fc3f)[q];
+    }
+    // constants of the gate pointwise role (units u0 + e): rnn1: b_ih1, u1 = W_ih1 . w0 (the x_{t-1} term), w0 (rnn2's b_ih2 is inside c2f); b_hh
+    float cb[3][4], ux[3][4], w0o[4], bh[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cb[g][e] = LA ? a.b_ih1[g * H + u0 + e] : 0.f;
+            ux[g][e] = LA ? a.u1[g * H + u0 + e] : 0.f;
+            bh[g][e] = (LA ? a.b_hh1 : a.b_hh2)[g * H + u0 + e];
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w0o[e] = LA ? a.I_w0[u0 + e] : 0.f;
+    const float b3a = sampler ? a.fc3_b[pu] : 0.f, b3b = (sampler && 16 + pu < 30) ? a.fc3_b[16 + pu] : 0.f;
+    CondTile ct;
+    if constexpr (LA) cond_tile_init(ct, a.I_cT, a.I_b, rb, lane);
+    __syncthreads();
+    if (tid < SEG) {
+        const int sc = b0g + (tid < nb ? tid : nb - 1);
+        const int pos = a.seg_pos[sc];
+        SEGT[tid] = pos;
+        SEGT[SEG + tid] = a.seg_lim[sc];
+        SEGT[2 * SEG + tid] = sc * a.tab_fps - (pos + a.tab_t0) / a.hop;
+        SEGT[3 * SEG + tid] = a.mel_stage ? a.seg_moff[sc] : 0;
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.xbuf, (unsigned)(DXBUF_FLOATS * 4));
+    const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.c2f, 0x7FFFF000u);          // rnn2: per-frame table of its aux columns + b_ih2
+    const __amdgpu_buffer_rsrc_t f1rs = make_rsrc(a.c3f, 0x7FFFF000u), f2rs = make_rsrc(a.c4f, 0x7FFFF000u);
+    const int cbase = rg * DSLOTB;
+    const int voff_frag = frag_off(w, 0, lane) * 4;      // fc stages: this lane's first fragment of a layer (bytes)
+    const int voff_blk = rb * 1024 + lane * 16;          // gate stages: this lane's 16-byte word {units u0 .. u0 + 3, segment fi} of a layer
+    const bool live = fi < nb;                           // this lane's segment exists (gate stages, fragment polls)
+
+    bool dead = false;
+    int pp = 0;
+    int t = T0;
+    float h[4] = {0.f, 0.f, 0.f, 0.f};                   // the GRU state of the lane's four units (fatchord_version.py:194-195: zeros)
+    float ghr[4], ghz[4], ghn[4];                        // gh(t) = W_hh . h(t - 1) + b_hh of those units: formed during step t - 1, kept here
+    f32x4 gacc[3];                                       // rnn1: W_ih1 . cI(t), formed at the end of step t - 1
+    u32x4 own = {0u, 0u, 0u, 0u};                        // the lane's own words of the gates' input layer (cI / x1) = the residual input
+    gacc[0] = gacc[1] = gacc[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (resume) {
+        const float4 hv = *reinterpret_cast<const float4 *>(state_wg + tid * 16), r4 = *reinterpret_cast<const float4 *>(state_wg + tid * 16 + 4),
+                     z4 = *reinterpret_cast<const float4 *>(state_wg + tid * 16 + 8), n4 = *reinterpret_cast<const float4 *>(state_wg + tid * 16 + 12);
+        h[0] = hv.x; h[1] = hv.y; h[2] = hv.z; h[3] = hv.w;
+        ghr[0] = r4.x; ghr[1] = r4.y; ghr[2] = r4.z; ghr[3] = r4.w; ghz[0] = z4.x; ghz[1] = z4.y; ghz[2] = z4.z; ghz[3] = z4.w;
+        ghn[0] = n4.x; ghn[1] = n4.y; ghn[2] = n4.z; ghn[3] = n4.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ghr[e] = bh[0][e]; ghz[e] = bh[1][e]; ghn[e] = bh[2][e]; }      // W_hh . 0 + b_hh
+    }
+
+    auto store16 = [&](const u32x4 &q, int voff, int soff) {
+        if (loc) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, voff, soff, 0);       // the whole cluster was seen on one XCD: a plain store stays in its L2
+        else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, voff, soff, 16 /* sc1 */);
+    };
+    // ring hygiene (header): after the last poll of step t this wave resets its OWN words of entry (t + 2) % 4 in the sentinel layers it
+    // publishes: its quarters of the workgroup's two y1 and two y2 blocks (one 16-lane group each), its block of h and of the residual sum
+    auto rearm = [&]() {
+        const int so = cbase + ((t + DAHEAD_IH) & (DRING - 1)) * XTB;
+        const u32x4 q = {SENT, SENT, SENT, SENT};
+        store16(q, (kq < 2 ? 2 : 3) * DLAYERB + (2 * wgi + (kq & 1)) * 1024 + w * 256 + fi * 16, so);
+        store16(q, L_H * DLAYERB + voff_blk, so);
+        store16(q, L_XR * DLAYERB + voff_blk, so);
+    };
+
+    // ---------------- fc stage: relu(fc1([x2, a3])) -> y1 (which = 1) / relu(fc2([y1, a4])) -> y2 (which = 2), the workgroup's 32 rows
+    auto fc = [&](auto WC) {
+        constexpr int which = decltype(WC)::value;
+        constexpr int LI = which == 1 ? 6 : 2, LO = which == 1 ? 2 : 3;
+        const int sb = cbase + (t & (DRING - 1)) * XTB;
+        u32x4 x[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + LI * DLAYERB, 16 /* sc1 */);
+        const int fr = table_row(SEGT[pj] + t, SEGT[SEG + pj], SEGT[2 * SEG + pj], magic, mshift, hop, zrow);
+        const int vo = (fr * H + 2 * LU * wgi + pu) * 4;
+        const float cv0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(which == 1 ? f1rs : f2rs, vo, 0, 0));
+        const float cv1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(which == 1 ? f1rs : f2rs, vo, LU * 4, 0));
+        if (__builtin_expect(!frag_there(x, live), 0))
+            wait_for([&] { return frag_there(x, live); },
+                     [&] {
+#pragma unroll
+                         for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + LI * DLAYERB, 16 /* sc1 */);
+                     },
+                     status, dead, 0x700u | (unsigned)which, t);
+        if constexpr (which == 2) rearm();
+        float b[32];
+        frag_to_b(x, b);
+        float *PW = PART + pp * (NW * 2 * 256);
+        f32x4 o0, o1;
+        if constexpr (which == 1) mfma2(A_fc1[0], A_fc1[1], b, o0, o1);
+        else mfma2(A_fc2[0], A_fc2[1], b, o0, o1);
+        put_partial<2>(PW, w, 0, lane, o0);
+        put_partial<2>(PW, w, 1, lane, o1);
+        lds_barrier();
+        publish4l(xrs, sb + LO * DLAYERB + (2 * wgi) * 1024, tid, fmaxf(get_partial<2>(PW, 0, pu, pj) + cv0, 0.f), pj < nb, loc);
+        publish4l(xrs, sb + LO * DLAYERB + (2 * wgi + 1) * 1024, tid, fmaxf(get_partial<2>(PW, 1, pu, pj) + cv1, 0.f), pj < nb, loc);
+        pp ^= 1;
+    };
+
+    // ---------------- gate stages ----------------
+    // the GRU cell of the lane's four units (ATen gru_cell; hardware exp / rcp as the duo kernel's MoL path) and the publication of
+    // the residual sum (on the chain: first) and of h
+    auto cell_publish = [&](const float (&gir)[4], const float (&giz)[4], const float (&gin)[4], const float (&xin)[4]) {
+        u32x4 qx, qh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = gru_update_fast(gir[e], giz[e], gin[e], ghr[e], ghz[e], ghn[e], h[e]);
+            qx[e] = __float_as_uint(xin[e] + h[e]);       // x1 = xi + h1 (:212) / x2 = x1 + h2 (:216)
+            qh[e] = __float_as_uint(h[e]);
+        }
+        if (live) {
+            const int sb = cbase + (t & (DRING - 1)) * XTB;
+            store16(qx, L_XR * DLAYERB + voff_blk, sb);
+            store16(qh, L_H * DLAYERB + voff_blk, sb);
+        }
+    };
+
+    // rnn1, front half: W_ih1 . cI(ts) of the wave's rows + the lane's own cI words (the residual input xi - w0 x), as soon as cI(ts) is there
+    auto front_a = [&](int ts) {
+        const int so = cbase + L_IN * DLAYERB + (ts & (DRING - 1)) * XTB;
+        unsigned v[3][MPW];
+        gather_issue(xrs, so, gi, v);
+        own = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_blk, so, 16 /* sc1 */);
+        if (__builtin_expect(!gather_there(v, max4(own), live), 0))
+            wait_for([&] { return gather_there(v, max4(own), live); },
+                     [&] { gather_issue(xrs, so, gi, v); own = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_blk, so, 16 /* sc1 */); },
+                     status, dead, 0x720u, ts);
+        gate_mfma(gi, v, gacc[0], gacc[1], gacc[2]);
+    };
+    // rnn1, back half (the chain: sampling -> here): x_{t-1} arrives as a tagged word {x, tag = t}
+    auto back_a = [&]() {
+        float xv = 0.f;
+        if (t > T0) {
+            const int sx = cbase + 7 * DLAYERB + ((t - 1) & 1) * XTB;
+            u32x2 xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, fi * 8, sx, 16 /* sc1 */);
+            if (__builtin_expect(__any(live && xq.y != (unsigned)t), 0))
+                wait_for([&] { return !__any(live && xq.y != (unsigned)t); }, [&] { xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, fi * 8, sx, 16 /* sc1 */); },
+                         status, dead, 0x730u, t);
+            xv = __uint_as_float(xq.x);
+        } else if (resume) xv = state_wg[NT * 16 + fi];
+        float gir[4], giz[4], gin[4], xin[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gir[e] = gacc[0][e] + fmaf(xv, ux[0][e], cb[0][e]);
+            giz[e] = gacc[1][e] + fmaf(xv, ux[1][e], cb[1][e]);
+            gin[e] = gacc[2][e] + fmaf(xv, ux[2][e], cb[2][e]);
+            xin[e] = fmaf(w0o[e], xv, __uint_as_float(own[e]));      // xi of the lane's units (:208-209)
+        }
+        cell_publish(gir, giz, gin, xin);
+    };
+    // rnn2: the whole gate stage is on the chain (x1 -> here)
+    auto gates_b = [&]() {
+        const int so = cbase + L_IN * DLAYERB + (t & (DRING - 1)) * XTB;
+        unsigned v[3][MPW];
+        gather_issue(xrs, so, gi, v);
+        own = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_blk, so, 16 /* sc1 */);
+        const int fr = table_row(SEGT[fi] + t, SEGT[SEG + fi], SEGT[2 * SEG + fi], magic, mshift, hop, zrow);
+        u32x4 c2[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) c2[q] = __builtin_amdgcn_raw_buffer_load_b128(crs, (fr * 3 * H + q * H + u0) * 4, 0, 0);
+        if (__builtin_expect(!gather_there(v, max4(own), live), 0))
+            wait_for([&] { return gather_there(v, max4(own), live); },
+                     [&] { gather_issue(xrs, so, gi, v); own = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_blk, so, 16 /* sc1 */); },
+                     status, dead, 0x728u, t);
+        f32x4 o0, o1, o2;
+        gate_mfma(gi, v, o0, o1, o2);
+        float gir[4], giz[4], gin[4], xin[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gir[e] = o0[e] + __uint_as_float(c2[0][e]);
+            giz[e] = o1[e] + __uint_as_float(c2[1][e]);
+            gin[e] = o2[e] + __uint_as_float(c2[2][e]);
+            xin[e] = __uint_as_float(own[e]);
+        }
+        cell_publish(gir, giz, gin, xin);
+    };
+    // gh(t + 1) = W_hh . h(t) + b_hh of the wave's rows (h(t) of the whole layer gathered from the ring): stays in this lane's registers
+    auto gh_stage = [&]() {
+        const int so = cbase + L_H * DLAYERB + (t & (DRING - 1)) * XTB;
+        unsigned v[3][MPW];
+        gather_issue(xrs, so, gh, v);
+        if (__builtin_expect(!gather_there(v, 0u, live), 0))
+            wait_for([&] { return gather_there(v, 0u, live); }, [&] { gather_issue(xrs, so, gh, v); }, status, dead, 0x740u | (LA ? 0u : 8u), t);
+        f32x4 o0, o1, o2;
+        gate_mfma(gh, v, o0, o1, o2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ghr[e] = o0[e] + bh[0][e]; ghz[e] = o1[e] + bh[1][e]; ghn[e] = o2[e] + bh[2][e]; }
+    };
+    // rnn1: cI(tt) = b_I + W_I[:, 1:] . [m ; a1] of the wave's 16 rows (fatchord_version.py:203-209 without the x_{t-1} column), formed from
+    // the mel (or, wrnn_options.mel_stage, from the x25 signal: the last up-sampling stage too) and the frame's aux row -- wrnn_ring.h
+    auto cond_step = [&](int tt) {
+        const int p = SEGT[fi] + tt;
+        const bool valid = live && p < SEGT[SEG + fi];
+        const int fr = magic ? (int)(__umulhi((unsigned)p, magic) >> mshift) : p / hop;
+        f32x4 v;
+        if (mel_stage) {
+            const int j = p + SEGT[3 * SEG + fi];
+            const int row = j / LAST_SCALE;
+            v = cond_tile_rows(ct, mels_up + (size_t)(row - 1) * MEL, mel_coef + 3 * (j - row * LAST_SCALE), aux_fr + (size_t)fr * (4 * AUX), valid, lane);
+        } else v = cond_tile(ct, mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane);
+        const u32x4 q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+        store16(q, voff_blk, cbase + 4 * DLAYERB + (tt & (DRING - 1)) * XTB);
+    };
+    // rnn2's workgroup 0: fc3 (30 x 512: two 16-row tiles in A-fragment order, in LDS) + the mixture-of-logistics sampling of step t
+    auto sample = [&]() {
+        const int sb = cbase + (t & (DRING - 1)) * XTB;
+        u32x4 x[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 3 * DLAYERB, 16 /* sc1 */);
+        const int su = tid >> 4, sm = tid & 15;         // sampling role: 16-lane row = segment su, lane sm = mixture
+        const float *nrow = noise_pre + (size_t)(t - noise_t0) * 11 * Nall;
+        const int suc = su < nb ? su : nb - 1;
+        const float nz0 = nrow[(size_t)(b0g + suc) * 10 + (sm < 10 ? sm : 9)];
+        const float nz1 = nrow[(size_t)10 * Nall + b0g + suc];
+        if (__builtin_expect(!frag_there(x, live), 0))
+            wait_for([&] { return frag_there(x, live); },
+                     [&] {
+#pragma unroll
+                         for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 3 * DLAYERB, 16 /* sc1 */);
+                     },
+                     status, dead, 0x750u, t);
+        float b[32];
+        frag_to_b(x, b);
+        float *PW = PART + pp * (NW * 2 * 256);
+        put_partial<2>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
+        put_partial<2>(PW, w, 1, lane, mfma1_lds(F3 + XT + frag_off(w, 0, lane), b));
+        lds_barrier();
+        {   // 30 logit rows x 16 segments: thread (rows pu and 16 + pu, segment pj)
+            const float lg = get_partial<2>(PW, 0, pu, pj) + b3a;
+            const float lg2 = get_partial<2>(PW, 1, pu, pj) + b3b;
+            LOG[pj * SPLOGS + pu] = lg;
+            if (dbgl && pj < nb) dbgl[((size_t)t * Nall + b0g + pj) * C + pu] = lg;
+            if (pu < 14) {
+                LOG[pj * SPLOGS + 16 + pu] = lg2;
+                if (dbgl && pj < nb) dbgl[((size_t)t * Nall + b0g + pj) * C + 16 + pu] = lg2;
+            }
+        }
+        lds_barrier();
+        {
+            float best = (sm < 10) ? mol_gumbel_pre(LOG[su * SPLOGS + sm], nz0) : -INFINITY;
+            int bidx = sm;
+            argmax_row16(best, bidx);
+            if (sm == 0 && su < nb) {
+                float xv = mol_sample_pre(LOG[su * SPLOGS + 10 + bidx], LOG[su * SPLOGS + 20 + bidx], nz1);
+                outp[(size_t)(b0g + su) * Tall + t] = xv;
+                if (forcex) xv = forcex[(size_t)(b0g + su) * Tall + t];
+                const u32x2 q = {__float_as_uint(xv), (unsigned)t + 1u};          // one 8-byte word {x_t, tag}: its own flag, two entries, no re-arm
+                __builtin_amdgcn_raw_buffer_store_b64(q, xrs, su * 8, cbase + 7 * DLAYERB + (t & 1) * XTB, 16 /* sc1 */);
+            }
+        }
+        pp ^= 1;
+    };
+
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    if constexpr (LA) {                                 // the two steps a launch starts with; every later cI is formed at the end of the step before its use
+        cond_step(T0);
+        if (T0 + 1 < T1) cond_step(T0 + 1);
+        front_a(T0);
+    }
+    for (; t < T1; ++t) {
+        // ring hygiene: last step's re-arm stores (and, rnn1, the cI formed at its end) are out before anything of this step is published
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (LA) {
+            back_a();
+            gh_stage();                                 // (needs h1(t) of every rnn1 workgroup: one hop behind the publication above, long before x2(t))
+            fc(I1{});
+            fc(I2{});
+            if (t + 1 < T1) front_a(t + 1);             // under the sampling of step t
+            if (t + 2 < T1) cond_step(t + 2);
+        } else {
+            gates_b();
+            fc(I1{});
+            gh_stage();                                 // (h2(t) arrived with x2(t); its product is needed a step later: under y1's hop)
+            fc(I2{});
+            if (sampler) sample();
+        }
+    }
+    // ---- what the next launch of this round needs: h and gh(T1) of every (unit, segment), rnn1: x_{T1-1}; rnn1 leaves the sentinel in the cI
+    //      entries of steps T1 and T1 + 1 (the next launch polls its first two steps)
+    *reinterpret_cast<float4 *>(state_wg + tid * 16) = make_float4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<float4 *>(state_wg + tid * 16 + 4) = make_float4(ghr[0], ghr[1], ghr[2], ghr[3]);
+    *reinterpret_cast<float4 *>(state_wg + tid * 16 + 8) = make_float4(ghz[0], ghz[1], ghz[2], ghz[3]);
+    *reinterpret_cast<float4 *>(state_wg + tid * 16 + 12) = make_float4(ghn[0], ghn[1], ghn[2], ghn[3]);
+    if constexpr (LA) {
+        const int sx = cbase + 7 * DLAYERB + ((T1 - 1) & 1) * XTB;
+        u32x2 xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, fi * 8, sx, 16 /* sc1 */);
+        wait_for([&] { return !__any(live && xq.y != (unsigned)T1); }, [&] { xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, fi * 8, sx, 16 /* sc1 */); },
+                 status, dead, 0x761u, T1);
+        if (tid < SEG) state_wg[NT * 16 + tid] = live ? __uint_as_float(xq.x) : 0.f;
+        const u32x4 q = {SENT, SENT, SENT, SENT};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) store16(q, voff_blk, cbase + 4 * DLAYERB + ((T1 + e) & (DRING - 1)) * XTB);
+    }
+}
+
+// Grid = 16 clusters x 16 workgroups of 256 threads (one per CU), cooperative launch.  Placement (speed only, verified at run time): block
+// b is observed to run on XCD b % 8 and the blocks of an XCD to be dealt round-robin over its 32 CUs.  XCD x hosts clusters x (its CUs
+// 0-15) and 8 + x (CUs 16-31); CU c of a cluster: c / 8 = rnn1 | rnn2, unit block c % 8.  Group g of a round runs on cluster g: the first
+// eight groups take one cluster on every XCD.
+template <int NBP>
+__global__ __launch_bounds__(NT, 1) void wrnn_sparse_kernel(const LoopArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    check_kind(a);
+    const int b = blockIdx.x;
+    const int xcd = b % 8, q = b / 8;
+    const int cl = xcd + 8 * (q >> 4);
+    const int cu = q & 15;
+    if (cl >= a.NG) return;                             // a cluster without a group of this round
+    // ---- placement handshake (as wrnn_duo.hip): a cluster seen on ONE XCD exchanges everything through that XCD's L2 with plain stores
+    bool loc = false;
+    {
+        int *TAB = reinterpret_cast<int *>(smem) + sp_lds().off_misc;
+        const int tid = threadIdx.x;
+        unsigned *tab = a.xcc_tab + cl * SPWG;
+        if (tid == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;          // HW_REG_XCC_ID
+            __hip_atomic_store(tab + cu, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.prof && (a.tuning & 64)) {                                                 // placement read-out (test / profiling hook)
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                a.prof[blockIdx.x] = ((u64)xcc << 32) | hw | ((u64)(unsigned)(cu | (cl << 8)) << 40);
+            }
+        }
+        unsigned v = 1u;
+        if (tid < SPWG) {
+            unsigned spins = 0;
+            v = ld_agent32(tab + tid);
+            while (v == 0u && ++spins < 200000u) {
+                __builtin_amdgcn_s_sleep(2);
+                v = ld_agent32(tab + tid);
+            }
+            TAB[tid] = (int)v;
+        }
+        __syncthreads();
+        const int ok = (tid < SPWG) ? (v != 0u && (int)v == TAB[0]) : 1;
+        loc = __syncthreads_and(ok) != 0;
+        if (a.tuning & 256) loc = false;                // A/B: everything written through
+        __syncthreads();
+    }
+    if (cu < 8) sp_role<NBP, true>(a, smem, cl, cl, cu, cu, loc);
+    else sp_role<NBP, false>(a, smem, cl, cl, cu - 8, cu, loc);
+}
+
+// clusters of 16 CUs: the kernel's block -> role map is written for the whole 256-CU chip
+int sparse_clusters(int n_cus) { return n_cus >= SPCLUSTERS * SPWG ? SPCLUSTERS : 0; }
+size_t sparse_state_floats() { return (size_t)SPCLUSTERS * SPSTATE_CL; }
+size_t sparse_xbuf_bytes() { return (size_t)SPCLUSTERS * DSLOTB; }      // the regions a launch touches: a prefix of the duo kernel's buffer
+size_t sparse_lds_bytes() { return (size_t)sp_lds().total * sizeof(float); }
+
+hipError_t launch_sparse(const LoopArgs &args, int nbp, hipStream_t stream)
+{
+    if ((nbp != 48 && nbp != 64) || !args.fc3f || !args.u1 || !args.xcc_tab || !args.sp_vals || args.NG < 1 || args.NG > SPCLUSTERS) return hipErrorInvalidValue;
+    const size_t lds = sparse_lds_bytes();
+    const void *fn = nbp == 48 ? (const void *)wrnn_sparse_kernel<48> : (const void *)wrnn_sparse_kernel<64>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     LoopArgs a = args;
     void *params[] = {(void *)&a};
-    return hipLaunchCooperativeKernel((const void *)wrnn_sparse_kernel<G, NBP>, dim3(ncl * SNWGC), dim3(NT), params, (unsigned)lds, stream);
-}
-
-// clusters of 32 workgroups on an n_cus-CU device (8 = one per XCD on MI355X)
-int sparse_clusters(int n_cus)
-{
-    int ncl = n_cus / SNWGC;
-    if (ncl > SPCL) ncl = SPCL;
-    return ncl;
-}
-
-hipError_t launch_sparse(const LoopArgs &args, int G, int ncl, int nbp, hipStream_t stream)
-{
-    if (ncl < 1 || (nbp != 48 && nbp != 64)) return hipErrorInvalidValue;
-    if (G == 1) return nbp == 48 ? launch_sparse_t<1, 48>(args, ncl, stream) : launch_sparse_t<1, 64>(args, ncl, stream);
-    if (G == 2) return nbp == 48 ? launch_sparse_t<2, 48>(args, ncl, stream) : launch_sparse_t<2, 64>(args, ncl, stream);
-    return hipErrorInvalidValue;
+    return hipLaunchCooperativeKernel(fn, dim3(SPCLUSTERS * SPWG), dim3(NT), params, (unsigned)lds, stream);
 }
 
 }  // namespace wrnn

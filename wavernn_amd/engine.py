@@ -14,8 +14,16 @@ LOOP_KEYS = dict(I_w='I.weight', I_b='I.bias', w_ih1='rnn1.weight_ih_l0', w_hh1=
                  fc2_w='fc2.weight', fc2_b='fc2.bias', fc3_w='fc3.weight', fc3_b='fc3.bias')
 
 
+#: loop kernels that keep their state between launches: a call can be continued in step slices (wrnn_options.t_begin / t_end)
+RESUMABLE_KERNELS = ('wrnn_loop_kernel', 'wrnn_duo_kernel', 'wrnn_sparse_kernel')
+#: ... and those that form the last up-sampling stage of the mel themselves (wrnn_options.mel_stage: they take `MelRows`)
+MEL_STAGE_KERNELS = ('wrnn_duo_kernel', 'wrnn_sparse_kernel')
+#: what `auto` falls back to when a persistent grid is refused (cooperative launch not co-resident): kernel -> next algo
+FALLBACK_ALGO = {'wrnn_sparse_kernel': 'duo', 'wrnn_duo_kernel': 'loop'}
+
+
 class MelRows:
-    """The conditioning mel handed to the loop ONE up-sampling stage short (`wrnn_options.mel_stage = 1`, wrnn_duo_kernel only): the
+    """The conditioning mel handed to the loop ONE up-sampling stage short (`wrnn_options.mel_stage = 1`; wrnn_duo_kernel and wrnn_sparse_kernel): the
     kernel forms the last Stretch2d + conv stage and the crop (reference models/fatchord_version.py:73-80, :86-88) itself, so the
     [L, feat] up-sampled mel is never written.
 
@@ -206,22 +214,30 @@ class LoopEngine:
                                              self._ws.data_ptr(), self._ws.numel(), ctypes.byref(o), stream)
         if rc == _lib.ERR_RESIDENCY and t0 == 0 and (algo == 'auto' or _fallback):
             # the persistent grid is not co-resident right now (CU masking, a smaller partition, another cooperative kernel).  `auto`
-            # degrades in two steps: two workgroups per CU (wrnn_duo_kernel) -> one (wrnn_loop_kernel, its own workspace layout;
-            # continuations are pinned to it) -> the stream kernel (any device, no inter-workgroup traffic; whole calls only)
+            # degrades step by step (FALLBACK_ALGO): wrnn_sparse_kernel -> two workgroups per CU (wrnn_duo_kernel) -> one (wrnn_loop_kernel;
+            # each has its own workspace layout, continuations are pinned to the kernel the first slice ran on) -> the stream kernel (any
+            # device, no inter-workgroup traffic; whole calls only)
             import warnings
             why = self.lib.wrnn_last_error().decode()
-            if rows_in is not None:       # the other kernels read the up-sampled mel: the caller, who has the mel, redoes the conditioning
-                raise _lib.ResidencyError('cooperative launch refused (' + why + ')')
             planned = _lib.RunInfo()
             self.lib.wrnn_plan_segments(self._pack, B, T, ctypes.byref(o), ctypes.byref(planned))
-            if algo == 'auto' and (planned.kernel or b'') == b'wrnn_duo_kernel':
-                warnings.warn('wavernn_amd: cooperative launch refused (' + why + '); using wrnn_loop_kernel')
+            nxt = FALLBACK_ALGO.get((planned.kernel or b'').decode())
+            if rows_in is not None and nxt != 'duo':       # the other kernels read the up-sampled mel: the caller, who has the mel, redoes the conditioning
+                raise _lib.ResidencyError('cooperative launch refused (' + why + ')')
+            if rows_in is not None:
+                mels_up = rows_in
+            if nxt is not None:
+                warnings.warn('wavernn_amd: cooperative launch refused (' + why + '); trying algo = ' + nxt)
                 self._ws = None
-                return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='loop', force_x=force_x, want_logits=want_logits,
-                                         check=check, cond_valu=cond_valu, t_range=t_range, out=out, logits=logits, progress=progress,
-                                         _fallback=True)
+                if progress is not None:
+                    self._progress_keep.pop()       # (the retry registers its own thunk)
+                return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo=nxt, force_x=force_x, want_logits=want_logits,
+                                         check=check, slab_steps=slab_steps, cond_valu=cond_valu, t_range=t_range, out=out, logits=logits,
+                                         phase_clocks=phase_clocks, tuning=tuning, progress=progress, _fallback=True)
             if t1 == T:
                 warnings.warn('wavernn_amd: cooperative launch refused (' + why + '); using the stream kernel')
+                if progress is not None:
+                    self._progress_keep.pop()
                 return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='stream', force_x=force_x,
                                          want_logits=want_logits, check=check, cond_valu=cond_valu, out=out, logits=logits, progress=progress)
             # ... the same refusal on the first slice of a step-sliced run (only the loop kernels continue a call): the caller, who owns
@@ -230,7 +246,7 @@ class LoopEngine:
         _lib.check(rc, 'wrnn_generate_segments')
         self._launches = (self._launches if t0 > 0 else 0) + int(self._info.launches)
         if t0 == 0:
-            self._slice_algo = {'wrnn_loop_kernel': 'loop', 'wrnn_duo_kernel': 'duo'}.get((self._info.kernel or b'').decode())
+            self._slice_algo = {'wrnn_loop_kernel': 'loop', 'wrnn_duo_kernel': 'duo', 'wrnn_sparse_kernel': 'sparse'}.get((self._info.kernel or b'').decode())
         self._last_opts = (B, T, n_frames, self.options(algo, depth, clusters, slab_steps, cond_valu, None))
         if check:
             rc = self.lib.wrnn_status(self._ws.data_ptr(), stream)      # synchronises the stream: every queued progress call has run

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from . import _lib
 from . import fold as _fold
 from .dsp import save_wav
-from .engine import LoopEngine, LOOP_KEYS
+from .engine import LoopEngine, LOOP_KEYS, RESUMABLE_KERNELS, MEL_STAGE_KERNELS
 from .rng import burn_ctor_draws, draw_steps
 
 
@@ -214,12 +214,12 @@ class WaveRNN(nn.Module):
                                'there is no CPU path in this package')
 
     def mel_rows_ok(self, eng, n_segments, T):
-        """Whether a run over this many segments takes the mel one up-sampling stage short (`mel_in_loop`): it runs on wrnn_duo_kernel and
+        """Whether a run over this many segments takes the mel one up-sampling stage short (`mel_in_loop`): it runs on wrnn_duo_kernel / wrnn_sparse_kernel and
         the HIP pre-loop stage ends with the stretch factor that kernel is built for."""
         device = next(self.parameters()).device
         if not (self.mel_in_loop and self.pre_algo == 'native' and device.type == 'cuda'):
             return False
-        if eng.plan(n_segments, T, algo=self.loop_algo)['kernel'] != 'wrnn_duo_kernel':
+        if eng.plan(n_segments, T, algo=self.loop_algo)['kernel'] not in MEL_STAGE_KERNELS:
             return False
         try:
             return self._pre_engine().scales[2] == 11
@@ -278,7 +278,7 @@ class WaveRNN(nn.Module):
             # the sampling noise is drawn and uploaded in slices of steps (RAW: B * n_classes floats per step), each slice
             # continuing the loop where the previous one stopped (wrnn_options.t_begin / t_end)
             per_step = B * (11 if self.mode == 'MOL' else self.n_classes) * 4
-            resumable = eng.plan(B, T, algo=self.loop_algo)['kernel'] in ('wrnn_loop_kernel', 'wrnn_duo_kernel')
+            resumable = eng.plan(B, T, algo=self.loop_algo)['kernel'] in RESUMABLE_KERNELS
             chunk = max(1, min(T, self.noise_chunk_bytes // per_step)) if resumable else T
             chunk = -(-T // (-(-T // chunk)))                # equal slices (no short tail slice with its own launches)
             rng_state = torch.get_rng_state() if (self.noise_source == 'cpu' and (chunk < T or rows)) else None
