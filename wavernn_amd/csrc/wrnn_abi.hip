@@ -617,7 +617,7 @@ extern "C" int wrnn_plan_segments(const wrnn_pack *p, int32_t n_segments, int32_
     if (rc != WRNN_OK) return rc;
     memset(out, 0, sizeof *out);
     out->kernel = pl.kind == K_GENERIC ? "wrnn_generic_kernel" : pl.kind == K_DUO ? "wrnn_duo_kernel" : pl.kind == K_LOOP ? "wrnn_loop_kernel" : (pl.kind == K_SPARSE ? "wrnn_sparse_kernel" : "wrnn_stream_kernel");
-    out->units_per_wg = pl.kind == K_STREAM ? 0 : 16;
+    out->units_per_wg = pl.kind == K_STREAM ? 0 : (pl.kind == K_SPARSE ? 64 : 16);
     out->clusters = pl.ncl; out->depth = pl.G; out->rounds = pl.rounds; out->slab_steps = pl.slab;
     return WRNN_OK;
 }
