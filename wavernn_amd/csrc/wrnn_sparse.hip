@@ -50,7 +50,7 @@ static_assert(SPCLUSTERS <= LMAXG * MAXCL, "one exchange-buffer region per clust
 static_assert(SPCLUSTERS * SPWG <= XCC_WORDS, "placement table");
 
 struct SpLds {
-    int off_seg, off_part, off_log, off_misc, off_f3, total;
+    int off_seg, off_part, off_log, off_misc, off_prof, off_f3, total;
 };
 __host__ __device__ inline SpLds sp_lds()
 {
@@ -60,6 +60,7 @@ __host__ __device__ inline SpLds sp_lds()
     l.off_part = o; o += SPPART;
     l.off_log = o;  o += SEG * SPLOGS;
     l.off_misc = o; o += 64;                 // placement table of the cluster (ints)
+    l.off_prof = o; o += 64;                 // [32] u64 phase clocks (profiling builds)
     o = (o + 3) & ~3;
     l.off_f3 = o;   o += 2 * XT;             // the sampling workgroup: fc3 (30 x 512 = two 16-row tiles) in A-fragment order
     l.total = o;
@@ -122,6 +123,14 @@ __device__ __forceinline__ void gate_mfma(const GateTiles<MPW> &gt, const unsign
 
 __device__ __forceinline__ unsigned max4(const u32x4 &q) { return max(max(q.x, q.y), max(q.z, q.w)); }
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#define SPX(k)                                                                 \
+    do {                                                                       \
+        if (PROF && tid == 0) {                                                \
+            const u64 now_ = __builtin_amdgcn_s_memtime();                     \
+            PROFL[k] += now_ - plast;                                          \
+            plast = now_;                                                      \
+        }                                                                      \
+    } while (0)
 
 // two fc row tiles that share the activation operand (B fragments in registers); per tile mfma1's order (two chains by k-block parity)
 __device__ __forceinline__ void mfma2(const float (&a0)[AF], const float (&a1)[AF], const float (&b)[32], f32x4 &o0, f32x4 &o1)
@@ -145,13 +154,18 @@ __device__ __forceinline__ void mfma2(const float (&a0)[AF], const float (&a1)[A
 // One workgroup of a cluster: 64 units (unit block ub) of rnn1 (LA) or rnn2.  rg = the cluster's region of the exchange buffer, gid =
 // its group of the round, wgi = index in the cluster (fc rows [32 wgi, 32 wgi + 32) of fc1 and of fc2).
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int NBP, bool LA>
+// PROF (wrnn_options.phase_clocks; thread 0 of every workgroup, shader clocks per segment of a step): rnn1: 0 drain + wait for x_{t-1}, 1 cell +
+// publish, 2 wait for h1(t), 3 gh tiles, 4 wait x2, 5 fc1, 6 wait y1, 7 fc2, 8 wait cI(t+1), 9 W_ih . cI tiles, 10 cI(t+2) formed; rnn2: 0 drain + wait
+// for x1(t), 1 gate tiles + cell + publish, 2 wait x2, 3 fc1, 4 wait h2 (there), 5 gh tiles, 6 wait y1, 7 fc2, 8 wait y2, 9 fc3 + sampling; 15 = steps
+template <int NBP, bool LA, bool PROF>
 __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const int rg, const int gid, const int ub, const int wgi, const bool loc)
 {
     constexpr int MPW = NBP / 4;
     const SpLds L = sp_lds();
     float *PART = smem + L.off_part, *LOG = smem + L.off_log, *F3 = smem + L.off_f3;
     int *SEGT = reinterpret_cast<int *>(smem + L.off_seg);
+    u64 *PROFL = reinterpret_cast<u64 *>(smem + L.off_prof);
+    u64 plast = 0;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, kq = lane >> 4;           // MFMA coordinates: A row / B segment, k-quad; D: rows 4 kq + e, segment fi
     const int rb = 4 * ub + w;                          // this wave's 16-unit block of the layer (gate stages)
@@ -276,6 +290,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
                          for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + LI * DLAYERB, 16 /* sc1 */);
                      },
                      status, dead, 0x700u | (unsigned)which, t);
+        SPX(LA ? (which == 1 ? 4 : 6) : (which == 1 ? 2 : 6));
         if constexpr (which == 2) rearm();
         float b[32];
         frag_to_b(x, b);
@@ -289,6 +304,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         publish4l(xrs, sb + LO * DLAYERB + (2 * wgi) * 1024, tid, fmaxf(get_partial<2>(PW, 0, pu, pj) + cv0, 0.f), pj < nb, loc);
         publish4l(xrs, sb + LO * DLAYERB + (2 * wgi + 1) * 1024, tid, fmaxf(get_partial<2>(PW, 1, pu, pj) + cv1, 0.f), pj < nb, loc);
         pp ^= 1;
+        SPX(LA ? (which == 1 ? 5 : 7) : (which == 1 ? 3 : 7));
     };
 
     // ---------------- gate stages ----------------
@@ -319,7 +335,9 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
             wait_for([&] { return gather_there(v, max4(own), live); },
                      [&] { gather_issue(xrs, so, gi, v); own = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_blk, so, 16 /* sc1 */); },
                      status, dead, 0x720u, ts);
+        SPX(8);
         gate_mfma(gi, v, gacc[0], gacc[1], gacc[2]);
+        SPX(9);
     };
     // rnn1, back half (the chain: sampling -> here): x_{t-1} arrives as a tagged word {x, tag = t}
     auto back_a = [&]() {
@@ -332,6 +350,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
                          status, dead, 0x730u, t);
             xv = __uint_as_float(xq.x);
         } else if (resume) xv = state_wg[NT * 16 + fi];
+        SPX(0);
         float gir[4], giz[4], gin[4], xin[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -341,6 +360,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
             xin[e] = fmaf(w0o[e], xv, __uint_as_float(own[e]));      // xi of the lane's units (:208-209)
         }
         cell_publish(gir, giz, gin, xin);
+        SPX(1);
     };
     // rnn2: the whole gate stage is on the chain (x1 -> here)
     auto gates_b = [&]() {
@@ -356,6 +376,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
             wait_for([&] { return gather_there(v, max4(own), live); },
                      [&] { gather_issue(xrs, so, gi, v); own = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_blk, so, 16 /* sc1 */); },
                      status, dead, 0x728u, t);
+        SPX(0);
         f32x4 o0, o1, o2;
         gate_mfma(gi, v, o0, o1, o2);
         float gir[4], giz[4], gin[4], xin[4];
@@ -367,6 +388,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
             xin[e] = __uint_as_float(own[e]);
         }
         cell_publish(gir, giz, gin, xin);
+        SPX(1);
     };
     // gh(t + 1) = W_hh . h(t) + b_hh of the wave's rows (h(t) of the whole layer gathered from the ring): stays in this lane's registers
     auto gh_stage = [&]() {
@@ -375,10 +397,12 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         gather_issue(xrs, so, gh, v);
         if (__builtin_expect(!gather_there(v, 0u, live), 0))
             wait_for([&] { return gather_there(v, 0u, live); }, [&] { gather_issue(xrs, so, gh, v); }, status, dead, 0x740u | (LA ? 0u : 8u), t);
+        SPX(LA ? 2 : 4);
         f32x4 o0, o1, o2;
         gate_mfma(gh, v, o0, o1, o2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ghr[e] = o0[e] + bh[0][e]; ghz[e] = o1[e] + bh[1][e]; ghn[e] = o2[e] + bh[2][e]; }
+        SPX(LA ? 3 : 5);
     };
     // rnn1: cI(tt) = b_I + W_I[:, 1:] . [m ; a1] of the wave's 16 rows (fatchord_version.py:203-209 without the x_{t-1} column), formed from
     // the mel (or, wrnn_options.mel_stage, from the x25 signal: the last up-sampling stage too) and the frame's aux row -- wrnn_ring.h
@@ -394,6 +418,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         } else v = cond_tile(ct, mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane);
         const u32x4 q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
         store16(q, voff_blk, cbase + 4 * DLAYERB + (tt & (DRING - 1)) * XTB);
+        SPX(10);
     };
     // rnn2's workgroup 0: fc3 (30 x 512: two 16-row tiles in A-fragment order, in LDS) + the mixture-of-logistics sampling of step t
     auto sample = [&]() {
@@ -413,6 +438,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
                          for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 3 * DLAYERB, 16 /* sc1 */);
                      },
                      status, dead, 0x750u, t);
+        SPX(8);
         float b[32];
         frag_to_b(x, b);
         float *PW = PART + pp * (NW * 2 * 256);
@@ -443,6 +469,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
             }
         }
         pp ^= 1;
+        SPX(9);
     };
 
     using I1 = std::integral_constant<int, 1>;
@@ -452,7 +479,9 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         if (T0 + 1 < T1) cond_step(T0 + 1);
         front_a(T0);
     }
+    if (PROF && tid == 0) plast = __builtin_amdgcn_s_memtime();
     for (; t < T1; ++t) {
+        if (PROF && tid == 0) PROFL[15] += 1;
         // ring hygiene: last step's re-arm stores (and, rnn1, the cI formed at its end) are out before anything of this step is published
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (LA) {
@@ -469,6 +498,9 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
             fc(I2{});
             if (sampler) sample();
         }
+    }
+    if (PROF && tid == 0 && a.prof) {
+        for (int k = 0; k < 16; ++k) a.prof[(size_t)(blockIdx.x & 255) * 32 + k] += PROFL[k];
     }
     // ---- what the next launch of this round needs: h and gh(T1) of every (unit, segment), rnn1: x_{T1-1}; rnn1 leaves the sentinel in the cI
     //      entries of steps T1 and T1 + 1 (the next launch polls its first two steps)
@@ -492,7 +524,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
 // b is observed to run on XCD b % 8 and the blocks of an XCD to be dealt round-robin over its 32 CUs.  XCD x hosts clusters x (its CUs
 // 0-15) and 8 + x (CUs 16-31); CU c of a cluster: c / 8 = rnn1 | rnn2, unit block c % 8.  Group g of a round runs on cluster g: the first
 // eight groups take one cluster on every XCD.
-template <int NBP>
+template <int NBP, bool PROF>
 __global__ __launch_bounds__(NT, 1) void wrnn_sparse_kernel(const LoopArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -511,7 +543,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_sparse_kernel(const LoopArgs a)
         if (tid == 0) {
             const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;          // HW_REG_XCC_ID
             __hip_atomic_store(tab + cu, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.prof && (a.tuning & 64)) {                                                 // placement read-out (test / profiling hook)
+            if (!PROF && a.prof && (a.tuning & 64)) {                                                 // placement read-out (test / profiling hook)
                 const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
                 a.prof[blockIdx.x] = ((u64)xcc << 32) | hw | ((u64)(unsigned)(cu | (cl << 8)) << 40);
             }
@@ -532,8 +564,8 @@ __global__ __launch_bounds__(NT, 1) void wrnn_sparse_kernel(const LoopArgs a)
         if (a.tuning & 256) loc = false;                // A/B: everything written through
         __syncthreads();
     }
-    if (cu < 8) sp_role<NBP, true>(a, smem, cl, cl, cu, cu, loc);
-    else sp_role<NBP, false>(a, smem, cl, cl, cu - 8, cu, loc);
+    if (cu < 8) sp_role<NBP, true, PROF>(a, smem, cl, cl, cu, cu, loc);
+    else sp_role<NBP, false, PROF>(a, smem, cl, cl, cu - 8, cu, loc);
 }
 
 // clusters of 16 CUs: the kernel's block -> role map is written for the whole 256-CU chip
@@ -546,7 +578,9 @@ hipError_t launch_sparse(const LoopArgs &args, int nbp, hipStream_t stream)
 {
     if ((nbp != 48 && nbp != 64) || !args.fc3f || !args.u1 || !args.xcc_tab || !args.sp_vals || args.NG < 1 || args.NG > SPCLUSTERS) return hipErrorInvalidValue;
     const size_t lds = sparse_lds_bytes();
-    const void *fn = nbp == 48 ? (const void *)wrnn_sparse_kernel<48> : (const void *)wrnn_sparse_kernel<64>;
+    const bool prof = args.prof && !(args.tuning & 64);              // phase clocks (wrnn_options.phase_clocks)
+    const void *fn = nbp == 48 ? (prof ? (const void *)wrnn_sparse_kernel<48, true> : (const void *)wrnn_sparse_kernel<48, false>)
+                               : (prof ? (const void *)wrnn_sparse_kernel<64, true> : (const void *)wrnn_sparse_kernel<64, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     LoopArgs a = args;
