@@ -18,14 +18,16 @@
 //     over the 4 waves, partial tiles through LDS, one barrier) spread over all 64 waves of the cluster.
 //   * gate stage, no K split: wave w of a workgroup owns the 16-row block 4 ub + w of all three gates over the whole COMPACTED K
 //     (NBP <= 48 / 64 surviving columns, the pack's sp_vals / sp_cols): NBP / 4 MFMAs per gate, A = the packed block values, B = the
-//     activations GATHERED from the fragment-order layer (element (k, n) of a layer sits at float (k >> 2) * 64 + 4 n + (k & 3)): one
-//     4-byte sc1 load per lane and MFMA, every word its own arrival flag (the sentinel).  The accumulators ARE the gate pre-activations
+//     activations GATHERED from the layer: the layers the gate stages read (h1 h2 x1 cI) are k-major -- element (k, n) at float 16 k + n, so
+//     the 16 lanes of a k-quad read 64 contiguous bytes (in the fc stages' fragment order they would touch 4 x as many) --: one 4-byte sc1
+//     load per lane and MFMA, every word its own arrival flag (the sentinel).  The accumulators ARE the gate pre-activations
 //     of 4 consecutive units x 1 segment per lane: no partial tiles, no LDS, no barrier; the GRU cell runs in the accumulator registers
-//     and the lane's four new h / residual values are ONE 16-byte store straight into fragment order.
+//     and the lane's four new h values go out as four 4-byte stores (k-major h), its residual sums likewise (x1) or as ONE 16-byte
+//     store in the fc stages' fragment order (x2).
 //   * exchange: the duo kernel's buffer geometry and ring rules (wrnn_ring.h; wrnn_duo.hip "Ring discipline"): sentinel layers h1 h2 x1
 //     x2 y1 y2 with 4 ring entries, re-armed TWO steps ahead by the wave that publishes the words, after its last poll of the step (y1, in
-//     the fc2 stage) and drained at the top of its next step; cI without a sentinel inside a launch (formed one step ahead of its use,
-//     drained before the workgroup publishes anything of the next step; the first two steps of a launch are polled); x_t as tagged
+//     the fc2 stage) and drained at the top of its next step; cI without a sentinel inside a launch (cI(t + 2) is formed in the middle
+//     of step t, drained at the top of step t + 1 and gathered at the end of step t + 1; the first two steps of a launch are polled); x_t as tagged
 //     8-byte words {x, step + 1} in two entries (no re-arm at all).  The skew argument is simpler than the duo kernel's: every
 //     workgroup polls x2(t) and y1(t) of EVERY workgroup in every step, so nobody is ever more than one stage ahead of anybody.
 //     tests/test_sparse_exchange_model.py runs these rules as a discrete-event model under adversarial timing.
@@ -86,7 +88,7 @@ __device__ __forceinline__ void gate_tiles_init(GateTiles<MPW> &gt, const float 
             const size_t r = ((size_t)(m * 32 + rb) * 3 + g) * (4 * MPW) + 4 * i + kq;
             gt.a[g][i] = sp_vals[r * 16 + fi];
             const int c = sp_cols[r];                       // (padding blocks: column 0 with zero values)
-            gt.off[g][i] = (c >> 2) * 256 + (c & 3) * 4 + fi * 16;
+            gt.off[g][i] = c * 64 + fi * 4;                 // k-major layer: element (column c, segment fi)
         }
 }
 template <int MPW>
@@ -154,9 +156,10 @@ __device__ __forceinline__ void mfma2(const float (&a0)[AF], const float (&a1)[A
 // One workgroup of a cluster: 64 units (unit block ub) of rnn1 (LA) or rnn2.  rg = the cluster's region of the exchange buffer, gid =
 // its group of the round, wgi = index in the cluster (fc rows [32 wgi, 32 wgi + 32) of fc1 and of fc2).
 // ---------------------------------------------------------------------------------------------------------------------------------
-// PROF (wrnn_options.phase_clocks; thread 0 of every workgroup, shader clocks per segment of a step): rnn1: 0 drain + wait for x_{t-1}, 1 cell +
-// publish, 2 wait for h1(t), 3 gh tiles, 4 wait x2, 5 fc1, 6 wait y1, 7 fc2, 8 wait cI(t+1), 9 W_ih . cI tiles, 10 cI(t+2) formed; rnn2: 0 drain + wait
-// for x1(t), 1 gate tiles + cell + publish, 2 wait x2, 3 fc1, 4 wait h2 (there), 5 gh tiles, 6 wait y1, 7 fc2, 8 wait y2, 9 fc3 + sampling; 15 = steps
+// PROF (wrnn_options.phase_clocks; thread 0 of every workgroup, shader clocks per segment of a step, in program order): rnn1: 0 drain + wait for
+// x_{t-1}, 1 cell + publish, 2 wait for h1(t), 3 gh tiles, 10 cI(t+2) formed, 4 wait x2, 5 fc1, 6 wait y1, 7 fc2, 8 wait cI(t+1), 9 W_ih . cI tiles;
+// rnn2: 0 drain + wait for x1(t), 1 gate tiles + cell + publish, 2 wait x2, 3 fc1, 6 wait y1, 7 fc2, 8 wait y2, 9 fc3 + sampling, 4 wait h2 (there), 5 gh
+// tiles; 15 = steps
 template <int NBP, bool LA, bool PROF>
 __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const int rg, const int gid, const int ub, const int wgi, const bool loc)
 {
@@ -235,7 +238,8 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
     const __amdgpu_buffer_rsrc_t f1rs = make_rsrc(a.c3f, 0x7FFFF000u), f2rs = make_rsrc(a.c4f, 0x7FFFF000u);
     const int cbase = rg * DSLOTB;
     const int voff_frag = frag_off(w, 0, lane) * 4;      // fc stages: this lane's first fragment of a layer (bytes)
-    const int voff_blk = rb * 1024 + lane * 16;          // gate stages: this lane's 16-byte word {units u0 .. u0 + 3, segment fi} of a layer
+    const int voff_blk = rb * 1024 + lane * 16;          // gate stages: this lane's quarter-row of the wave's 1 KB block of a k-major layer (re-arm stores)
+    const int voff_own = u0 * 64 + fi * 4;               // ... the word of (unit u0, segment fi) in a k-major layer; units u0 + e: + 64 e
     const bool live = fi < nb;                           // this lane's segment exists (gate stages, fragment polls)
 
     bool dead = false;
@@ -257,6 +261,21 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         for (int e = 0; e < 4; ++e) { ghr[e] = bh[0][e]; ghz[e] = bh[1][e]; ghn[e] = bh[2][e]; }      // W_hh . 0 + b_hh
     }
 
+    // the lane's four units of a k-major layer (h1 h2 x1 cI: the layers the gate stages GATHER from -- [k][16 segments], 64 contiguous bytes
+    // per k: a gathering wave's load touches 4 x 64 B instead of 16 x 64 B in fragment order): four 4-byte stores, 64 bytes apart
+    auto store4 = [&](const u32x4 &q, int voff_layer, int soff) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (loc) __builtin_amdgcn_raw_buffer_store_b32(q[e], xrs, voff_layer + voff_own + 64 * e, soff, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(q[e], xrs, voff_layer + voff_own + 64 * e, soff, 16 /* sc1 */);
+        }
+    };
+    auto load_own = [&](int soff) {
+        u32x4 q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own + 64 * e, soff, 16 /* sc1 */);
+        return q;
+    };
     auto store16 = [&](const u32x4 &q, int voff, int soff) {
         if (loc) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, voff, soff, 0);       // the whole cluster was seen on one XCD: a plain store stays in its L2
         else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, voff, soff, 16 /* sc1 */);
@@ -320,8 +339,9 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         }
         if (live) {
             const int sb = cbase + (t & (DRING - 1)) * XTB;
-            store16(qx, L_XR * DLAYERB + voff_blk, sb);
-            store16(qh, L_H * DLAYERB + voff_blk, sb);
+            if constexpr (LA) store4(qx, L_XR * DLAYERB, sb);               // x1: gathered by rnn2's gate stage (k-major)
+            else store16(qx, L_XR * DLAYERB + voff_blk, sb);               // x2: read by the fc1 stages (fragment order: units u0 .. u0 + 3 of segment fi = one word)
+            store4(qh, L_H * DLAYERB, sb);
         }
     };
 
@@ -330,11 +350,9 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         const int so = cbase + L_IN * DLAYERB + (ts & (DRING - 1)) * XTB;
         unsigned v[3][MPW];
         gather_issue(xrs, so, gi, v);
-        own = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_blk, so, 16 /* sc1 */);
+        own = load_own(so);
         if (__builtin_expect(!gather_there(v, max4(own), live), 0))
-            wait_for([&] { return gather_there(v, max4(own), live); },
-                     [&] { gather_issue(xrs, so, gi, v); own = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_blk, so, 16 /* sc1 */); },
-                     status, dead, 0x720u, ts);
+            wait_for([&] { return gather_there(v, max4(own), live); }, [&] { gather_issue(xrs, so, gi, v); own = load_own(so); }, status, dead, 0x720u, ts);
         SPX(8);
         gate_mfma(gi, v, gacc[0], gacc[1], gacc[2]);
         SPX(9);
@@ -367,15 +385,13 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         const int so = cbase + L_IN * DLAYERB + (t & (DRING - 1)) * XTB;
         unsigned v[3][MPW];
         gather_issue(xrs, so, gi, v);
-        own = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_blk, so, 16 /* sc1 */);
+        own = load_own(so);
         const int fr = table_row(SEGT[fi] + t, SEGT[SEG + fi], SEGT[2 * SEG + fi], magic, mshift, hop, zrow);
         u32x4 c2[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) c2[q] = __builtin_amdgcn_raw_buffer_load_b128(crs, (fr * 3 * H + q * H + u0) * 4, 0, 0);
         if (__builtin_expect(!gather_there(v, max4(own), live), 0))
-            wait_for([&] { return gather_there(v, max4(own), live); },
-                     [&] { gather_issue(xrs, so, gi, v); own = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_blk, so, 16 /* sc1 */); },
-                     status, dead, 0x728u, t);
+            wait_for([&] { return gather_there(v, max4(own), live); }, [&] { gather_issue(xrs, so, gi, v); own = load_own(so); }, status, dead, 0x728u, t);
         SPX(0);
         f32x4 o0, o1, o2;
         gate_mfma(gi, v, o0, o1, o2);
@@ -417,7 +433,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
             v = cond_tile_rows(ct, mels_up + (size_t)(row - 1) * MEL, mel_coef + 3 * (j - row * LAST_SCALE), aux_fr + (size_t)fr * (4 * AUX), valid, lane);
         } else v = cond_tile(ct, mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane);
         const u32x4 q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-        store16(q, voff_blk, cbase + 4 * DLAYERB + (tt & (DRING - 1)) * XTB);
+        store4(q, 0, cbase + 4 * DLAYERB + (tt & (DRING - 1)) * XTB);
         SPX(10);
     };
     // rnn2's workgroup 0: fc3 (30 x 512: two 16-row tiles in A-fragment order, in LDS) + the mixture-of-logistics sampling of step t
@@ -474,29 +490,35 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
 
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
-    if constexpr (LA) {                                 // the two steps a launch starts with; every later cI is formed at the end of the step before its use
+    if (PROF && tid == 0) plast = __builtin_amdgcn_s_memtime();
+    if constexpr (LA) {                                 // the two steps a launch starts with; every later cI is formed during the step before its use
         cond_step(T0);
         if (T0 + 1 < T1) cond_step(T0 + 1);
         front_a(T0);
     }
-    if (PROF && tid == 0) plast = __builtin_amdgcn_s_memtime();
     for (; t < T1; ++t) {
         if (PROF && tid == 0) PROFL[15] += 1;
         // ring hygiene: last step's re-arm stores (and, rnn1, the cI formed at its end) are out before anything of this step is published
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (LA) {
+            // Off the chain, placed where this workgroup waits anyway (profiles/r05b_sparse_phase_clocks.json: with front_a and cond_step both
+            // behind fc2 the workgroup was ~1 us late for x_t): gh(t + 1) and cI(t + 2) while x1 -> rnn2 -> x2 is under way, W_ih . cI(t + 1)
+            // under the sampling of step t.  cI(t + 2) overwrites cI(t - 2), read by everybody before its fc1(t - 2); it is drained at the top of
+            // step t + 1 and read by workgroups that have seen x1(t + 1) of every rnn1 workgroup (header).
             back_a();
-            gh_stage();                                 // (needs h1(t) of every rnn1 workgroup: one hop behind the publication above, long before x2(t))
+            gh_stage();                                 // (needs h1(t) of every rnn1 workgroup: one hop behind the publication above)
+            if (t + 2 < T1) cond_step(t + 2);
             fc(I1{});
             fc(I2{});
-            if (t + 1 < T1) front_a(t + 1);             // under the sampling of step t
-            if (t + 2 < T1) cond_step(t + 2);
+            if (t + 1 < T1) front_a(t + 1);
         } else {
+            // gh(t + 1) is needed at the cell of step t + 1: behind fc2 (and, in the sampling workgroup, behind the sampling) it sits in the
+            // wait for x1(t + 1); between fc1 and fc2 its gather (~2 us) outlasted y1's hop and held up y2 (r05b phase clocks)
             gates_b();
             fc(I1{});
-            gh_stage();                                 // (h2(t) arrived with x2(t); its product is needed a step later: under y1's hop)
             fc(I2{});
             if (sampler) sample();
+            gh_stage();
         }
     }
     if (PROF && tid == 0 && a.prof) {
