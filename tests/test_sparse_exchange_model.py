@@ -1,13 +1,13 @@
 """A discrete-event MODEL of wrnn_sparse_kernel's exchange (csrc/wrnn_sparse.hip, round 5): one workgroup per CU, 8 rnn1 + 8 rnn2 workgroups
 per cluster (here: n + n), ONE group per cluster, every stage in one instruction stream per workgroup:
 
-    rnn1 j:  drain | x_{t-1} (tagged) -> cell -> publish x1, h1 | poll h1(t) -> gh (registers) | form cI(t + 2) | poll x2(t) -> publish y1 |
-             poll y1(t), RE-ARM own words of entry t + 2, publish y2 | poll cI(t + 1) -> W_ih . cI
+    rnn1 j:  drain | x_{t-1} (tagged) -> cell -> publish x1, h1 | poll h1(t) -> gh (registers) | poll x2(t) -> publish y1 |
+             poll y1(t), RE-ARM own words of entry t + 2, publish y2 | poll cI(t + 1) -> W_ih . cI | form cI(t + 2)
     rnn2 j:  drain | poll x1(t) -> cell -> publish x2, h2 | poll x2(t) -> publish y1 | poll y1(t), RE-ARM, publish y2 |
              j = 0: poll y2(t) -> sample -> x_t as a tagged word in entry t % 2 | poll h2(t) -> gh
 
 Sentinel layers (h1 x1 h2 x2 y1 y2): four ring entries, re-armed two steps ahead after the last poll of the step, drained at the top of the
-next step.  cI: no sentinel inside a launch, cI(t + 2) formed in the MIDDLE of step t, covered by the same drain, gathered at the end of step t + 1.  x_t: a
+next step.  cI: no sentinel inside a launch, cI(t + 2) formed at the END of step t, covered by the same drain, gathered at the end of step t + 1.  x_t: a
 tagged word, two entries, never re-armed.  Checked under adversarial timing (the engine of tests/test_duo_exchange_model.py: stores land
 after random delays, out of order, now and then later than ten whole steps -- only a drain waits for them): whatever a consumer accepts
 carries ITS step in every word, no re-arm lands on data still to be read, no tagged word is overwritten before it was read, everybody
@@ -67,8 +67,6 @@ class SparseSim(DuoSim):
                 yield ('work', 0.3)
                 publish('x1', t, j); publish('h1', t, j)
                 yield ('poll', ('h1', 0, t)); yield ('work', 0.5)                  # gh(t + 1), kept in registers
-                if self.cond_lead >= 1:
-                    form(t + 1 + self.cond_lead)                                   # cI(t + 2) in the middle of step t
                 yield ('poll', ('x2', 0, t)); yield ('work', 0.4); publish('y1', t, yj)
                 yield ('poll', ('y1', 0, t))
                 if self.rearm_site == 'fc2':
@@ -76,8 +74,7 @@ class SparseSim(DuoSim):
                 yield ('work', 0.4); publish('y2', t, yj)
                 if t + 1 < steps:
                     yield ('poll', ('cI', 0, t + 1)); yield ('work', 0.5)          # (no sentinel from step 2 on: the words must be step t + 1's)
-                if self.cond_lead < 1:
-                    form(t + 1 + self.cond_lead)
+                form(t + 1 + self.cond_lead)                                       # cI(t + 2) at the end of step t
             else:
                 yield ('poll', ('x1', 0, t)); yield ('work', 0.6)
                 publish('x2', t, j); publish('h2', t, j)

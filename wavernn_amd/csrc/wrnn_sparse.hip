@@ -26,7 +26,7 @@
 //     store in the fc stages' fragment order (x2).
 //   * exchange: the duo kernel's buffer geometry and ring rules (wrnn_ring.h; wrnn_duo.hip "Ring discipline"): sentinel layers h1 h2 x1
 //     x2 y1 y2 with 4 ring entries, re-armed TWO steps ahead by the wave that publishes the words, after its last poll of the step (y1, in
-//     the fc2 stage) and drained at the top of its next step; cI without a sentinel inside a launch (cI(t + 2) is formed in the middle
+//     the fc2 stage) and drained at the top of its next step; cI without a sentinel inside a launch (cI(t + 2) is formed at the end
 //     of step t, drained at the top of step t + 1 and gathered at the end of step t + 1; the first two steps of a launch are polled); x_t as tagged
 //     8-byte words {x, step + 1} in two entries (no re-arm at all).  The skew argument is simpler than the duo kernel's: every
 //     workgroup polls x2(t) and y1(t) of EVERY workgroup in every step, so nobody is ever more than one stage ahead of anybody.
@@ -157,7 +157,7 @@ __device__ __forceinline__ void mfma2(const float (&a0)[AF], const float (&a1)[A
 // its group of the round, wgi = index in the cluster (fc rows [32 wgi, 32 wgi + 32) of fc1 and of fc2).
 // ---------------------------------------------------------------------------------------------------------------------------------
 // PROF (wrnn_options.phase_clocks; thread 0 of every workgroup, shader clocks per segment of a step, in program order): rnn1: 0 drain + wait for
-// x_{t-1}, 1 cell + publish, 2 wait for h1(t), 3 gh tiles, 10 cI(t+2) formed, 4 wait x2, 5 fc1, 6 wait y1, 7 fc2, 8 wait cI(t+1), 9 W_ih . cI tiles;
+// x_{t-1}, 1 cell + publish, 2 wait for h1(t), 3 gh tiles, 4 wait x2, 5 fc1, 6 wait y1, 7 fc2, 8 wait cI(t+1), 9 W_ih . cI tiles, 10 cI(t+2) formed;
 // rnn2: 0 drain + wait for x1(t), 1 gate tiles + cell + publish, 2 wait x2, 3 fc1, 6 wait y1, 7 fc2, 8 wait y2, 9 fc3 + sampling, 4 wait h2 (there), 5 gh
 // tiles; 15 = steps
 template <int NBP, bool LA, bool PROF>
@@ -501,16 +501,17 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         // ring hygiene: last step's re-arm stores (and, rnn1, the cI formed at its end) are out before anything of this step is published
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (LA) {
-            // Off the chain, placed where this workgroup waits anyway (profiles/r05b_sparse_phase_clocks.json: with front_a and cond_step both
-            // behind fc2 the workgroup was ~1 us late for x_t): gh(t + 1) and cI(t + 2) while x1 -> rnn2 -> x2 is under way, W_ih . cI(t + 1)
-            // under the sampling of step t.  cI(t + 2) overwrites cI(t - 2), read by everybody before its fc1(t - 2); it is drained at the top of
-            // step t + 1 and read by workgroups that have seen x1(t + 1) of every rnn1 workgroup (header).
+            // Off the chain, placed where this workgroup waits anyway (profiles/r05b / r05c_sparse_phase_clocks.json): gh(t + 1) while x1 -> rnn2 ->
+            // x2 is under way (with cI(t + 2) formed there as well the workgroup reached fc1 ~0.5 us after x2: r05c); W_ih . cI(t + 1) and the
+            // forming of cI(t + 2) under the sampling of step t (2.3 us of wait for x_t were left with only the former there).  cI(t + 2)
+            // overwrites cI(t - 2), gathered by everybody at the end of step t - 3; it is drained at the top of step t + 1 and gathered by
+            // workgroups that have seen x1(t + 1) of every rnn1 workgroup (header).
             back_a();
             gh_stage();                                 // (needs h1(t) of every rnn1 workgroup: one hop behind the publication above)
-            if (t + 2 < T1) cond_step(t + 2);
             fc(I1{});
             fc(I2{});
             if (t + 1 < T1) front_a(t + 1);
+            if (t + 2 < T1) cond_step(t + 2);
         } else {
             // gh(t + 1) is needed at the cell of step t + 1: behind fc2 (and, in the sampling workgroup, behind the sampling) it sits in the
             // wait for x1(t + 1); between fc1 and fc2 its gather (~2 us) outlasted y1's hop and held up y2 (r05b phase clocks)
