@@ -2,12 +2,12 @@
 per cluster (here: n + n), ONE group per cluster, every stage in one instruction stream per workgroup:
 
     rnn1 j:  drain | x_{t-1} (tagged) -> cell -> publish x1, h1 | poll h1(t) -> gh (registers) | poll x2(t) -> publish y1 |
-             poll y1(t), RE-ARM own words of entry t + 2, publish y2 | poll cI(t + 1) -> W_ih . cI | form cI(t + 2)
+             poll y1(t), RE-ARM own words of entry t + 2, publish y2 | poll cI(t + 1) -> W_ih . cI
     rnn2 j:  drain | poll x1(t) -> cell -> publish x2, h2 | poll x2(t) -> publish y1 | poll y1(t), RE-ARM, publish y2 |
-             j = 0: poll y2(t) -> sample -> x_t as a tagged word in entry t % 2 | poll h2(t) -> gh
+             j = 0: poll y2(t) -> sample -> x_t as a tagged word in entry t % 2 | poll h2(t) -> gh | form cI(t + 2)
 
 Sentinel layers (h1 x1 h2 x2 y1 y2): four ring entries, re-armed two steps ahead after the last poll of the step, drained at the top of the
-next step.  cI: no sentinel inside a launch, cI(t + 2) formed at the END of step t, covered by the same drain, gathered at the end of step t + 1.  x_t: a
+next step.  cI: no sentinel inside a launch, cI(t + 2) formed by the rnn2 workgroups at the END of their step t, covered by the same drain, gathered by rnn1 at the end of step t + 1.  x_t: a
 tagged word, two entries, never re-armed.  Checked under adversarial timing (the engine of tests/test_duo_exchange_model.py: stores land
 after random delays, out of order, now and then later than ten whole steps -- only a drain waits for them): whatever a consumer accepts
 carries ITS step in every word, no re-arm lands on data still to be read, no tagged word is overwritten before it was read, everybody
@@ -49,13 +49,14 @@ class SparseSim(DuoSim):
             for layer, idx in ((mine[0], j), (mine[1], j), ('y1', yj), ('y2', yj)):
                 self.store(who, layer, 0, (t + self.ahead) % RING, idx, SENT, rearm_turn=t + self.ahead - RING + 1)
 
-        def form(tt):
-            if a and tt < steps:
+        def form(tt):                                         # (rnn2 workgroups form cI: they wait for x1 anyway)
+            if not a and tt < steps:
                 self.store(who, 'cI', 0, tt % RING, j, tt)
 
         if a:
-            form(0); form(1)
             yield ('poll', ('cI', 0, 0)); yield ('work', 0.5)                     # front half of step 0
+        else:
+            form(0); form(1)
         for t in range(steps):
             if self.drain:
                 yield ('drain', who)
@@ -74,7 +75,6 @@ class SparseSim(DuoSim):
                 yield ('work', 0.4); publish('y2', t, yj)
                 if t + 1 < steps:
                     yield ('poll', ('cI', 0, t + 1)); yield ('work', 0.5)          # (no sentinel from step 2 on: the words must be step t + 1's)
-                form(t + 1 + self.cond_lead)                                       # cI(t + 2) at the end of step t
             else:
                 yield ('poll', ('x1', 0, t)); yield ('work', 0.6)
                 publish('x2', t, j); publish('h2', t, j)
@@ -87,6 +87,7 @@ class SparseSim(DuoSim):
                     yield ('poll', ('y2', 0, t)); yield ('work', 0.8)
                     self.store(who, 'xt', 0, t % 2, 0, t)
                 yield ('poll', ('h2', 0, t)); yield ('work', 0.5)                  # gh(t + 1): behind fc2 (and the sampling), in the wait for x1(t + 1)
+                form(t + 1 + self.cond_lead)                                       # cI(t + 2) at the end of step t
 
 
 def test_sparse_exchange_is_safe_under_adversarial_timing():

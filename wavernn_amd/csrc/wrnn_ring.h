@@ -245,19 +245,22 @@ __device__ __forceinline__ void cond_tile_init(CondTile &c, const float *I_cT /*
     for (int i = 0; i < 4; ++i) c.bias[i] = I_b[LU * J + 4 * kq + i];
 }
 // mel_row = &mels_up[p][0] (80 floats), aux_row = &aux[frame][0] (a1 = its first 32 floats) of THIS lane's segment; valid == false (the
-// fold's zero padding, an absent segment): zero conditioning -> b_I
-__device__ __forceinline__ f32x4 cond_tile(const CondTile &c, const float *mel_row, const float *aux_row, bool valid, int lane)
+// fold's zero padding, an absent segment): zero conditioning -> b_I.  In two halves -- the lane's 28 inputs, the 28 MFMAs -- so that a
+// wave that forms TWO row blocks for the same segments (wrnn_sparse.hip) loads the inputs once.
+__device__ __forceinline__ void cond_inputs(const float *mel_row, const float *aux_row, bool valid, int lane, float4 (&v)[7])
 {
     const int kq = lane >> 4;
     // inputs 28 kq + 4 j .. + 3:  kq 0, 1: mel;  kq 2: mel 56..79 (j < 6), aux 0..3 (j = 6);  kq 3: aux 4..31
     const float *lo = (kq == 3) ? aux_row + 4 : mel_row + CK * kq;
     const float *hi = (kq == 2) ? aux_row : lo + 24;
-    float4 v[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) v[j] = *reinterpret_cast<const float4 *>(j < 6 ? lo + 4 * j : hi);
     }
+}
+__device__ __forceinline__ f32x4 cond_mfma(const CondTile &c, const float4 (&v)[7])
+{
     f32x4 a0 = {c.bias[0], c.bias[1], c.bias[2], c.bias[3]}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
@@ -268,13 +271,18 @@ __device__ __forceinline__ f32x4 cond_tile(const CondTile &c, const float *mel_r
     }
     return a0 + a1;
 }
+__device__ __forceinline__ f32x4 cond_tile(const CondTile &c, const float *mel_row, const float *aux_row, bool valid, int lane)
+{
+    float4 v[7];
+    cond_inputs(mel_row, aux_row, valid, lane, v);
+    return cond_mfma(c, v);
+}
 
-// The same tile with the mel row formed from the three rows of the last up-sampling stage's input that its 2 s + 1 taps reach
+// The same inputs with the mel row formed from the three rows of the last up-sampling stage's input that its 2 s + 1 taps reach
 // (s = LAST_SCALE): rows r0 (= row j / s - 1), r0 + MEL, r0 + 2 MEL; co = the three tap sums of this lane's phase j % s.
-__device__ __forceinline__ f32x4 cond_tile_rows(const CondTile &c, const float *r0, const float *co, const float *aux_row, bool valid, int lane)
+__device__ __forceinline__ void cond_inputs_rows(const float *r0, const float *co, const float *aux_row, bool valid, int lane, float4 (&v)[7])
 {
     const int kq = lane >> 4;
-    float4 v[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) {
@@ -295,15 +303,12 @@ __device__ __forceinline__ f32x4 cond_tile_rows(const CondTile &c, const float *
             }
         }
     }
-    f32x4 a0 = {c.bias[0], c.bias[1], c.bias[2], c.bias[3]}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w[4 * j + 0], v[j].x, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w[4 * j + 1], v[j].y, a1, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w[4 * j + 2], v[j].z, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w[4 * j + 3], v[j].w, a1, 0, 0, 0);
-    }
-    return a0 + a1;
+}
+__device__ __forceinline__ f32x4 cond_tile_rows(const CondTile &c, const float *r0, const float *co, const float *aux_row, bool valid, int lane)
+{
+    float4 v[7];
+    cond_inputs_rows(r0, co, aux_row, valid, lane, v);
+    return cond_mfma(c, v);
 }
 
 // GRU pointwise math with the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each) instead of the library's expf, tanhf

@@ -11,9 +11,10 @@
 //     cluster: the step IS the chain, no software pipeline, every stage is straight-line code in one instruction stream per wave.
 //   * a workgroup owns 64 hidden units of ONE GRU -- CUs 0-7 of a cluster: rnn1, CUs 8-15: rnn2 -- with BOTH halves of the cell: its rows
 //     of W_ih (on the chain) and of W_hh (gh(t+1) = W_hh . h(t) + b_hh, needed a step later: it stays in the wave's registers, no exchange).
-//     rnn1 workgroups also form the I-layer conditioning cI of their 64 rows (from the mel / the x25 signal and the frame's aux row, as
-//     wrnn_duo.hip) and multiply it through W_ih ahead of time: when x_{t-1} arrives only the x u1 term and the cell are left;
-//     rnn2's workgroup 0 runs fc3 + the mixture-of-logistics sampling (utils/distribution.py:87-123; both fc3 tiles in LDS).
+//     rnn1 workgroups multiply the I-layer conditioning cI through W_ih ahead of time: when x_{t-1} arrives only the x u1 term and the cell
+//     are left; rnn2's workgroup 0 runs fc3 + the mixture-of-logistics sampling (utils/distribution.py:87-123; both fc3 tiles in LDS); its
+//     other seven workgroups, which would wait ~3.5 us per step for x1, form cI (from the mel / the x25 signal and the frame's aux row, as
+//     wrnn_duo.hip: 32 row blocks over 28 waves, four of them two blocks from one set of inputs).
 //     EVERY workgroup owns 32 rows of fc1 and 32 rows of fc2 (registers): the two dense layers are the duo kernel's fc stage (K split
 //     over the 4 waves, partial tiles through LDS, one barrier) spread over all 64 waves of the cluster.
 //   * gate stage, no K split: wave w of a workgroup owns the 16-row block 4 ub + w of all three gates over the whole COMPACTED K
@@ -26,8 +27,9 @@
 //     store in the fc stages' fragment order (x2).
 //   * exchange: the duo kernel's buffer geometry and ring rules (wrnn_ring.h; wrnn_duo.hip "Ring discipline"): sentinel layers h1 h2 x1
 //     x2 y1 y2 with 4 ring entries, re-armed TWO steps ahead by the wave that publishes the words, after its last poll of the step (y1, in
-//     the fc2 stage) and drained at the top of its next step; cI without a sentinel inside a launch (cI(t + 2) is formed at the end
-//     of step t, drained at the top of step t + 1 and gathered at the end of step t + 1; the first two steps of a launch are polled); x_t as tagged
+//     the fc2 stage) and drained at the top of its next step; cI without a sentinel inside a launch (cI(t + 2) is formed by rnn2
+//     workgroups at the end of their step t, drained at the top of their step t + 1 -- before x2(t + 1) goes out -- and gathered by rnn1
+//     workgroups at the end of step t + 1, behind y1(t + 1), which needed every x2(t + 1); the first two steps of a launch are polled); x_t as tagged
 //     8-byte words {x, step + 1} in two entries (no re-arm at all).  The skew argument is simpler than the duo kernel's: every
 //     workgroup polls x2(t) and y1(t) of EVERY workgroup in every step, so nobody is ever more than one stage ahead of anybody.
 //     tests/test_sparse_exchange_model.py runs these rules as a discrete-event model under adversarial timing.
@@ -44,7 +46,6 @@ namespace wrnn {
 
 constexpr int SPCLUSTERS = 16;               // clusters of 16 CUs per chip
 constexpr int SPWG = 16;                     // workgroups per cluster (one per CU)
-constexpr int SPLOGS = 36;                   // LDS row stride of the 30 logits of a segment
 constexpr int SPPART = 2 * NW * 2 * 256;     // two ping-pong sets of [wave][tile 0..1][lane][4]
 constexpr int SPSTATE_WG = NT * 16 + SEG;    // saved state of a workgroup: per thread {h[4], gh_r[4], gh_z[4], gh_n[4]}, then x_{t1-1} (rnn1)
 constexpr int SPSTATE_CL = SPWG * SPSTATE_WG; // ... of a cluster
@@ -52,7 +53,7 @@ static_assert(SPCLUSTERS <= LMAXG * MAXCL, "one exchange-buffer region per clust
 static_assert(SPCLUSTERS * SPWG <= XCC_WORDS, "placement table");
 
 struct SpLds {
-    int off_seg, off_part, off_log, off_misc, off_prof, off_f3, total;
+    int off_seg, off_part, off_log, off_misc, off_prof, off_ct1, off_f3, total;
 };
 __host__ __device__ inline SpLds sp_lds()
 {
@@ -60,10 +61,11 @@ __host__ __device__ inline SpLds sp_lds()
     int o = 0;
     l.off_seg = o;  o += 64;                 // ints: 16 positions | 16 limits | 16 table-row bases of this slab | 16 mel offsets
     l.off_part = o; o += SPPART;
-    l.off_log = o;  o += SEG * SPLOGS;
+    l.off_log = o;  o += 32;                 // the sampling workgroup: fc3.bias
     l.off_misc = o; o += 64;                 // placement table of the cluster (ints)
     l.off_prof = o; o += 64;                 // [32] u64 phase clocks (profiling builds)
     o = (o + 3) & ~3;
+    l.off_ct1 = o;  o += 64 * (CK + 4);       // wave 0 of four workgroups: the I-layer tile of its SECOND cI block, [kk | bias][lane]
     l.off_f3 = o;   o += 2 * XT;             // the sampling workgroup: fc3 (30 x 512 = two 16-row tiles) in A-fragment order
     l.total = o;
     return l;
@@ -157,15 +159,15 @@ __device__ __forceinline__ void mfma2(const float (&a0)[AF], const float (&a1)[A
 // its group of the round, wgi = index in the cluster (fc rows [32 wgi, 32 wgi + 32) of fc1 and of fc2).
 // ---------------------------------------------------------------------------------------------------------------------------------
 // PROF (wrnn_options.phase_clocks; thread 0 of every workgroup, shader clocks per segment of a step, in program order): rnn1: 0 drain + wait for
-// x_{t-1}, 1 cell + publish, 2 wait for h1(t), 3 gh tiles, 4 wait x2, 5 fc1, 6 wait y1, 7 fc2, 8 wait cI(t+1), 9 W_ih . cI tiles, 10 cI(t+2) formed;
+// x_{t-1}, 1 cell + publish, 2 wait for h1(t), 3 gh tiles, 4 wait x2, 5 fc1, 6 wait y1, 7 fc2, 8 wait cI(t+1), 9 W_ih . cI tiles;
 // rnn2: 0 drain + wait for x1(t), 1 gate tiles + cell + publish, 2 wait x2, 3 fc1, 6 wait y1, 7 fc2, 8 wait y2, 9 fc3 + sampling, 4 wait h2 (there), 5 gh
-// tiles; 15 = steps
+// tiles, 10 cI(t+2) formed; 15 = steps
 template <int NBP, bool LA, bool PROF>
 __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const int rg, const int gid, const int ub, const int wgi, const bool loc)
 {
     constexpr int MPW = NBP / 4;
     const SpLds L = sp_lds();
-    float *PART = smem + L.off_part, *LOG = smem + L.off_log, *F3 = smem + L.off_f3;
+    float *PART = smem + L.off_part, *fc3b = smem + L.off_log, *F3 = smem + L.off_f3;
     int *SEGT = reinterpret_cast<int *>(smem + L.off_seg);
     u64 *PROFL = reinterpret_cast<u64 *>(smem + L.off_prof);
     u64 plast = 0;
@@ -220,9 +222,27 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
 #pragma unroll
     for (int e = 0; e < 4; ++e) w0o[e] = LA ? a.I_w0[u0 + e] : 0.f;
     const float b3a = sampler ? a.fc3_b[pu] : 0.f, b3b = (sampler && 16 + pu < 30) ? a.fc3_b[16 + pu] : 0.f;
-    CondTile ct;
-    if constexpr (LA) cond_tile_init(ct, a.I_cT, a.I_b, rb, lane);
+    // The I-layer conditioning cI (512 rows = 32 blocks of 16) is formed by rnn2's SEVEN non-sampling workgroups, which otherwise wait ~3.5 us
+    // per step for x1 (profiles/r05d_sparse_phase_clocks.json; on rnn1's workgroups it made them late for x_t): wave (ub >= 1, w) forms block
+    // 4 (ub - 1) + w, and wave 0 of ub = 1 .. 4 a second block 27 + ub from the same inputs (28 more MFMAs, no more loads).
+    const bool cond_wg = !LA && ub >= 1;
+    const bool cond2 = cond_wg && ub <= 4 && w == 0;
+    const int cblk0 = cond_wg ? 4 * (ub - 1) + w : 0, cblk1 = cond2 ? 27 + ub : 0;
+    CondTile ct0;
+    float *CT1 = smem + L.off_ct1;                      // (the second tile: LDS, read by wave 0 when it is used -- 32 registers fewer for everybody)
+    if constexpr (!LA) {
+        if (cond_wg) cond_tile_init(ct0, a.I_cT, a.I_b, cblk0, lane);
+    }
     __syncthreads();
+    if (sampler && tid >= 32 && tid < 64) fc3b[tid - 32] = tid - 32 < 30 ? a.fc3_b[tid - 32] : 0.f;
+    if (cond2) {
+        CondTile c1;
+        cond_tile_init(c1, a.I_cT, a.I_b, cblk1, lane);
+#pragma unroll
+        for (int kk = 0; kk < CK; ++kk) CT1[kk * 64 + lane] = c1.w[kk];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) CT1[(CK + i) * 64 + lane] = c1.bias[i];
+    }
     if (tid < SEG) {
         const int sc = b0g + (tid < nb ? tid : nb - 1);
         const int pos = a.seg_pos[sc];
@@ -310,7 +330,6 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
                      },
                      status, dead, 0x700u | (unsigned)which, t);
         SPX(LA ? (which == 1 ? 4 : 6) : (which == 1 ? 2 : 6));
-        if constexpr (which == 2) rearm();
         float b[32];
         frag_to_b(x, b);
         float *PW = PART + pp * (NW * 2 * 256);
@@ -322,6 +341,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         lds_barrier();
         publish4l(xrs, sb + LO * DLAYERB + (2 * wgi) * 1024, tid, fmaxf(get_partial<2>(PW, 0, pu, pj) + cv0, 0.f), pj < nb, loc);
         publish4l(xrs, sb + LO * DLAYERB + (2 * wgi + 1) * 1024, tid, fmaxf(get_partial<2>(PW, 1, pu, pj) + cv1, 0.f), pj < nb, loc);
+        if constexpr (which == 2) rearm();              // (behind the last poll of the step -- y1(t) above -- and behind the publication: off the chain)
         pp ^= 1;
         SPX(LA ? (which == 1 ? 5 : 7) : (which == 1 ? 3 : 7));
     };
@@ -345,16 +365,20 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         }
     };
 
-    // rnn1, front half: W_ih1 . cI(ts) of the wave's rows + the lane's own cI words (the residual input xi - w0 x), as soon as cI(ts) is there
-    auto front_a = [&](int ts) {
+    // rnn1, front half: W_ih1 . cI(ts) of the wave's rows + the lane's own cI words (the residual input xi - w0 x), as soon as cI(ts) is there.
+    // In two parts, so that the forming of cI(ts + 1) runs under the gather's latency: issue | ... | finish
+    unsigned fv[3][MPW];
+    auto front_issue = [&](int ts) {
         const int so = cbase + L_IN * DLAYERB + (ts & (DRING - 1)) * XTB;
-        unsigned v[3][MPW];
-        gather_issue(xrs, so, gi, v);
+        gather_issue(xrs, so, gi, fv);
         own = load_own(so);
-        if (__builtin_expect(!gather_there(v, max4(own), live), 0))
-            wait_for([&] { return gather_there(v, max4(own), live); }, [&] { gather_issue(xrs, so, gi, v); own = load_own(so); }, status, dead, 0x720u, ts);
+    };
+    auto front_finish = [&](int ts) {
+        const int so = cbase + L_IN * DLAYERB + (ts & (DRING - 1)) * XTB;
+        if (__builtin_expect(!gather_there(fv, max4(own), live), 0))
+            wait_for([&] { return gather_there(fv, max4(own), live); }, [&] { gather_issue(xrs, so, gi, fv); own = load_own(so); }, status, dead, 0x720u, ts);
         SPX(8);
-        gate_mfma(gi, v, gacc[0], gacc[1], gacc[2]);
+        gate_mfma(gi, fv, gacc[0], gacc[1], gacc[2]);
         SPX(9);
     };
     // rnn1, back half (the chain: sampling -> here): x_{t-1} arrives as a tagged word {x, tag = t}
@@ -420,20 +444,37 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         for (int e = 0; e < 4; ++e) { ghr[e] = o0[e] + bh[0][e]; ghz[e] = o1[e] + bh[1][e]; ghn[e] = o2[e] + bh[2][e]; }
         SPX(LA ? 3 : 5);
     };
-    // rnn1: cI(tt) = b_I + W_I[:, 1:] . [m ; a1] of the wave's 16 rows (fatchord_version.py:203-209 without the x_{t-1} column), formed from
-    // the mel (or, wrnn_options.mel_stage, from the x25 signal: the last up-sampling stage too) and the frame's aux row -- wrnn_ring.h
+    // rnn2's non-sampling workgroups: cI(tt) = b_I + W_I[:, 1:] . [m ; a1] of the wave's row block(s) (fatchord_version.py:203-209 without the
+    // x_{t-1} column), formed from the mel (or, wrnn_options.mel_stage, from the x25 signal: the last up-sampling stage too) and the frame's
+    // aux row -- wrnn_ring.h -- into the k-major layer 4
+    auto cond_store = [&](const f32x4 &v, int blk, int soff) {
+        const int vo = (LU * blk + 4 * kq) * 64 + fi * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (loc) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), xrs, vo + 64 * e, soff, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), xrs, vo + 64 * e, soff, 16 /* sc1 */);
+        }
+    };
     auto cond_step = [&](int tt) {
         const int p = SEGT[fi] + tt;
         const bool valid = live && p < SEGT[SEG + fi];
         const int fr = magic ? (int)(__umulhi((unsigned)p, magic) >> mshift) : p / hop;
-        f32x4 v;
+        float4 v[7];
         if (mel_stage) {
             const int j = p + SEGT[3 * SEG + fi];
             const int row = j / LAST_SCALE;
-            v = cond_tile_rows(ct, mels_up + (size_t)(row - 1) * MEL, mel_coef + 3 * (j - row * LAST_SCALE), aux_fr + (size_t)fr * (4 * AUX), valid, lane);
-        } else v = cond_tile(ct, mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane);
-        const u32x4 q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-        store4(q, 0, cbase + 4 * DLAYERB + (tt & (DRING - 1)) * XTB);
+            cond_inputs_rows(mels_up + (size_t)(row - 1) * MEL, mel_coef + 3 * (j - row * LAST_SCALE), aux_fr + (size_t)fr * (4 * AUX), valid, lane, v);
+        } else cond_inputs(mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane, v);
+        const int so = cbase + 4 * DLAYERB + (tt & (DRING - 1)) * XTB;
+        cond_store(cond_mfma(ct0, v), cblk0, so);
+        if (cond2) {
+            CondTile c1;
+#pragma unroll
+            for (int kk = 0; kk < CK; ++kk) c1.w[kk] = CT1[kk * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c1.bias[i] = CT1[(CK + i) * 64 + lane];
+            cond_store(cond_mfma(c1, v), cblk1, so);
+        }
         SPX(10);
     };
     // rnn2's workgroup 0: fc3 (30 x 512: two 16-row tiles in A-fragment order, in LDS) + the mixture-of-logistics sampling of step t
@@ -461,23 +502,19 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         put_partial<2>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
         put_partial<2>(PW, w, 1, lane, mfma1_lds(F3 + XT + frag_off(w, 0, lane), b));
         lds_barrier();
-        {   // 30 logit rows x 16 segments: thread (rows pu and 16 + pu, segment pj)
-            const float lg = get_partial<2>(PW, 0, pu, pj) + b3a;
-            const float lg2 = get_partial<2>(PW, 1, pu, pj) + b3b;
-            LOG[pj * SPLOGS + pu] = lg;
-            if (dbgl && pj < nb) dbgl[((size_t)t * Nall + b0g + pj) * C + pu] = lg;
-            if (pu < 14) {
-                LOG[pj * SPLOGS + 16 + pu] = lg2;
-                if (dbgl && pj < nb) dbgl[((size_t)t * Nall + b0g + pj) * C + 16 + pu] = lg2;
-            }
+        if (dbgl && pj < nb) {                          // test hook: the 30 logits of every segment (thread: rows pu and 16 + pu, segment pj)
+            dbgl[((size_t)t * Nall + b0g + pj) * C + pu] = get_partial<2>(PW, 0, pu, pj) + b3a;
+            if (pu < 14) dbgl[((size_t)t * Nall + b0g + pj) * C + 16 + pu] = get_partial<2>(PW, 1, pu, pj) + b3b;
         }
-        lds_barrier();
-        {
-            float best = (sm < 10) ? mol_gumbel_pre(LOG[su * SPLOGS + sm], nz0) : -INFINITY;
+        {   // utils/distribution.py:102-121: lane sm < 10 of a 16-lane row sums the partial tiles of ITS mixture logit (row sm of segment su) straight
+            // from LDS -- no second pass through LDS, no second barrier --, Gumbel-max over the row, then lane 0 fetches mean and log-scale of the winner
+            float best = (sm < 10) ? mol_gumbel_pre(get_partial<2>(PW, 0, sm < 10 ? sm : 0, su) + fc3b[sm < 10 ? sm : 0], nz0) : -INFINITY;
             int bidx = sm;
             argmax_row16(best, bidx);
             if (sm == 0 && su < nb) {
-                float xv = mol_sample_pre(LOG[su * SPLOGS + 10 + bidx], LOG[su * SPLOGS + 20 + bidx], nz1);
+                const float mean = get_partial<2>(PW, (10 + bidx) >> 4, (10 + bidx) & 15, su) + fc3b[10 + bidx];
+                const float ls = get_partial<2>(PW, (20 + bidx) >> 4, (20 + bidx) & 15, su) + fc3b[20 + bidx];
+                float xv = mol_sample_pre(mean, ls, nz1);
                 outp[(size_t)(b0g + su) * Tall + t] = xv;
                 if (forcex) xv = forcex[(size_t)(b0g + su) * Tall + t];
                 const u32x2 q = {__float_as_uint(xv), (unsigned)t + 1u};          // one 8-byte word {x_t, tag}: its own flag, two entries, no re-arm
@@ -491,41 +528,43 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     if (PROF && tid == 0) plast = __builtin_amdgcn_s_memtime();
-    if constexpr (LA) {                                 // the two steps a launch starts with; every later cI is formed during the step before its use
+    if constexpr (LA) {
+        front_issue(T0);
+        front_finish(T0);
+    } else if (cond_wg) {                               // the two steps a launch starts with; every later cI is formed during the step before its use
         cond_step(T0);
         if (T0 + 1 < T1) cond_step(T0 + 1);
-        front_a(T0);
     }
     for (; t < T1; ++t) {
         if (PROF && tid == 0) PROFL[15] += 1;
         // ring hygiene: last step's re-arm stores (and, rnn1, the cI formed at its end) are out before anything of this step is published
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (LA) {
-            // Off the chain, placed where this workgroup waits anyway (profiles/r05b / r05c_sparse_phase_clocks.json): gh(t + 1) while x1 -> rnn2 ->
-            // x2 is under way (with cI(t + 2) formed there as well the workgroup reached fc1 ~0.5 us after x2: r05c); W_ih . cI(t + 1) and the
-            // forming of cI(t + 2) under the sampling of step t (2.3 us of wait for x_t were left with only the former there).  cI(t + 2)
-            // overwrites cI(t - 2), gathered by everybody at the end of step t - 3; it is drained at the top of step t + 1 and gathered by
-            // workgroups that have seen x1(t + 1) of every rnn1 workgroup (header).
+            // Off the chain, placed where this workgroup waits anyway (profiles/r05b .. r05d_sparse_phase_clocks.json): gh(t + 1) while x1 -> rnn2
+            // -> x2 is under way, W_ih . cI(t + 1) under the sampling of step t.
             back_a();
             gh_stage();                                 // (needs h1(t) of every rnn1 workgroup: one hop behind the publication above)
             fc(I1{});
             fc(I2{});
-            if (t + 1 < T1) front_a(t + 1);
-            if (t + 2 < T1) cond_step(t + 2);
+            if (t + 1 < T1) { front_issue(t + 1); front_finish(t + 1); }
         } else {
             // gh(t + 1) is needed at the cell of step t + 1: behind fc2 (and, in the sampling workgroup, behind the sampling) it sits in the
-            // wait for x1(t + 1); between fc1 and fc2 its gather (~2 us) outlasted y1's hop and held up y2 (r05b phase clocks)
+            // wait for x1(t + 1); between fc1 and fc2 its gather outlasted y1's hop and held up y2 (r05b phase clocks).  The non-sampling
+            // workgroups then form cI(t + 2): it overwrites cI(t - 2), gathered by every rnn1 workgroup at the end of its step t - 3; it is
+            // drained at the top of step t + 1, before x2(t + 1) goes out, and gathered by workgroups that have polled y1(t + 1), which needed
+            // x2(t + 1) of every rnn2 workgroup (header).
             gates_b();
             fc(I1{});
             fc(I2{});
             if (sampler) sample();
             gh_stage();
+            if (cond_wg && t + 2 < T1) cond_step(t + 2);
         }
     }
     if (PROF && tid == 0 && a.prof) {
         for (int k = 0; k < 16; ++k) a.prof[(size_t)(blockIdx.x & 255) * 32 + k] += PROFL[k];
     }
-    // ---- what the next launch of this round needs: h and gh(T1) of every (unit, segment), rnn1: x_{T1-1}; rnn1 leaves the sentinel in the cI
+    // ---- what the next launch of this round needs: h and gh(T1) of every (unit, segment), rnn1: x_{T1-1}; the workgroups that form cI leave the sentinel in the cI
     //      entries of steps T1 and T1 + 1 (the next launch polls its first two steps)
     *reinterpret_cast<float4 *>(state_wg + tid * 16) = make_float4(h[0], h[1], h[2], h[3]);
     *reinterpret_cast<float4 *>(state_wg + tid * 16 + 4) = make_float4(ghr[0], ghr[1], ghr[2], ghr[3]);
@@ -537,9 +576,14 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         wait_for([&] { return !__any(live && xq.y != (unsigned)T1); }, [&] { xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, fi * 8, sx, 16 /* sc1 */); },
                  status, dead, 0x761u, T1);
         if (tid < SEG) state_wg[NT * 16 + tid] = live ? __uint_as_float(xq.x) : 0.f;
+    }
+    if (cond_wg) {                                      // (a block of a k-major layer is 1 KB: one 16-byte store per lane)
         const u32x4 q = {SENT, SENT, SENT, SENT};
 #pragma unroll
-        for (int e = 0; e < 2; ++e) store16(q, voff_blk, cbase + 4 * DLAYERB + ((T1 + e) & (DRING - 1)) * XTB);
+        for (int e = 0; e < 2; ++e) {
+            store16(q, cblk0 * 1024 + lane * 16, cbase + 4 * DLAYERB + ((T1 + e) & (DRING - 1)) * XTB);
+            if (cond2) store16(q, cblk1 * 1024 + lane * 16, cbase + 4 * DLAYERB + ((T1 + e) & (DRING - 1)) * XTB);
+        }
     }
 }
 
