@@ -65,7 +65,7 @@ __host__ __device__ inline SpLds sp_lds()
     l.off_misc = o; o += 64;                 // placement table of the cluster (ints)
     l.off_prof = o; o += 64;                 // [32] u64 phase clocks (profiling builds)
     o = (o + 3) & ~3;
-    l.off_ct1 = o;  o += 64 * (CK + 4);       // wave 0 of four workgroups: the I-layer tile of its SECOND cI block, [kk | bias][lane]
+    l.off_ct1 = o;  o += 5 * 64 * (CK + 4);   // rnn2's cI-forming workgroups: the I-layer tiles [wave 0..3 | wave 0's SECOND block][kk | bias][lane]
     l.off_f3 = o;   o += 2 * XT;             // the sampling workgroup: fc3 (30 x 512 = two 16-row tiles) in A-fragment order
     l.total = o;
     return l;
@@ -228,20 +228,25 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
     const bool cond_wg = !LA && ub >= 1;
     const bool cond2 = cond_wg && ub <= 4 && w == 0;
     const int cblk0 = cond_wg ? 4 * (ub - 1) + w : 0, cblk1 = cond2 ? 27 + ub : 0;
-    CondTile ct0;
-    float *CT1 = smem + L.off_ct1;                      // (the second tile: LDS, read by wave 0 when it is used -- 32 registers fewer for everybody)
-    if constexpr (!LA) {
-        if (cond_wg) cond_tile_init(ct0, a.I_cT, a.I_b, cblk0, lane);
-    }
+    // (the I-layer tiles live in LDS and are read when a block is formed, off the chain: with them in registers every stage of the rnn2
+    // workgroups -- fc1 / fc2 are on the chain -- ran ~0.3 us slower, profiles/r05e_sparse_phase_clocks.json)
+    float *CT0 = smem + L.off_ct1 + w * 64 * (CK + 4), *CT1 = smem + L.off_ct1 + 4 * 64 * (CK + 4);
     __syncthreads();
     if (sampler && tid >= 32 && tid < 64) fc3b[tid - 32] = tid - 32 < 30 ? a.fc3_b[tid - 32] : 0.f;
-    if (cond2) {
+    if (cond_wg) {
         CondTile c1;
-        cond_tile_init(c1, a.I_cT, a.I_b, cblk1, lane);
+        cond_tile_init(c1, a.I_cT, a.I_b, cblk0, lane);
 #pragma unroll
-        for (int kk = 0; kk < CK; ++kk) CT1[kk * 64 + lane] = c1.w[kk];
+        for (int kk = 0; kk < CK; ++kk) CT0[kk * 64 + lane] = c1.w[kk];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) CT1[(CK + i) * 64 + lane] = c1.bias[i];
+        for (int i = 0; i < 4; ++i) CT0[(CK + i) * 64 + lane] = c1.bias[i];
+        if (cond2) {
+            cond_tile_init(c1, a.I_cT, a.I_b, cblk1, lane);
+#pragma unroll
+            for (int kk = 0; kk < CK; ++kk) CT1[kk * 64 + lane] = c1.w[kk];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) CT1[(CK + i) * 64 + lane] = c1.bias[i];
+        }
     }
     if (tid < SEG) {
         const int sc = b0g + (tid < nb ? tid : nb - 1);
@@ -466,9 +471,13 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
             cond_inputs_rows(mels_up + (size_t)(row - 1) * MEL, mel_coef + 3 * (j - row * LAST_SCALE), aux_fr + (size_t)fr * (4 * AUX), valid, lane, v);
         } else cond_inputs(mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane, v);
         const int so = cbase + 4 * DLAYERB + (tt & (DRING - 1)) * XTB;
-        cond_store(cond_mfma(ct0, v), cblk0, so);
+        CondTile c1;
+#pragma unroll
+        for (int kk = 0; kk < CK; ++kk) c1.w[kk] = CT0[kk * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c1.bias[i] = CT0[(CK + i) * 64 + lane];
+        cond_store(cond_mfma(c1, v), cblk0, so);
         if (cond2) {
-            CondTile c1;
 #pragma unroll
             for (int kk = 0; kk < CK; ++kk) c1.w[kk] = CT1[kk * 64 + lane];
 #pragma unroll
