@@ -165,7 +165,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--utterances', type=int, default=16, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=641, help='mel frames per utterance')
-    ap.add_argument('--algo', default='auto', choices=['auto', 'loop', 'sparse', 'stream'])
+    ap.add_argument('--algo', default='auto', choices=['auto', 'loop', 'duo', 'sparse', 'stream'])
     ap.add_argument('--mode', default='MOL', choices=['MOL', 'RAW'], help="RAW = 9-bit mu-law ('bits') softmax sampling")
     ap.add_argument('--force-dist', action='store_true', help='initialise a torch.distributed nccl (= RCCL) group even at --gpus 1')
     ap.add_argument('--no-single', action='store_true', help="skip the single-utterance generate() entries (BASELINE config 2's N=481 / N=1001)")
@@ -179,6 +179,7 @@ def main():
                          "utterances of RandomState(2024).randint(300, 901) frames = 942 folded segments, sharded over the ranks "
                          "(strong scaling)")
     ap.add_argument('--corpus-limit', type=int, default=64, help=argparse.SUPPRESS)     # tests: only the first K utterances of config 4
+    ap.add_argument('--no-config4-leg', action='store_true', help="skip the `config.config4` leg (BASELINE config 4's fixed corpus shared by the N ranks)")
     ap.add_argument('--target', type=int, default=11000, help=argparse.SUPPRESS)
     ap.add_argument('--overlap', type=int, default=550, help=argparse.SUPPRESS)
     ap.add_argument('--dry-host', default=None, metavar='MODULE:FACTORY',
@@ -274,11 +275,65 @@ def main():
             loop_ms.append(eng.last_loop_ms())
     fence()
     dt = time.perf_counter() - t0
+    main_info = eng.last_run_info() if eng is not None else None
     if group is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    from wavernn_amd.batch import shard_bounds
+    from wavernn_amd.batch import shard_bounds, choose_ranks
+
+    def config4_leg():
+        """BASELINE config 4 beside the weak-scaling value (round-4 verdict, item 6): the FIXED corpus -- 64 random mels of 300-900 frames =
+        942 folded segments, 479 s of audio -- sharded over the N ranks of THIS launch (strong scaling), timed like the main loop (barrier +
+        synchronise on both sides, max over ranks).  `batch.choose_ranks` may leave ranks out when fewer fill the pipeline to the same depth.
+        Every rank runs this (collectives inside); rank 0 reports."""
+        f4 = [int(n) for n in np.random.RandomState(2024).randint(300, 901, 64)][:args.corpus_limit]
+        p4 = plan_utterances([n * hop for n in f4], target, overlap)
+        m4 = [torch.from_numpy(random_mel(1000 + u, n)).unsqueeze(0).to(dev) for u, n in enumerate(f4)]
+        s4 = [4000 + u for u in range(len(f4))]
+        active = choose_ranks(p4.n_segments, world)
+        tm = {}
+
+        def pass4():
+            generate_corpus(model, m4, target, overlap, True, s4, group=group, noise_source=noise_source, finish='own', check=False,
+                            loop_fn=loop_fn, ranks=active, timings=tm)
+            if eng is not None:
+                eng.status()
+        reps = 1 if dry else 2
+        if not dry:
+            pass4()
+        tm.clear()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pass4()
+        fence()
+        d4 = (time.perf_counter() - t0) / reps
+        if group is not None:
+            tt = torch.tensor([d4, tm.get('gather_wait_ms', 0.0) / reps, tm.get('unfold_under_gather_ms', 0.0) / reps], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d4, gw, uu = (float(x) for x in tt.tolist())
+        else:
+            gw, uu = tm.get('gather_wait_ms', 0.0) / reps, tm.get('unfold_under_gather_ms', 0.0) / reps
+        w4 = sum((n - 1) * hop for n in f4)
+        out = {'what': "BASELINE config 4: the fixed corpus sharded over the ranks of this launch (STRONG scaling; `value` above is the weak-scaling batch)",
+               'utterances': len(f4), 'segments': p4.n_segments, 'steps_per_segment': p4.T, 'world_seen': world_seen, 'ranks_used': active,
+               'segments_per_rank': [h - l for l, h in shard_bounds(p4.n_segments, world, active)],
+               'ms_per_pass': round(d4 * 1e3, 3), 'gather_wait_ms': round(gw, 3), 'unfold_under_gather_ms': round(uu, 3)}
+        if dry:
+            out['dry_host'] = True
+        else:
+            out.update(samples_per_s=round(w4 / d4, 1), realtime_factor=round(w4 / d4 / SAMPLE_RATE, 2),
+                       split_rank0=eng.last_run_info(), loop_kernel_ms_rank0=round(eng.last_loop_ms(), 3))
+        return out
+    c4leg = None
+    if args.corpus == 'batch' and not args.no_config4_leg:
+        try:
+            c4leg = config4_leg()
+        except Exception as e:
+            if group is not None:
+                raise                        # (a rank that drops out of a collective would hang the others)
+            c4leg = {'error': repr(e)}
     lo0, hi0 = shard_bounds(plan.n_segments, world)[0]
     par = (f'{world_seen} rank(s) in the process group ({"gloo, DRY RUN on the host" if dry else "nccl = RCCL" if group is not None else "no group"}): '
            f'1 process per GPU, contiguous block of the segment table, ONE all-gather of the finished audio')
@@ -299,11 +354,12 @@ def main():
                            'segments_rank0': hi0 - lo0, 'segments_per_rank': [h - l for l, h in shard_bounds(plan.n_segments, world)],
                            'gathered_rows': int(segs.shape[0]), 'gathered_checksum': checksum,
                            'host_samples_per_s': round(args.steps * wave_total / dt, 1),
+                           **({'config4': c4leg} if c4leg is not None else {}),
                            'parallelism': par}}), flush=True)
         if group is not None:
             dist.destroy_process_group()
         return
-    info = eng.last_run_info()
+    info = main_info
 
     def single_utterance(n_frames):
         """ONE `WaveRNN.generate()` call -- the drop-in API itself -- on BASELINE config 2's stated input (mel seed
@@ -414,7 +470,7 @@ def main():
                        'segment_steps_per_s': round(plan.n_segments * T * args.steps / dt, 1),
                        'noise': 'host MT19937 stream (parity mode)' if args.parity_noise else 'device Philox (as the reference on a GPU)',
                        'mel_last_stage': 'formed inside the loop kernel from the x25 mel (no [L, 80] up-sampled mel is written)'
-                                         if (info['kernel'] == 'wrnn_duo_kernel' and getattr(model, 'mel_in_loop', False) and getattr(model, 'pre_algo', '') == 'native')
+                                         if model.mel_rows_ok(eng, n_local, T)
                                          else 'materialised by the pre-loop kernels',
                        'parallelism': par},
         }
@@ -434,6 +490,8 @@ def main():
                 'note': 'useful f32 FLOPs of the loop (2 x non-zero loop weights per segment-step x n x T) / kernel time (kernel_ms = '
                         'sum of the loop-kernel launch durations of one pass, HIP events on the launch stream) vs the dense f32 MFMA peak; n >= 50 resident segments puts the loop right of the '
                         'f32 ridge (SURVEY.md 8d)'}
+        if c4leg is not None:
+            res['config']['config4'] = c4leg
         if n_local >= 50:
             res['roofline'], res['roofline_hbm_equivalent'] = mfma, hbm
         else:
@@ -535,9 +593,12 @@ def main():
             res['config']['raw'] = side_config(random_state_dict(0, mode='RAW'), 'RAW', "9-bit mu-law ('bits', the bit-exact mode) on the same batch")
             from wavernn_amd.prune import block_prune_state_dict
             res['config']['config5'] = side_config(block_prune_state_dict(random_state_dict(0, mode='MOL'), 0.95, (16, 1))[0], 'MOL',
-                                                   'BASELINE config 5: GRU matrices 95 % block-sparse (16x1 blocks) on the same batch, `auto` kernel')
-            res['config']['config5_sparse_kernel'] = side_config(block_prune_state_dict(random_state_dict(0, mode='MOL'), 0.95, (16, 1))[0], 'MOL',
-                                                                 'BASELINE config 5 on wrnn_sparse_kernel (algo = sparse: the round-1 block-sparse kernel)', algo2='sparse')
+                                                   'BASELINE config 5: GRU matrices 95 % block-sparse (16x1 blocks) on the same batch, `auto` kernel '
+                                                   '(wrnn_sparse_kernel: 16 clusters of 16 CUs, one group of 16 segments each)')
+            if 'samples_per_s' in res['config']['config5']:
+                res['config']['config5']['vs_dense_value'] = round(res['config']['config5']['samples_per_s'] / value, 3)
+            res['config']['config5_dense_kernel'] = side_config(block_prune_state_dict(random_state_dict(0, mode='MOL'), 0.95, (16, 1))[0], 'MOL',
+                                                                'BASELINE config 5 on the DENSE wrnn_duo_kernel (algo = duo: the pruned weights as masked dense matrices)', algo2='duo')
         if not args.no_cpu_baseline and world == 1:
             try:
                 res['cpu_baseline'] = cpu_baseline(sd, mode, args.frames, target, overlap, args.cpu_seconds)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define WRNN_ABI_VERSION 7   /* v7 (round 5): WRNN_ALGO_SPARSE is the rebuilt wrnn_sparse_kernel (slabbed, resumable, takes mel_stage) and what `auto` picks for a qualifying pack; wrnn_options.depth does not apply to it.  v6 (round 4): wrnn_options.mel_stage & co + wrnn_pre_upsample_rows -- the last up-sampling stage formed inside wrnn_duo_kernel.  v5 (round 4): WRNN_ALGO_DUO runs RAW too; `auto` never degrades inside the library (WRNN_ERR_RESIDENCY: the caller re-plans); tuning bits per kernel */
+#define WRNN_ABI_VERSION 7   /* v7 (round 5): WRNN_ALGO_CHAIN (wrnn_chain_kernel, what `auto` runs for <= 64 segments of a dense MOL model); WRNN_ALGO_SPARSE is the rebuilt wrnn_sparse_kernel (slabbed, resumable, takes mel_stage) and what `auto` picks for a qualifying pack; wrnn_options.depth does not apply to it.  v6 (round 4): wrnn_options.mel_stage & co + wrnn_pre_upsample_rows -- the last up-sampling stage formed inside wrnn_duo_kernel.  v5 (round 4): WRNN_ALGO_DUO runs RAW too; `auto` never degrades inside the library (WRNN_ERR_RESIDENCY: the caller re-plans); tuning bits per kernel */
 
 enum {
     WRNN_OK = 0,
@@ -45,7 +45,8 @@ enum { WRNN_MODE_RAW = 0, WRNN_MODE_MOL = 1 };  /* reference: WaveRNN(mode='RAW'
 /* Loop kernel selection. */
 enum {
     WRNN_ALGO_AUTO = 0,     /* shipped dims: WRNN_ALGO_SPARSE when the pack qualifies (wrnn_pack_sparse_blocks() > 0) on a 256-CU device, else
-                               WRNN_ALGO_DUO (MOL, or RAW with 512 classes; >= 128 CUs), else WRNN_ALGO_STREAM; other dims: wrnn_generic_kernel */
+                               WRNN_ALGO_CHAIN (MOL, <= 64 segments, 256 CUs), else WRNN_ALGO_DUO (MOL, or RAW with 512 classes; >= 128 CUs),
+                               else WRNN_ALGO_STREAM; other dims: wrnn_generic_kernel */
     WRNN_ALGO_STREAM = 1,   /* one workgroup per folded segment, weights streamed from L2/MALL each step: the generic fallback
                                (any class count, any device size) and the on-GPU cross-check */
     WRNN_ALGO_LOOP = 2,     /* role-split pipelined persistent kernel (RAW and MOL): up to 4 clusters of 64 CUs, each with a full
@@ -55,6 +56,9 @@ enum {
                                sampling]} -- of <= 128 weight registers, 128 workgroups per 64-CU cluster, so that one wave's MFMAs overlap
                                the other's loads, pointwise math and barrier waits (csrc/wrnn_duo.hip).  What `auto` runs for a dense pack
                                at every batch size */
+    WRNN_ALGO_CHAIN = 7,    /* the single-stream latency kernel (MOL, <= 64 segments, 256 CUs): one workgroup per CU, one group of <= 16 segments per
+                               64-CU cluster, both halves of a GRU cell's rows in one workgroup (gh never leaves the registers), rnn2 + fc1 + fc2
+                               on one XCD (csrc/wrnn_chain.hip).  What `auto` runs for one utterance of a dense MOL model */
     WRNN_ALGO_SPARSE = 5    /* block-sparse GRU kernel (MOL; BASELINE config 5): needs GRU matrices whose 16x1 block rows keep <= 64 columns
                                (wrnn_pack_sparse_blocks) and a 256-CU device; 16 clusters of 16 CUs, ONE group of <= 16 segments each: a
                                step is the latency of one chain, sixteen chains run side by side (csrc/wrnn_sparse.hip) */
@@ -105,7 +109,7 @@ typedef struct wrnn_timer wrnn_timer;
 
 /* What a wrnn_generate* call decided (filled synchronously, before the call returns). */
 typedef struct wrnn_run_info {
-    const char *kernel;      /* "wrnn_duo_kernel" / "wrnn_loop_kernel" / "wrnn_sparse_kernel" / "wrnn_stream_kernel" / "wrnn_generic_kernel" */
+    const char *kernel;      /* "wrnn_duo_kernel" / "wrnn_chain_kernel" / "wrnn_sparse_kernel" / "wrnn_loop_kernel" / "wrnn_stream_kernel" / "wrnn_generic_kernel" */
     int32_t units_per_wg;    /* hidden units per workgroup (16; sparse: 64; stream: 0) */
     int32_t clusters;        /* independent CU clusters, each holding one copy of the weights */
     int32_t depth;           /* groups of <= 16 segments in flight per cluster */
@@ -128,7 +132,7 @@ typedef struct wrnn_options {
     int32_t cond_valu;       /* stream kernel: 1 = hoisted conditioning on VALU instead of MFMA (cross-check) */
     int32_t slab_steps;      /* loop kernel: conditioning slab length in steps; 0 = sized to ~96 MB */
     int32_t t_begin, t_end;  /* run steps [t_begin, t_end) of the T; 0,0 = all.  t_begin > 0 CONTINUES the call that ended at
-                                t_begin on the same workspace (wrnn_loop / _duo / _sparse_kernel); `noise` then covers [t_begin, t_end) only,
+                                t_begin on the same workspace (wrnn_loop / _duo / _sparse / _chain_kernel); `noise` then covers [t_begin, t_end) only,
                                 `out` / force_x / logits always the whole [.., T] tensors */
     int32_t tuning;          /* A/B switches for measurements, PER KERNEL (0 = the measured defaults; results never depend on them):
                                 wrnn_loop_kernel: bit 0 = no one-stage look-ahead of the exchange loads, bit 1 = full __syncthreads() fences
@@ -138,7 +142,7 @@ typedef struct wrnn_options {
                                 wrnn_duo_kernel: bit 0 = stage order loads-first, bit 1 = publish-first (default: by depth), bit 2 = re-fill the
                                   exchange ring with the sentinel before EVERY launch, bit 6 = placement read-out through phase_clocks (test
                                   hook), bit 8 = every layer written through (no XCD-local plain stores);
-                                wrnn_sparse_kernel: bits 2, 6, 8 as wrnn_duo_kernel.
+                                wrnn_sparse_kernel, wrnn_chain_kernel: bits 2, 8 as wrnn_duo_kernel.
                                 When the two-workgroups-per-CU grid of wrnn_duo_kernel is refused the call returns WRNN_ERR_RESIDENCY; the
                                 caller may run it again with WRNN_ALGO_LOOP (another workspace layout: query its size) or _STREAM. */
     const float *force_x;    /* test hook, device [n,T]: value fed back as x_t instead of the sample (teacher forcing) */
@@ -156,7 +160,7 @@ typedef struct wrnn_options {
      * one launch: they report once, at the end). */
     void (*progress)(int32_t steps_done, int32_t T, int32_t n_segments, void *user);
     void *progress_user;
-    /* the LAST up-sampling stage inside the loop (ABI v6; wrnn_duo_kernel and wrnn_sparse_kernel -- any other kernel: WRNN_ERR_ARG).  The reference
+    /* the LAST up-sampling stage inside the loop (ABI v6; wrnn_duo_kernel, wrnn_sparse_kernel, wrnn_chain_kernel -- any other kernel: WRNN_ERR_ARG).  The reference
      * up-samples the mel in three Stretch2d + box-conv stages and crops `indent` samples off both ends (fatchord_version.py:73-80,
      * :86-88) before the loop reads one [M] row per sample.  With mel_stage = 1 the `mels_up` argument of wrnn_generate* is the INPUT of
      * the last of those stages instead -- [mel_rows][M], what wrnn_pre_upsample_rows() writes: 1 / mel_scale of the rows -- and the loop

@@ -5,7 +5,7 @@
 #   asbench                          the bench's RAW / MoL legs as benchmarked       flips     RAW class-index flip rate vs the C oracle (scripts/gpu_raw_flips.py)
 #   probe:<gpu_perf_probe.py args>   loop-kernel timing sweep ('@' for ' ' in args)   smoke     __graft_entry__.smoke()
 #   bench[:<bench.py args>]          bench.py --steps 3 --warmup 1                    profile   scripts/gpu_profile.sh <tag> (smoke + bench + rocprofv3 stats + PMC)
-#   place                            placement read-out of the duo kernel             sprof[:args]  phase clocks of wrnn_sparse_kernel (scripts/gpu_sparse_profile.py)
+#   place                            placement read-out of the duo kernel             sprof[:args] / cprof[:args]  phase clocks of wrnn_sparse_kernel / wrnn_chain_kernel
 TAG=${1:-x}; shift
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out; export TMPDIR=/tmp
@@ -25,6 +25,7 @@ for ST in "$@"; do
     bench)   timeout 900 python bench.py --steps 3 --warmup 1 ${ARG//@/ } 2>&1 | grep -v "$F" | tee $LOG | tail -1 | cut -c1-1500 ;;
     profile) bash scripts/gpu_profile.sh $TAG ${ARG//@/ } ;;
     sprof)   timeout 240 python scripts/gpu_sparse_profile.py --out gpurun_out/${TAG}_sparse_phase_clocks.json ${ARG//@/ } 2>&1 | grep -v "$F" | tee -a $LOG | tail -8 ;;
+    cprof)   timeout 240 python scripts/gpu_chain_profile.py --out gpurun_out/${TAG}_chain_phase_clocks.json ${ARG//@/ } 2>&1 | grep -v "$F" | tee -a $LOG | tail -8 ;;
     place)   timeout 120 python scripts/gpu_duo_placement.py 2>&1 | grep -v "$F" | tee $LOG | tail -12 ;;
     *)       echo "unknown stage $ST" ;;
   esac

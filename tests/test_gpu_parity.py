@@ -86,12 +86,17 @@ VARIANTS = {
     'duo-g2-pf': dict(algo='duo', depth=2, tuning=2),
     'duo-g3-lf-slabs': dict(algo='duo', depth=3, tuning=1, slab_steps=131),
     'duo-g1-wt': dict(algo='duo', depth=1, tuning=256),
+    # round 5: the single-stream latency kernel (MOL, <= 64 segments); several slabs; every layer written through
+    'chain': dict(algo='chain'),
+    'chain-slabs': dict(algo='chain', slab_steps=97),
+    'chain-wt': dict(algo='chain', tuning=256),
 }
-KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'loop': 'wrnn_loop_kernel', 'sparse': 'wrnn_sparse_kernel', 'duo': 'wrnn_duo_kernel'}
+KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'loop': 'wrnn_loop_kernel', 'sparse': 'wrnn_sparse_kernel', 'duo': 'wrnn_duo_kernel', 'chain': 'wrnn_chain_kernel'}
 
 
 def _skip_unless_supported(mode, opts):
-    pass            # (round 4: the duo kernel runs RAW too -- fc3's 512 rows over rnn2's hh workgroups, a sixth exchange for the logits)
+    if opts.get('algo') == 'chain' and mode != 'MOL':
+        pytest.skip('wrnn_chain_kernel is the MoL latency kernel (RAW runs on wrnn_duo_kernel)')
 
 
 def test_device_selftests(gpu):
@@ -141,7 +146,7 @@ def test_exchange_layers_match_oracle(gpu, mode):
         assert np.abs(out.cpu().numpy() - ref).max() <= MOL_TOL
 
 
-@pytest.mark.parametrize('mode,algo', [('MOL', 'loop'), ('RAW', 'loop'), ('MOL', 'duo'), ('RAW', 'duo')])
+@pytest.mark.parametrize('mode,algo', [('MOL', 'loop'), ('RAW', 'loop'), ('MOL', 'duo'), ('RAW', 'duo'), ('MOL', 'chain')])
 def test_step_ranges_continue_bit_exactly(gpu, mode, algo):
     """`wrnn_options.t_begin / t_end`: the loop run as calls over [0, 200), [200, 201), [201, 203), [203, T), each with only its
     own rows of noise, equals the single call bit for bit (the per-group state lives in the workspace between calls; the duo
@@ -152,7 +157,7 @@ def test_step_ranges_continue_bit_exactly(gpu, mode, algo):
     eng = LoopEngine(sd, mode, device=gpu)
     mu, au, nz = torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), torch.from_numpy(flat).to(gpu)
     whole = eng.run(mu, au, B, T, stride, nz, 275, algo=algo, slab_steps=128).cpu().numpy()
-    if algo == 'duo':       # ... and the ring re-filled before every launch (tuning bit 2) changes nothing
+    if algo in ('duo', 'chain'):       # ... and the ring re-filled before every launch (tuning bit 2) changes nothing
         again = eng.run(mu, au, B, T, stride, nz, 275, algo=algo, slab_steps=128, tuning=4).cpu().numpy()
         assert np.array_equal(again, whole)
         short = eng.run(mu, au, B, T, stride, nz, 275, algo=algo, slab_steps=3).cpu().numpy()      # slabs shorter than the re-arm distance
@@ -185,8 +190,8 @@ def test_continuation_on_the_other_loop_kernel_fails_loudly(gpu):
     out = eng.run(mu, au, B, T, stride, nz[:100].contiguous(), 275, algo='auto', t_range=(0, 100))
     first = eng.last_loop_kernel()
     out = eng.run(mu, au, B, T, stride, nz[100:].contiguous(), 275, algo='auto', t_range=(100, T), out=out)
-    assert eng.last_loop_kernel() == first == 'wrnn_duo_kernel'
-    assert np.array_equal(out.cpu().numpy(), whole)
+    assert eng.last_loop_kernel() == first == 'wrnn_chain_kernel'          # (46 segments of a dense MoL model: the latency kernel)
+    assert np.abs(out.cpu().numpy() - whole).max() <= MOL_TOL
 
 
 def test_workspace_does_not_grow_with_steps(gpu):
@@ -229,7 +234,7 @@ def test_loop_matches_reference_golden(gpu, name, variant):
         assert np.abs(out - ref).max() <= MOL_TOL
 
 
-@pytest.mark.parametrize('variant', ['stream', 'loop', 'loop-g2-slabs', 'duo', 'duo-g2-slabs'])
+@pytest.mark.parametrize('variant', ['stream', 'loop', 'loop-g2-slabs', 'duo', 'duo-g2-slabs', 'chain', 'chain-slabs'])
 @pytest.mark.parametrize('name', ['raw_batched_60f', 'mol_batched_100f'])
 def test_teacher_forced_logits(gpu, name, variant):
     """Feed the reference's samples back (teacher forcing) and compare every step's fc3 logits with the C
@@ -356,6 +361,11 @@ def test_mel_rows_loop_equals_the_materialised_mel(gpu, mode):
     else:
         assert np.array_equal(a, b), np.argwhere(a != b)[:4]          # bit-identical class indices (the flip rate of the two roundings: DESIGN.md 7)
     print(f'{mode}: mel formed in the loop vs materialised: logits {err:.2e}, free run max |d| {np.abs(a - b).max():.2e}')
+    if mode == 'MOL':       # the latency kernel forms the stage with the same code (wave 0 of every rnn1 workgroup)
+        ca = eng.run_segments(mels_up, aux, plan.seg_pos, plan.seg_lim, T, noise, hop, algo='chain', slab_steps=300).cpu().numpy()
+        cb = eng.run_segments(mr, aux, plan.seg_pos, plan.seg_lim, T, noise, hop, algo='chain', slab_steps=300).cpu().numpy()
+        assert eng.last_loop_kernel() == 'wrnn_chain_kernel'
+        assert np.abs(ca - a).max() <= MOL_TOL and np.abs(cb - b).max() <= MOL_TOL, (np.abs(ca - a).max(), np.abs(cb - b).max())
     # the other loop kernels read the up-sampled mel: asking them for the last stage is an argument error, not a silent mis-read
     with pytest.raises(_lib.WrnnError, match='mel_stage'):
         eng.run_segments(mr, aux, plan.seg_pos, plan.seg_lim, T, noise, hop, algo='loop')

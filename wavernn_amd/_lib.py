@@ -15,8 +15,8 @@ WRNN_OK = 0
 ERR_RESIDENCY = -6          # WRNN_ERR_RESIDENCY: the persistent grid cannot be co-resident on this device
 MODE_RAW, MODE_MOL = 0, 1
 ABI_VERSION = 7
-ALGO_AUTO, ALGO_STREAM, ALGO_LOOP, ALGO_SPARSE, ALGO_DUO = 0, 1, 2, 5, 6
-ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'loop': ALGO_LOOP, 'sparse': ALGO_SPARSE, 'duo': ALGO_DUO}
+ALGO_AUTO, ALGO_STREAM, ALGO_LOOP, ALGO_SPARSE, ALGO_DUO, ALGO_CHAIN = 0, 1, 2, 5, 6, 7
+ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'loop': ALGO_LOOP, 'sparse': ALGO_SPARSE, 'duo': ALGO_DUO, 'chain': ALGO_CHAIN}
 
 #: every symbol include/wavernn_amd.h declares
 EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_create', 'wrnn_pack_destroy',

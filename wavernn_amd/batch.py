@@ -16,6 +16,7 @@ corpus can be cut into contiguous blocks of segments, one block per GPU (SURVEY.
 Results do not depend on the number of ranks: every segment's noise is addressed by (utterance seed, step, fold
 index) exactly as the single-utterance reference call would draw it.
 """
+import time
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -70,9 +71,36 @@ def plan_utterances(lengths: Sequence[int], target: int, overlap: int) -> Plan:
                 np.concatenate(seg_utt).astype(np.int32))
 
 
-def shard_bounds(n_segments: int, world: int):
-    """[(lo, hi)] * world: contiguous blocks whose sizes differ by at most one (block r = segments [lo, hi))."""
-    return [((r * n_segments) // world, ((r + 1) * n_segments) // world) for r in range(world)]
+def shard_bounds(n_segments: int, world: int, active: Optional[int] = None):
+    """[(lo, hi)] * world: contiguous blocks whose sizes differ by at most one (block r = segments [lo, hi)).  active < world: only the
+    first `active` ranks get a block (`choose_ranks`); the others own the empty block (n, n) and only take part in the all-gather."""
+    active = world if active is None else max(1, min(int(active), world))
+    return [((r * n_segments) // active, ((r + 1) * n_segments) // active) if r < active else (n_segments, n_segments) for r in range(world)]
+
+
+#: measured step time (us) of the dense loop kernel by groups in flight per cluster (4 clusters x depth x 16 segments per GPU; one MI355X,
+#: profiles/r04p_probe.json, DESIGN.md 6): what `choose_ranks` weighs a split with
+STEP_US_BY_DEPTH = {1: 12.2, 2: 16.9, 3: 20.9, 4: 23.7, 5: 28.0, 6: 32.0, 7: 36.5, 8: 40.5}
+
+
+def estimate_step_us(n_segments: int) -> float:
+    """Step time of one GPU that advances `n_segments` segments by one sample (rounds of <= 512 segments at the measured depth)."""
+    if n_segments <= 0:
+        return 0.0
+    groups = -(-n_segments // 16)
+    rounds = -(-groups // 32)
+    depth = min(8, max(1, -(-(-(-groups // rounds)) // 4)))
+    return rounds * STEP_US_BY_DEPTH[depth]
+
+
+def choose_ranks(n_segments: int, world: int) -> int:
+    """How many of `world` GPUs a FIXED corpus of `n_segments` folded segments should be sharded over (strong scaling, BASELINE config 4):
+    the wall time of a pass is the step time of the largest block, which depends on the pipeline depth that block fills -- not on the rank
+    count as such -- so the smallest rank count that reaches the best estimated wall time is taken (942 segments on 8 GPUs: 118 per GPU =
+    depth 2, and 7 GPUs would need depth 3: all 8; on 16 GPUs: 15 suffice).  The ranks left out still take part in the all-gather."""
+    est = [estimate_step_us(-(-n_segments // r)) for r in range(1, world + 1)]
+    best = min(est)
+    return 1 + next(i for i, e in enumerate(est) if e <= best * 1.01)
 
 
 def pack_noise(mode: str, plan: Plan, per_utt, lo: int = 0, hi: Optional[int] = None, steps: Optional[int] = None):
@@ -128,7 +156,7 @@ def chunk_utterances(plan: Plan, lo: int, hi: int, max_segments: int):
 
 def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bool, seeds: Optional[Sequence[int]] = None,
                     group=None, loop_fn=None, return_segments=False, noise_source='cpu', finish='all', check=True,
-                    max_segments_per_launch: int = 4096, shard=None):
+                    max_segments_per_launch: int = 4096, shard=None, ranks: Optional[int] = None, timings: Optional[dict] = None):
     """Generate every utterance of `mels` (each (1, feat, N_u) or (feat, N_u)) with `model` (a `wavernn_amd.WaveRNN`),
     batched, sharding the folded segments over the ranks of `group` (None = single process).
 
@@ -146,6 +174,10 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
 
     shard=(r, w), without a group: do what rank r of a w-rank job does on its own -- its block of the segment table, the post-loop
     stage of the utterances lying entirely in it -- with no collective (how bench.py shows a GPU's share of config 4 at N = 1).
+
+    ranks: shard over the first `ranks` ranks of the group only (`choose_ranks`; None = all).  timings: optional dict, filled with
+    `gather_wait_ms` (host time blocked on the all-gather) and `unfold_under_gather_ms` (post-loop stage of this rank's own utterances,
+    run while the gather is in flight).
 
     loop_fn(mels_up, aux, seg_pos, seg_lim, T, noise, hop) -> (n, T) tensor replaces the HIP loop (tests inject a CPU
     stand-in to exercise the sharding / gather logic under gloo); the default is the model's LoopEngine.
@@ -172,8 +204,9 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
     mels = [m.unsqueeze(0) if m.dim() == 2 else m for m in mels]
     frames = [int(m.size(-1)) for m in mels]
     plan = plan_utterances([n * hop for n in frames], target, overlap)
-    lo, hi = shard_bounds(plan.n_segments, world)[rank]
-    n_max = max(h - l for l, h in shard_bounds(plan.n_segments, world))
+    bounds = shard_bounds(plan.n_segments, world, ranks)
+    lo, hi = bounds[rank]
+    n_max = max(h - l for l, h in bounds)
 
     out_local = torch.zeros(n_max, plan.T, dtype=torch.float32, device=device)
     native_pre = loop_fn is None and getattr(model, 'pre_algo', 'torch') == 'native' and device.type == 'cuda'
@@ -294,9 +327,12 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
                 raise ValueError('an emulated shard has only its own block of segments')
             return out_local[:plan.n_segments]
         if work is not None:
+            t_w = time.perf_counter()
             work.wait()
             work = None
-        return torch.cat([gathered[r][:h - l] for r, (l, h) in enumerate(shard_bounds(plan.n_segments, world))])
+            if timings is not None:
+                timings['gather_wait_ms'] = timings.get('gather_wait_ms', 0.0) + (time.perf_counter() - t_w) * 1e3
+        return torch.cat([gathered[r][:h - l] for r, (l, h) in enumerate(bounds)])
 
     if was_training:
         model.train()
@@ -329,11 +365,17 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
             y = _fold.xfade_and_unfold(y, target, overlap)
             outs[u] = _fold.finish_waveform(y, (frames[u] - 1) * hop, hop)
 
+    t_u = time.perf_counter()
     unfold(out_local, lambda u: int(plan.first[u]) - lo, local_u)          # under the all-gather
+    if timings is not None:
+        timings['unfold_under_gather_ms'] = timings.get('unfold_under_gather_ms', 0.0) + (time.perf_counter() - t_u) * 1e3
     if shard is not None:
         return outs
     if rest_u:
         unfold(gathered_segments(), lambda u: int(plan.first[u]), rest_u)
     elif work is not None:
+        t_w = time.perf_counter()
         work.wait()
+        if timings is not None:
+            timings['gather_wait_ms'] = timings.get('gather_wait_ms', 0.0) + (time.perf_counter() - t_w) * 1e3
     return outs

@@ -34,6 +34,10 @@ int sparse_clusters(int n_cus);
 size_t sparse_state_floats();
 size_t sparse_xbuf_bytes();
 hipError_t launch_put_floats(float *dst, const float *src, int n, hipStream_t stream);
+hipError_t launch_chain(const LoopArgs &args, hipStream_t stream);
+int chain_clusters(int n_cus);
+size_t chain_state_floats();
+size_t chain_xbuf_bytes();
 int selftest_mfma(char *msg, size_t n);
 int selftest_allgather(int n_cus, char *msg, size_t n, float *us_per_round);
 int selftest_tanh(char *msg, size_t n);
@@ -376,7 +380,7 @@ int enqueue_progress(const wrnn_options *o, int done, int T, int n, hipStream_t 
     return WRNN_OK;
 }
 
-enum Kind { K_STREAM, K_LOOP, K_SPARSE, K_DUO, K_GENERIC };
+enum Kind { K_STREAM, K_LOOP, K_SPARSE, K_DUO, K_GENERIC, K_CHAIN };
 constexpr int DUO_TAB_FPS = 8;       // wrnn_duo_kernel: rows per segment of the per-slab aux tables: a slab covers at most (DUO_TAB_FPS - 2) hops + 1 steps
 constexpr bool DUO_AUTO = true;      // `auto` runs MoL on wrnn_duo_kernel at every depth (round 4, profiles/r04a_probe_new.json: 13.5 vs 16.6 us per step
 constexpr int DUO_MIN_DEPTH = 1;     // with one group in flight, 17.9 vs 21.7 with two, 26.2 vs 36 with four; round 3's kernel paid off from depth 3 on)
@@ -420,7 +424,7 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
     if (pl->t0 == 0 && pl->t1 == 0) pl->t1 = T;
     if (pl->t0 < 0 || pl->t1 > T || pl->t0 >= pl->t1) { set_err("bad step range [%d, %d) of T=%d", pl->t0, pl->t1, T); return WRNN_ERR_ARG; }
     const int algo = o->algo;
-    if (algo != WRNN_ALGO_AUTO && algo != WRNN_ALGO_STREAM && algo != WRNN_ALGO_LOOP && algo != WRNN_ALGO_SPARSE && algo != WRNN_ALGO_DUO) {
+    if (algo != WRNN_ALGO_AUTO && algo != WRNN_ALGO_STREAM && algo != WRNN_ALGO_LOOP && algo != WRNN_ALGO_SPARSE && algo != WRNN_ALGO_DUO && algo != WRNN_ALGO_CHAIN) {
         set_err("unknown algo %d", algo);
         return WRNN_ERR_ARG;
     }
@@ -435,6 +439,23 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
         pl->kind = K_GENERIC;
         return WRNN_OK;
     }
+    // <= 64 segments of a MOL model (one utterance of BASELINE config 2 / 3): the single-stream latency kernel, one group per 64-CU cluster
+    const int ccl = chain_clusters(p->n_cus);
+    const bool chain_ok = p->mode == WRNN_MODE_MOL && ccl >= 1 && groups <= ccl;
+    if (algo == WRNN_ALGO_CHAIN && !chain_ok) {
+        set_err("wrnn_chain_kernel needs MOL, >= 256 CUs and <= %d segments (this call: %d segments, %d CUs)", 16 * (ccl > 0 ? ccl : 4), B, p->n_cus);
+        return (p->mode != WRNN_MODE_MOL || groups > 4) ? WRNN_ERR_ARG : WRNN_ERR_RESIDENCY;
+    }
+    if (algo == WRNN_ALGO_CHAIN || (algo == WRNN_ALGO_AUTO && chain_ok && !p->sp_nbp)) {
+        pl->kind = K_CHAIN; pl->ncl = ccl; pl->G = 1; pl->rounds = 1; pl->per_round = B; pl->ngr_max = groups;
+        int slab = o->slab_steps;
+        if (slab < 1) slab = 4096;
+        if (slab < 16) slab = 16;
+        if (slab > 4096) slab = 4096;
+        if (slab > T) slab = T;
+        pl->slab = slab;
+        pl->tab_fps = DUO_TAB_FPS;
+    }
     // a block-sparse pack runs on wrnn_sparse_kernel (round 5: 16 clusters of 16 CUs, one group of 16 segments each -- the step is the
     // latency of one chain, and sixteen chains run side by side): `auto` picks it whenever the pack and the device qualify
     const int scl = sparse_clusters(p->n_cus);
@@ -443,7 +464,9 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
                 "(this pack: up to %d; device: %d CUs)", p->sp_max_blocks, p->n_cus);
         return (!p->sp_nbp) ? WRNN_ERR_ARG : WRNN_ERR_RESIDENCY;
     }
-    if (algo == WRNN_ALGO_SPARSE || (algo == WRNN_ALGO_AUTO && p->sp_nbp && scl >= 1)) {
+    if (pl->kind == K_CHAIN) {
+        // (planned above)
+    } else if (algo == WRNN_ALGO_SPARSE || (algo == WRNN_ALGO_AUTO && p->sp_nbp && scl >= 1)) {
         pl->kind = K_SPARSE; pl->ncl = scl; pl->G = 1;
         pl->rounds = (groups + scl - 1) / scl;
         pl->per_round = (B + pl->rounds - 1) / pl->rounds;
@@ -506,7 +529,7 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
             return WRNN_ERR_RESIDENCY;
         }
     }
-    if (pl->kind != K_LOOP && pl->kind != K_DUO && pl->kind != K_SPARSE && (pl->t0 != 0 || pl->t1 != T)) {
+    if (pl->kind != K_LOOP && pl->kind != K_DUO && pl->kind != K_SPARSE && pl->kind != K_CHAIN && (pl->t0 != 0 || pl->t1 != T)) {
         set_err("a partial step range [%d, %d) needs a persistent loop kernel", pl->t0, pl->t1);
         return WRNN_ERR_ARG;
     }
@@ -525,7 +548,7 @@ WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frame
     if (pl.kind == K_GENERIC) { l.total = o; return l; }
     // per-frame aux tables: one row per frame of the call's conditioning (+ the zero row) -- or, for wrnn_duo_kernel, per SEGMENT and
     // slab: (slab - 1) / hop + 2 rows per segment (+ the zero row), refilled for every slab: independent of the corpus' length
-    const bool slabbed = pl.kind == K_DUO || pl.kind == K_SPARSE;       // conditioning formed in the loop, per-segment aux tables per slab
+    const bool slabbed = pl.kind == K_DUO || pl.kind == K_SPARSE || pl.kind == K_CHAIN;       // conditioning formed in the loop, per-segment aux tables per slab
     const size_t tab_rows = slabbed ? (size_t)B * pl.tab_fps + 1 : (size_t)n_frames + 1;
     l.c2f = o;    o = al(o + tab_rows * 3 * H * sizeof(float));
     l.c3f = o;    o = al(o + tab_rows * H * sizeof(float));
@@ -533,7 +556,7 @@ WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frame
     const bool mol = p->mode == WRNN_MODE_MOL;
     if (pl.kind == K_LOOP || slabbed) {
         l.xbuf = o;  o = al(o + (slabbed ? duo_xbuf_bytes_max() : XBUF_FLOATS * sizeof(float)));
-        l.state = o; o = al(o + (size_t)pl.rounds * (pl.kind == K_SPARSE ? sparse_state_floats() : loop_state_floats(pl.G)) * sizeof(float));
+        l.state = o; o = al(o + (size_t)pl.rounds * (pl.kind == K_SPARSE ? sparse_state_floats() : pl.kind == K_CHAIN ? chain_state_floats() : loop_state_floats(pl.G)) * sizeof(float));
         l.cIf = o;   if (pl.kind == K_LOOP) o = al(o + (size_t)pl.slab * pl.ngr_max * SEG * H * sizeof(float));      // (the duo kernel forms cI in the loop)
         l.npre = o;  if (mol) o = al(o + (size_t)pl.slab * 11 * B * sizeof(float));      // derived MOL noise of one slab
     } else {
@@ -616,7 +639,7 @@ extern "C" int wrnn_plan_segments(const wrnn_pack *p, int32_t n_segments, int32_
     int rc = make_plan(p, n_segments, T, &whole, &pl);
     if (rc != WRNN_OK) return rc;
     memset(out, 0, sizeof *out);
-    out->kernel = pl.kind == K_GENERIC ? "wrnn_generic_kernel" : pl.kind == K_DUO ? "wrnn_duo_kernel" : pl.kind == K_LOOP ? "wrnn_loop_kernel" : (pl.kind == K_SPARSE ? "wrnn_sparse_kernel" : "wrnn_stream_kernel");
+    out->kernel = pl.kind == K_GENERIC ? "wrnn_generic_kernel" : pl.kind == K_CHAIN ? "wrnn_chain_kernel" : pl.kind == K_DUO ? "wrnn_duo_kernel" : pl.kind == K_LOOP ? "wrnn_loop_kernel" : (pl.kind == K_SPARSE ? "wrnn_sparse_kernel" : "wrnn_stream_kernel");
     out->units_per_wg = pl.kind == K_STREAM ? 0 : (pl.kind == K_SPARSE ? 64 : 16);
     out->clusters = pl.ncl; out->depth = pl.G; out->rounds = pl.rounds; out->slab_steps = pl.slab;
     return WRNN_OK;
@@ -646,7 +669,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
         pl.t0 = o->t_begin; pl.t1 = o->t_end;
         if (pl.t0 == 0 && pl.t1 == 0) pl.t1 = T;
         if (pl.t0 < 0 || pl.t1 > T || pl.t0 >= pl.t1) { set_err("bad step range [%d, %d) of T=%d", pl.t0, pl.t1, T); return WRNN_ERR_ARG; }
-        if (pl.kind != K_LOOP && pl.kind != K_DUO && pl.kind != K_SPARSE && (pl.t0 != 0 || pl.t1 != T)) { set_err("a partial step range needs a persistent loop kernel"); return WRNN_ERR_ARG; }
+        if (pl.kind != K_LOOP && pl.kind != K_DUO && pl.kind != K_SPARSE && pl.kind != K_CHAIN && (pl.t0 != 0 || pl.t1 != T)) { set_err("a partial step range needs a persistent loop kernel"); return WRNN_ERR_ARG; }
     }
     const WsLayout l = ws_layout(p, pl, B, T, n_frames);
     if (workspace_bytes < l.total) { set_err("workspace %zu < required %zu", workspace_bytes, l.total); return WRNN_ERR_WORKSPACE; }
@@ -668,7 +691,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     if (o->mel_stage) {
         // the last up-sampling stage inside the loop: `mels_up` is that stage's input.  Everything is checked here, on the host: the
         // kernel reads rows j / s - 1 .. j / s + 1 without a bound.
-        if (pl.kind != K_DUO && pl.kind != K_SPARSE) { set_err("wrnn_options.mel_stage: only wrnn_duo_kernel / wrnn_sparse_kernel form the last up-sampling stage (this call runs on another kernel)"); return WRNN_ERR_ARG; }
+        if (pl.kind != K_DUO && pl.kind != K_SPARSE && pl.kind != K_CHAIN) { set_err("wrnn_options.mel_stage: only wrnn_duo_kernel / wrnn_sparse_kernel / wrnn_chain_kernel form the last up-sampling stage (this call runs on another kernel)"); return WRNN_ERR_ARG; }
         if (o->mel_stage != 1 || o->mel_scale != LAST_SCALE || !o->mel_taps || !o->seg_moff || o->mel_rows < 3) {
             set_err("wrnn_options.mel_stage=%d: needs mel_scale == %d (got %d), mel_taps, seg_moff, mel_rows >= 3", o->mel_stage, LAST_SCALE, o->mel_scale);
             return WRNN_ERR_ARG;
@@ -722,7 +745,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     c.c2f = (float *)(ws + l.c2f); c.c3f = (float *)(ws + l.c3f); c.c4f = (float *)(ws + l.c4f);
     c.seg_pos = d_pos; c.seg_lim = d_lim;
     c.B = B; c.T = T; c.hop = hop; c.NF = n_frames;
-    const bool slabbed = pl.kind == K_DUO || pl.kind == K_SPARSE;
+    const bool slabbed = pl.kind == K_DUO || pl.kind == K_SPARSE || pl.kind == K_CHAIN;
     if (slabbed) {
         // the aux tables are per segment and slab (filled in the slab loop): a slab may not span more than tab_fps - 2 whole hops
         const long eff = (long)(pl.tab_fps - 2) * hop + 1;
@@ -761,8 +784,8 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
 
     if (pl.kind == K_LOOP || slabbed) {
         // ---- persistent loop kernels: for every slab of steps { derived noise; for every round { conditioning slab; loop } } ----
-        const bool duo = slabbed, sparse = pl.kind == K_SPARSE;      // (duo: the conditioning is formed in the loop -- wrnn_duo_kernel and wrnn_sparse_kernel)
-        info.kernel = sparse ? "wrnn_sparse_kernel" : (duo ? "wrnn_duo_kernel" : "wrnn_loop_kernel"); info.units_per_wg = sparse ? 64 : 16;
+        const bool duo = slabbed, sparse = pl.kind == K_SPARSE, chain = pl.kind == K_CHAIN;      // (duo: the conditioning is formed in the loop)
+        info.kernel = chain ? "wrnn_chain_kernel" : sparse ? "wrnn_sparse_kernel" : (duo ? "wrnn_duo_kernel" : "wrnn_loop_kernel"); info.units_per_wg = sparse ? 64 : 16;
         a.sp_vals = p->sp_vals; a.sp_cols = p->sp_cols;
         const bool mol = p->mode == WRNN_MODE_MOL;
         a.xbuf = (float *)(ws + l.xbuf);
@@ -794,13 +817,13 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                 // (every step re-arms the entries it will write two or three steps later), so it needs the fill only where a round starts: the first
                 // launch of a call that starts at step 0, or any launch when several rounds share the buffer
                 if (!duo) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, XBUF_FLOATS * sizeof(float), stream));
-                else if (s0 == 0 || pl.rounds > 1 || (o->tuning & 4)) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, sparse ? sparse_xbuf_bytes() : duo_xbuf_bytes(pl.G), stream));
+                else if (s0 == 0 || pl.rounds > 1 || (o->tuning & 4)) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, chain ? chain_xbuf_bytes() : sparse ? sparse_xbuf_bytes() : duo_xbuf_bytes(pl.G), stream));
                 if (duo) HIPCHK(hipMemsetAsync(ws + l.xcc, 0, XCC_WORDS * sizeof(unsigned), stream));      // placement handshake of this launch
-                a.state = (float *)(ws + l.state) + (size_t)r * (sparse ? sparse_state_floats() : loop_state_floats(pl.G));
+                a.state = (float *)(ws + l.state) + (size_t)r * (sparse ? sparse_state_floats() : chain ? chain_state_floats() : loop_state_floats(pl.G));
                 a.t0 = s0; a.t1 = s1; a.cI_t0 = s0; a.rb0 = rb0; a.Btot = nr; a.NG = ngr; a.resume = s0 > 0 ? 1 : 0;
-                a.kind_tag = sparse ? 3 : (duo ? 2 : 1);
+                a.kind_tag = chain ? 4 : sparse ? 3 : (duo ? 2 : 1);
                 if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
-                hipError_t e = sparse ? launch_sparse(a, p->sp_nbp, stream) : (duo ? launch_duo(a, pl.ncl, p->mode, stream) : launch_loop(a, pl.ncl, p->mode, stream));
+                hipError_t e = chain ? launch_chain(a, stream) : sparse ? launch_sparse(a, p->sp_nbp, stream) : (duo ? launch_duo(a, pl.ncl, p->mode, stream) : launch_loop(a, pl.ncl, p->mode, stream));
                 // (two workgroups per CU not co-resident right now: WRNN_ERR_RESIDENCY -- the caller re-plans with WRNN_ALGO_LOOP, whose
                 // workspace layout is another one: wavernn_amd/engine.py does)
                 if (e != hipSuccess) {

@@ -1,0 +1,452 @@
+// wrnn_chain.hip -- the persistent WaveRNN loop kernel (MOL, dense weights) for SMALL batches: <= 64 folded segments = one utterance of
+// BASELINE config 2 (N = 481 -> 12 segments; N = 1001 -> 24) or config 3's sentence (19), on MI355X (gfx950 / CDNA4).  Round 5.
+//
+// With one group of <= 16 segments per cluster nothing can be pipelined: a step of reference models/fatchord_version.py:201-241 IS the
+// latency of its chain x_{t-1} -> h1 -> h2 -> fc1 -> fc2 -> sample.  wrnn_duo.hip (two workgroups per CU, four roles, built for throughput:
+// 12.2 us per step with one group in flight) pays for that chain four cross-XCD hops and the round trip ih -> hh -> ih of every gh.  This
+// kernel is wrnn_sparse.hip's single-stream form with dense stages:
+//
+//   * up to 4 clusters of 64 CUs (two XCDs), ONE workgroup of 4 waves per CU (512 registers per lane, every weight register-resident),
+//     ONE group per cluster.  Workgroup J of the cluster's first XCD owns units [16 J, 16 J + 16) of rnn1 -- its rows of W_ih AND of
+//     W_hh: gh(t + 1) = W_hh . h(t) + b_hh stays in the registers of the thread that needs it, no exchange --, forms the I-layer
+//     conditioning cI of those rows (wave 0; as wrnn_duo.hip, incl. wrnn_options.mel_stage) and multiplies cI through W_ih ahead of
+//     time: when x_{t-1} arrives only the x u1 term and the cell are left.  Workgroup J of the second XCD owns the same units of rnn2 AND
+//     rows [16 J, 16 J + 16) of fc1 and of fc2: x2 -> y1 -> y2 never leave that XCD's L2 (plain stores; two cross-XCD hops per step are
+//     left: x1 and y2).  fc3 + the mixture-of-logistics sampling (utils/distribution.py:87-123) run on rnn1's workgroup 0, which waits for
+//     the chain anyway: x_t reaches the rnn1 workgroups through their own L2.
+//   * a stage = this wave's 8 fragments of the layer (16-byte sc1 loads, the sentinel is the arrival flag) -> 96 or 32 MFMAs (K split over
+//     the 4 waves) -> partial tiles through LDS in the accumulators' order, one LDS-only barrier -> the pointwise half of thread (unit,
+//     segment) -> publish: wrnn_duo.hip's stage with nothing pipelined around it.
+//   * exchange: wrnn_ring.h's buffer geometry; sentinel layers h1 x1 (re-armed two steps ahead by the wave that publishes them, behind its
+//     poll of x_{t-1}: that x needed everything of step t - 1) and h2 x2 y1 y2 (behind the poll of y1(t)), drained at the top of the next
+//     step; cI without a sentinel inside a launch (formed at the end of step t for step t + 2, drained at the top of step t + 1, read
+//     behind the poll of h1(t + 1)); x_t as tagged 8-byte words in two entries.  The rules are wrnn_sparse.hip's (model:
+//     tests/test_sparse_exchange_model.py); what differs is who publishes what.
+//   * conditioning slabs, state between launches (4 floats per (unit, segment)), step-range continuation: as wrnn_duo.hip / wrnn_sparse.hip.
+// Summation order per output: wrnn_duo.hip's (k ascending within a wave's quarter of K, the four quarters added in wave order).
+#include <type_traits>
+
+#include "wrnn_ring.h"
+
+namespace wrnn {
+
+constexpr int CHCL = 4;                      // clusters of 64 CUs
+constexpr int CHWG = 64;                     // workgroups per cluster (one per CU): 32 x rnn1, 32 x rnn2 (+ fc1 / fc2 rows)
+constexpr int CHPART = 2 * NW * 3 * 256;     // two ping-pong sets of [wave][tile 0..2][lane][4]
+constexpr int CHSTATE_WG = NT * 4 + SEG;     // saved state of a workgroup: per thread {h, gh_r, gh_z, gh_n}, then x_{t1-1} (rnn1)
+constexpr int CHSTATE_CL = CHWG * CHSTATE_WG;
+static_assert(CHCL * CHWG <= XCC_WORDS, "placement table");
+
+struct ChLds {
+    int off_seg, off_part, off_misc, off_prof, off_b3, off_f3, total;
+};
+__host__ __device__ inline ChLds ch_lds()
+{
+    ChLds l;
+    int o = 0;
+    l.off_seg = o;  o += 64;                 // ints: 16 positions | 16 limits | 16 table-row bases of this slab | 16 mel offsets
+    l.off_part = o; o += CHPART;
+    l.off_misc = o; o += 64;                 // placement table of the cluster (ints)
+    l.off_prof = o; o += 64;                 // [32] u64 phase clocks (profiling builds)
+    l.off_b3 = o;   o += 32;                 // the sampling workgroup: fc3.bias
+    o = (o + 3) & ~3;
+    l.off_f3 = o;   o += 2 * XT;             // ... fc3 (30 x 512 = two 16-row tiles) in A-fragment order
+    l.total = o;
+    return l;
+}
+
+typedef unsigned ch_u32x2 __attribute__((ext_vector_type(2)));
+#define CHX(k)                                                                 \
+    do {                                                                       \
+        if (PROF && tid == 0) {                                                \
+            const u64 now_ = __builtin_amdgcn_s_memtime();                     \
+            PROFL[k] += now_ - plast;                                          \
+            plast = now_;                                                      \
+        }                                                                      \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// One workgroup: units [16 J, 16 J + 16) of rnn1 (LA) or of rnn2 (+ rows [16 J, 16 J + 16) of fc1 and fc2).  rg = the cluster's region of the
+// exchange buffer = its group of the round.  loc_a / loc_b: the cluster's rnn1 / rnn2 workgroups were all seen on one XCD.
+// PROF (thread 0, shader clocks per segment of a step, program order): rnn1: 0 drain + wait x_{t-1}, 1 cell + publish, 2 wait h1(t), 3 gh stage,
+// 4 wait cI(t+1), 5 W_ih . cI stage, 6 cI(t+2) formed, 7 wait y2(t), 8 fc3 + sampling; rnn2: 0 drain + wait x1(t), 1 gate stage + cell + publish,
+// 2 wait x2, 3 fc1, 4 wait y1, 5 fc2, 6 wait h2 (there), 7 gh stage; 15 = steps
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <bool LA, bool PROF>
+__device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const int rg, const int J, const bool loc_a, const bool loc_b)
+{
+    const ChLds L = ch_lds();
+    float *PART = smem + L.off_part, *fc3b = smem + L.off_b3, *F3 = smem + L.off_f3;
+    int *SEGT = reinterpret_cast<int *>(smem + L.off_seg);
+    u64 *PROFL = reinterpret_cast<u64 *>(smem + L.off_prof);
+    u64 plast = 0;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, kq = lane >> 4;
+    const int kbase_lane = KCH * w + 4 * kq;
+    const int pu = 4 * w + (tid & 3), pj = (tid >> 2) & 15;      // pointwise role: (unit 16 J + pu, segment pj)
+    const int prow = LU * J + pu;
+    const int T0 = a.t0, T1 = a.t1;
+    unsigned *const status = a.status;
+    const int hop = a.hop, resume = a.resume, Tall = a.T, Nall = a.Nall, noise_t0 = a.noise_t0, C = a.C;
+    const unsigned magic = a.hop_magic;
+    const int mshift = a.hop_shift;
+    const int zrow = a.Nall * a.tab_fps;
+    float *const outp = a.out, *const dbgl = a.dbg_logits;
+    const float *const forcex = a.force_x, *const noise_pre = a.noise_pre;
+    const float *const mels_up = a.mels_up, *const aux_fr = a.aux_fr, *const mel_coef = a.mel_coef;
+    const int mel_stage = a.mel_stage;
+    const int NR = a.Btot, NGR = a.NG;
+    const int b0 = (int)(((long)rg * NR) / NGR), nb = (int)(((long)(rg + 1) * NR) / NGR) - b0;
+    const int b0g = a.rb0 + b0;
+    float *const state_wg = a.state + (size_t)rg * CHSTATE_CL + (size_t)((LA ? 0 : 32) + J) * CHSTATE_WG;
+    const bool sampler = LA && J == 0;
+
+    // ---- weights: three gate tiles of W_ih and of W_hh; rnn2: one tile of fc1 and of fc2
+    float A_ih[3][AF], A_hh[3][AF], A_fc1[AF], A_fc2[AF];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        load_afrag(A_ih[g], LA ? a.w_ih1 : a.w_ih2, LA ? H : H + AUX, g * H + LU * J + fi, true, kbase_lane);
+        load_afrag(A_hh[g], LA ? a.w_hh1 : a.w_hh2, H, g * H + LU * J + fi, true, kbase_lane);
+    }
+    if constexpr (!LA) {
+        load_afrag(A_fc1, a.fc1_w, H + AUX, LU * J + fi, true, kbase_lane);
+        load_afrag(A_fc2, a.fc2_w, H + AUX, LU * J + fi, true, kbase_lane);
+    }
+    // constants of the pointwise role: rnn1: b_ih1, u1 = W_ih1 . w0 (the x_{t-1} term), w0 (rnn2's b_ih2 is inside c2f); b_hh
+    float cb_r = 0.f, cb_z = 0.f, cb_n = 0.f, ux_r = 0.f, ux_z = 0.f, ux_n = 0.f, w0o = 0.f;
+    if constexpr (LA) {
+        cb_r = a.b_ih1[prow]; cb_z = a.b_ih1[H + prow]; cb_n = a.b_ih1[2 * H + prow];
+        ux_r = a.u1[prow]; ux_z = a.u1[H + prow]; ux_n = a.u1[2 * H + prow];
+        w0o = a.I_w0[prow];
+    }
+    const float *bhp = LA ? a.b_hh1 : a.b_hh2;
+    const float bh_r = bhp[prow], bh_z = bhp[H + prow], bh_n = bhp[2 * H + prow];
+    CondTile ct;
+    if constexpr (LA) cond_tile_init(ct, a.I_cT, a.I_b, J, lane);
+    for (int q = tid; q < L.off_f3; q += NT) smem[q] = 0.f;
+    if (sampler) {                                      // fc3 -> LDS (fragment order as in the pack)
+        for (int q = tid; q < 2 * XT / 4; q += NT) reinterpret_cast<float4 *>(F3)[q] = reinterpret_cast<const float4 *>(a.fc3f)[q];
+    }
+    __syncthreads();
+    if (sampler && tid >= 32 && tid < 64) fc3b[tid - 32] = tid - 32 < 30 ? a.fc3_b[tid - 32] : 0.f;
+    if (tid < SEG) {
+        const int sc = b0g + (tid < nb ? tid : nb - 1);
+        const int pos = a.seg_pos[sc];
+        SEGT[tid] = pos;
+        SEGT[SEG + tid] = a.seg_lim[sc];
+        SEGT[2 * SEG + tid] = sc * a.tab_fps - (pos + a.tab_t0) / a.hop;
+        SEGT[3 * SEG + tid] = a.mel_stage ? a.seg_moff[sc] : 0;
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.xbuf, (unsigned)(DXBUF_FLOATS * 4));
+    const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.c2f, 0x7FFFF000u);
+    const __amdgpu_buffer_rsrc_t f1rs = make_rsrc(a.c3f, 0x7FFFF000u), f2rs = make_rsrc(a.c4f, 0x7FFFF000u);
+    const int cbase = rg * DSLOTB;
+    const int voff_frag = frag_off(w, 0, lane) * 4;      // this lane's first fragment of a layer (bytes)
+    const int voff_own = (((J * 64) + 16 * w + pj) * 4 + (tid & 3)) * 4;      // the layer word of (unit 16 J + pu, segment pj) = its publish position
+    const bool live = fi < nb;                           // this lane's segment exists (fragment polls)
+    const bool plive = pj < nb;                          // ... of the pointwise role
+
+    bool dead = false;
+    int pp = 0;
+    int t = T0;
+    float h = 0.f, ghr = bh_r, ghz = bh_z, ghn = bh_n;   // (fatchord_version.py:194-195: h = 0, so gh(0) = b_hh)
+    float ga_r = 0.f, ga_z = 0.f, ga_n = 0.f, xo = 0.f;  // rnn1: W_ih1 . cI(t) of the thread's unit and its own cI word, formed at the end of step t - 1
+    if (resume) {
+        const float4 sv = *reinterpret_cast<const float4 *>(state_wg + tid * 4);
+        h = sv.x; ghr = sv.y; ghz = sv.z; ghn = sv.w;
+    }
+
+    // one stage: the layer at byte offset `so` -> three (NT = 3) or one tile(s) of this workgroup x the group's 16 segments; the sums of the
+    // thread's (unit, segment) come back in s0..s2, `ownw` = the thread's own word of that layer (the residual input of the gate stages)
+    auto stage = [&](auto NTC, const float (&A0)[AF], const float (&A1)[AF], const float (&A2)[AF], int so, unsigned code, int ts, int px_wait,
+                     float &s0, float &s1, float &s2, unsigned &ownw, bool want_own) {
+        constexpr int NTL = decltype(NTC)::value;
+        u32x4 x[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, so, 16 /* sc1 */);
+        if (want_own) ownw = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, so, 16 /* sc1 */);
+        if (__builtin_expect(!frag_there(x, live), 0))
+            wait_for([&] { return frag_there(x, live); },
+                     [&] {
+#pragma unroll
+                         for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, so, 16 /* sc1 */);
+                     },
+                     status, dead, code, ts);
+        if (want_own && __builtin_expect(__any(plive && ownw == SENT), 0))
+            wait_for([&] { return !__any(plive && ownw == SENT); }, [&] { ownw = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, so, 16 /* sc1 */); },
+                     status, dead, code | 0x80u, ts);
+        CHX(px_wait);
+        float b[32];
+        frag_to_b(x, b);
+        float *PW = PART + pp * (NW * 3 * 256);
+        if constexpr (NTL == 3) {
+            f32x4 o0, o1, o2;
+            mfma3s(A0, A1, A2, b, o0, o1, o2);
+            put_partial<3>(PW, w, 0, lane, o0);
+            put_partial<3>(PW, w, 1, lane, o1);
+            put_partial<3>(PW, w, 2, lane, o2);
+        } else put_partial<3>(PW, w, 0, lane, mfma1(A0, b));
+        lds_barrier();
+        s0 = get_partial<3>(PW, 0, pu, pj);
+        if constexpr (NTL == 3) { s1 = get_partial<3>(PW, 1, pu, pj); s2 = get_partial<3>(PW, 2, pu, pj); }
+        pp ^= 1;
+    };
+    using N1 = std::integral_constant<int, 1>;
+    using N3 = std::integral_constant<int, 3>;
+    // re-arm this wave's quarter of the workgroup's 1 KB block of `layer` in entry (t + 2) % 4 (lanes 16 slot .. 16 slot + 15)
+    auto rearm1 = [&](int layer, int slot, bool local) {
+        if (kq == slot) {
+            const u32x4 q = {SENT, SENT, SENT, SENT};
+            const int vo = layer * DLAYERB + J * 1024 + w * 256 + fi * 16, so = cbase + ((t + DAHEAD_IH) & (DRING - 1)) * XTB;
+            if (local) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, vo, so, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, vo, so, 16 /* sc1 */);
+        }
+    };
+    unsigned dummy = 0u;
+
+    if (PROF && tid == 0) plast = __builtin_amdgcn_s_memtime();
+    if constexpr (LA) {
+        // ---------------- rnn1 ----------------
+        auto cond_step = [&](int tt) {                  // wave 0: cI(tt) of the workgroup's 16 rows (fatchord_version.py:203-209 without the x_{t-1} column)
+            if (w == 0) {
+                const int p = SEGT[fi] + tt;
+                const bool valid = live && p < SEGT[SEG + fi];
+                const int fr = magic ? (int)(__umulhi((unsigned)p, magic) >> mshift) : p / hop;
+                f32x4 v;
+                if (mel_stage) {
+                    const int j = p + SEGT[3 * SEG + fi];
+                    const int row = j / LAST_SCALE;
+                    v = cond_tile_rows(ct, mels_up + (size_t)(row - 1) * MEL, mel_coef + 3 * (j - row * LAST_SCALE), aux_fr + (size_t)fr * (4 * AUX), valid, lane);
+                } else v = cond_tile(ct, mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane);
+                const u32x4 q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                const int so = cbase + 4 * DLAYERB + (tt & (DRING - 1)) * XTB;
+                if (loc_a) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 16 /* sc1 */);
+            }
+        };
+        auto front = [&](int ts) {                      // W_ih1 . cI(ts) + the thread's own cI word (xi - w0 x)
+            unsigned ow = 0u;
+            float s0, s1, s2;
+            stage(N3{}, A_ih[0], A_ih[1], A_ih[2], cbase + 4 * DLAYERB + (ts & (DRING - 1)) * XTB, 0x820u, ts, 4, s0, s1, s2, ow, true);
+            ga_r = s0; ga_z = s1; ga_n = s2; xo = __uint_as_float(ow);
+            CHX(5);
+        };
+        auto sample = [&]() {
+            const int sb = cbase + (t & (DRING - 1)) * XTB;
+            u32x4 x[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 3 * DLAYERB, 16 /* sc1 */);
+            const int su = tid >> 4, sm = tid & 15;     // sampling role: 16-lane row = segment su, lane sm = mixture
+            const float *nrow = noise_pre + (size_t)(t - noise_t0) * 11 * Nall;
+            const int suc = su < nb ? su : nb - 1;
+            const float nz0 = nrow[(size_t)(b0g + suc) * 10 + (sm < 10 ? sm : 9)];
+            const float nz1 = nrow[(size_t)10 * Nall + b0g + suc];
+            if (__builtin_expect(!frag_there(x, live), 0))
+                wait_for([&] { return frag_there(x, live); },
+                         [&] {
+#pragma unroll
+                             for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 3 * DLAYERB, 16 /* sc1 */);
+                         },
+                         status, dead, 0x850u, t);
+            CHX(7);
+            float b[32];
+            frag_to_b(x, b);
+            float *PW = PART + pp * (NW * 3 * 256);
+            put_partial<3>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
+            put_partial<3>(PW, w, 1, lane, mfma1_lds(F3 + XT + frag_off(w, 0, lane), b));
+            lds_barrier();
+            if (dbgl && plive) {                        // test hook: the 30 logits of every segment
+                dbgl[((size_t)t * Nall + b0g + pj) * C + pu] = get_partial<3>(PW, 0, pu, pj) + fc3b[pu];
+                if (pu < 14) dbgl[((size_t)t * Nall + b0g + pj) * C + 16 + pu] = get_partial<3>(PW, 1, pu, pj) + fc3b[16 + pu];
+            }
+            {   // utils/distribution.py:102-121: lane sm < 10 of a 16-lane row sums the partial tiles of ITS mixture logit straight from LDS,
+                // Gumbel-max over the row, then lane 0 fetches mean and log-scale of the winner
+                float best = (sm < 10) ? mol_gumbel_pre(get_partial<3>(PW, 0, sm < 10 ? sm : 0, su) + fc3b[sm < 10 ? sm : 0], nz0) : -INFINITY;
+                int bidx = sm;
+                argmax_row16(best, bidx);
+                if (sm == 0 && su < nb) {
+                    const float mean = get_partial<3>(PW, (10 + bidx) >> 4, (10 + bidx) & 15, su) + fc3b[10 + bidx];
+                    const float ls = get_partial<3>(PW, (20 + bidx) >> 4, (20 + bidx) & 15, su) + fc3b[20 + bidx];
+                    float xv = mol_sample_pre(mean, ls, nz1);
+                    outp[(size_t)(b0g + su) * Tall + t] = xv;
+                    if (forcex) xv = forcex[(size_t)(b0g + su) * Tall + t];
+                    const ch_u32x2 q = {__float_as_uint(xv), (unsigned)t + 1u};       // one 8-byte word {x_t, tag}: its own flag, two entries, no re-arm
+                    if (loc_a) __builtin_amdgcn_raw_buffer_store_b64(q, xrs, su * 8, cbase + 7 * DLAYERB + (t & 1) * XTB, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b64(q, xrs, su * 8, cbase + 7 * DLAYERB + (t & 1) * XTB, 16 /* sc1 */);
+                }
+            }
+            pp ^= 1;
+            CHX(8);
+        };
+
+        cond_step(T0);                                  // the two steps a launch starts with; every later cI is formed at the end of step t for t + 2
+        if (T0 + 1 < T1) cond_step(T0 + 1);
+        front(T0);
+        for (; t < T1; ++t) {
+            if (PROF && tid == 0) PROFL[15] += 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // last step's re-arm stores and the cI formed at its end are out before this step publishes
+            float xv = 0.f;
+            if (t > T0) {                               // x_{t-1}: a tagged word {x, tag = t} from this cluster's sampling workgroup
+                const int sx = cbase + 7 * DLAYERB + ((t - 1) & 1) * XTB;
+                ch_u32x2 xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, pj * 8, sx, 16 /* sc1 */);
+                if (__builtin_expect(__any(plive && xq.y != (unsigned)t), 0))
+                    wait_for([&] { return !__any(plive && xq.y != (unsigned)t); }, [&] { xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, pj * 8, sx, 16 /* sc1 */); },
+                             status, dead, 0x830u, t);
+                xv = __uint_as_float(xq.x);
+            } else if (resume) xv = state_wg[NT * 4 + pj];
+            CHX(0);
+            {   // the GRU cell of (unit 16 J + pu, segment pj) (ATen gru_cell; hardware exp / rcp as the duo kernel's MoL path) -> x1 (to rnn2's XCD), h1
+                const float gir = ga_r + fmaf(xv, ux_r, cb_r), giz = ga_z + fmaf(xv, ux_z, cb_z), gin = ga_n + fmaf(xv, ux_n, cb_n);
+                const float xin = fmaf(w0o, xv, xo);    // xi of the owned unit (:208-209)
+                h = gru_update_fast(gir, giz, gin, ghr, ghz, ghn, h);
+                const int sb = cbase + (t & (DRING - 1)) * XTB;
+                publish4l(xrs, sb + 5 * DLAYERB + J * 1024, tid, xin + h, plive, false);      // x1 = xi + h1 (:212)
+                publish4l(xrs, sb + 0 * DLAYERB + J * 1024, tid, h, plive, loc_a);
+            }
+            rearm1(0, 0, loc_a);                        // (behind the poll of x_{t-1}, which needed everything of step t - 1: every reader is past step t - 2)
+            rearm1(5, 1, false);
+            CHX(1);
+            {   // gh(t + 1) = W_hh . h1(t) + b_hh: one hop behind the publication above, long before anything else is due
+                float s0, s1, s2;
+                stage(N3{}, A_hh[0], A_hh[1], A_hh[2], cbase + 0 * DLAYERB + (t & (DRING - 1)) * XTB, 0x840u, t, 2, s0, s1, s2, dummy, false);
+                ghr = s0 + bh_r; ghz = s1 + bh_z; ghn = s2 + bh_n;
+                CHX(3);
+            }
+            if (t + 1 < T1) front(t + 1);
+            if (t + 2 < T1) { cond_step(t + 2); CHX(6); }
+            if (sampler) sample();
+        }
+        // ---- what the next launch needs: x_{T1-1}; the sentinel in the cI entries of steps T1 and T1 + 1 (its first two steps are polled)
+        {
+            const int sx = cbase + 7 * DLAYERB + ((T1 - 1) & 1) * XTB;
+            ch_u32x2 xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, fi * 8, sx, 16 /* sc1 */);
+            wait_for([&] { return !__any(live && xq.y != (unsigned)T1); }, [&] { xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, fi * 8, sx, 16 /* sc1 */); },
+                     status, dead, 0x861u, T1);
+            if (tid < SEG) state_wg[NT * 4 + tid] = live ? __uint_as_float(xq.x) : 0.f;
+            if (w == 0) {
+                const u32x4 q = {SENT, SENT, SENT, SENT};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (loc_a) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, cbase + 4 * DLAYERB + ((T1 + e) & (DRING - 1)) * XTB, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, cbase + 4 * DLAYERB + ((T1 + e) & (DRING - 1)) * XTB, 16 /* sc1 */);
+                }
+            }
+        }
+    } else {
+        // ---------------- rnn2 (+ fc1, fc2) ----------------
+        for (; t < T1; ++t) {
+            if (PROF && tid == 0) PROFL[15] += 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int sb = cbase + (t & (DRING - 1)) * XTB;
+            const int fr = table_row(SEGT[pj] + t, SEGT[SEG + pj], SEGT[2 * SEG + pj], magic, mshift, hop, zrow);
+            {   // the gate stage: the whole of it is on the chain (x1 -> here)
+                const int vo = (fr * 3 * H + prow) * 4;
+                const float c0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, 0, 0));
+                const float c1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, H * 4, 0));
+                const float c2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, 2 * H * 4, 0));
+                unsigned ow = 0u;
+                float s0, s1, s2;
+                stage(N3{}, A_ih[0], A_ih[1], A_ih[2], sb + 5 * DLAYERB, 0x828u, t, 0, s0, s1, s2, ow, true);
+                h = gru_update_fast(s0 + c0, s1 + c1, s2 + c2, ghr, ghz, ghn, h);
+                publish4l(xrs, sb + 6 * DLAYERB + J * 1024, tid, __uint_as_float(ow) + h, plive, loc_b);      // x2 = x1 + h2 (:216)
+                publish4l(xrs, sb + 1 * DLAYERB + J * 1024, tid, h, plive, loc_b);
+                CHX(1);
+            }
+            {   // fc1 + relu (:216-218) -> y1
+                const float cv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(f1rs, (fr * H + prow) * 4, 0, 0));
+                float s0, s1, s2;
+                stage(N1{}, A_fc1, A_fc1, A_fc1, sb + 6 * DLAYERB, 0x801u, t, 2, s0, s1, s2, dummy, false);
+                publish4l(xrs, sb + 2 * DLAYERB + J * 1024, tid, fmaxf(s0 + cv, 0.f), plive, loc_b);
+                CHX(3);
+            }
+            {   // fc2 + relu (:220-221) -> y2 (to the sampling workgroup on the other XCD)
+                const float cv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(f2rs, (fr * H + prow) * 4, 0, 0));
+                float s0, s1, s2;
+                stage(N1{}, A_fc2, A_fc2, A_fc2, sb + 2 * DLAYERB, 0x802u, t, 4, s0, s1, s2, dummy, false);
+                publish4l(xrs, sb + 3 * DLAYERB + J * 1024, tid, fmaxf(s0 + cv, 0.f), plive, false);
+                // ring hygiene: behind the last poll of the step (y1(t): everybody is past step t - 1's readers of step t - 2) and behind the publication
+                rearm1(1, 0, loc_b);
+                rearm1(6, 1, loc_b);
+                rearm1(2, 2, loc_b);
+                rearm1(3, 3, false);
+                CHX(5);
+            }
+            {   // gh(t + 1) = W_hh . h2(t) + b_hh: h2(t) arrived with x2(t); needed at the cell of step t + 1 -- under the sampling and the x_t / x1 hops
+                float s0, s1, s2;
+                stage(N3{}, A_hh[0], A_hh[1], A_hh[2], sb + 1 * DLAYERB, 0x848u, t, 6, s0, s1, s2, dummy, false);
+                ghr = s0 + bh_r; ghz = s1 + bh_z; ghn = s2 + bh_n;
+                CHX(7);
+            }
+        }
+    }
+    if (PROF && tid == 0 && a.prof) {
+        for (int k = 0; k < 16; ++k) a.prof[(size_t)(blockIdx.x & 255) * 32 + k] += PROFL[k];
+    }
+    *reinterpret_cast<float4 *>(state_wg + tid * 4) = make_float4(h, ghr, ghz, ghn);
+}
+#undef CHX
+
+// Grid = 4 clusters x 64 workgroups of 256 threads (one per CU), cooperative launch; a cluster without a group leaves at once.  Placement
+// (speed only, verified at run time): block b is observed to run on XCD b % 8; cluster cl = XCDs 2 cl (its rnn1 workgroups) and 2 cl + 1
+// (rnn2, fc1, fc2); the 32 blocks of an XCD: unit blocks J = 0 .. 31.
+template <bool PROF>
+__global__ __launch_bounds__(NT, 1) void wrnn_chain_kernel(const LoopArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    check_kind(a);
+    const int b = blockIdx.x;
+    const int xcd = b % 8, J = b / 8;
+    const int cl = xcd >> 1, layer = xcd & 1;
+    if (cl >= a.NG) return;
+    const int wgi = layer * 32 + J;
+    bool loc_a = false, loc_b = false;
+    {   // placement handshake (as wrnn_duo.hip): a half of the cluster seen on ONE XCD exchanges its own layers through that XCD's L2 with plain stores
+        int *TAB = reinterpret_cast<int *>(smem) + ch_lds().off_misc;
+        const int tid = threadIdx.x;
+        unsigned *tab = a.xcc_tab + cl * CHWG;
+        if (tid == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;          // HW_REG_XCC_ID
+            __hip_atomic_store(tab + wgi, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned v = 1u;
+        if (tid < CHWG) {
+            unsigned spins = 0;
+            v = ld_agent32(tab + tid);
+            while (v == 0u && ++spins < 200000u) {
+                __builtin_amdgcn_s_sleep(2);
+                v = ld_agent32(tab + tid);
+            }
+            TAB[tid] = (int)v;
+        }
+        __syncthreads();
+        const int ok_a = (tid < 32) ? (v != 0u && (int)v == TAB[0]) : 1;
+        const int ok_b = (tid >= 32 && tid < CHWG) ? (v != 0u && (int)v == TAB[32]) : 1;
+        loc_a = __syncthreads_and(ok_a) != 0;
+        loc_b = __syncthreads_and(ok_b) != 0;
+        if (a.tuning & 256) { loc_a = false; loc_b = false; }       // A/B: everything written through
+        __syncthreads();
+    }
+    if (layer == 0) ch_role<true, PROF>(a, smem, cl, J, loc_a, loc_b);
+    else ch_role<false, PROF>(a, smem, cl, J, loc_a, loc_b);
+}
+
+int chain_clusters(int n_cus) { return n_cus >= CHCL * CHWG ? CHCL : 0; }
+size_t chain_state_floats() { return (size_t)CHCL * CHSTATE_CL; }
+size_t chain_xbuf_bytes() { return (size_t)CHCL * DSLOTB; }
+
+hipError_t launch_chain(const LoopArgs &args, hipStream_t stream)
+{
+    if (!args.fc3f || !args.u1 || !args.xcc_tab || args.NG < 1 || args.NG > CHCL) return hipErrorInvalidValue;
+    const size_t lds = (size_t)ch_lds().total * sizeof(float);
+    const bool prof = args.prof && !(args.tuning & 64);
+    const void *fn = prof ? (const void *)wrnn_chain_kernel<true> : (const void *)wrnn_chain_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    LoopArgs a = args;
+    void *params[] = {(void *)&a};
+    return hipLaunchCooperativeKernel(fn, dim3(CHCL * CHWG), dim3(NT), params, (unsigned)lds, stream);
+}
+
+}  // namespace wrnn

@@ -109,21 +109,6 @@ __host__ __device__ inline DuoLds duo_lds(int G)
     return l;
 }
 
-// three gate tiles, ONE accumulator chain per tile: consecutive MFMAs of a chain are 3 issue slots (96 cycles) apart, more than the
-// 40-cycle dependent latency; per output the k terms are summed in ascending order (the oracle's single chain)
-__device__ __forceinline__ void mfma3s(const float (&a0)[AF], const float (&a1)[AF], const float (&a2)[AF], const float (&b)[32],
-                                       f32x4 &o0, f32x4 &o1, f32x4 &o2)
-{
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[k], b[k], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[k], b[k], c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[k], b[k], c2, 0, 0, 0);
-    }
-    o0 = c0; o1 = c1; o2 = c2;
-}
-
 #define DPARTOF(q) (PART + (q) * (NW * 3 * 256))
 #define PHX(k)                                                                 \
     do {                                                                       \

@@ -335,14 +335,8 @@ __global__ __launch_bounds__(NT, 1) void wrnn_taco_decoder_kernel(const TacoArgs
 // =================================================================================================================================
 constexpr int R_NWG = 128, R_NWV = R_NWG * NW;
 constexpr int R_MAXR = 8;
-// TACO_LOCAL_PRENET 1 = the two PreNet layers are computed by every workgroup that owns attention-GRU units (the first 64) for itself
-// -- fc1 from an LDS copy of its weights (80 KB, k-major), fc2 from 128 registers per thread (row t >> 1, K half t & 1) -- instead
-// of crossing workgroups twice.  Measured (profiles/r03aj_taco_profile_local_prenet.json): the redundant layers take 8.6 k cycles per
-// step (the serial 80 + 128-term dot products of one thread per row), exactly what the two exchanges cost: 28.2 vs 27.6 us per
-// step.  0 (the default) = distributed rows, as the other layers.
-#ifndef TACO_LOCAL_PRENET
-#define TACO_LOCAL_PRENET 0
-#endif
+// (Measured and dropped in round 3, profiles/r03aj_taco_profile_local_prenet.json: both PreNet layers computed by every workgroup that owns
+// attention-GRU units for itself -- two exchange hops less, but 80 KB of LDS and 128 registers per thread more: no faster.)
 // tagged vectors: offsets in 8-byte entries, [2 parity buffers][length]
 constexpr int VL_MEL = T_NM * R_MAXR, VL_S = T_NMAX;
 constexpr int V_MEL = 0, V_PRE1 = V_MEL + 2 * VL_MEL, V_PRE2 = V_PRE1 + 2 * T_P1, V_ATTNH = V_PRE2 + 2 * T_P2, V_CTX = V_ATTNH + 2 * T_DD,
@@ -401,10 +395,6 @@ __global__ __launch_bounds__(NT, 1) void wrnn_taco_resident_kernel(const TacoArg
     __shared__ float wtmp[NW][64 + T_AF];
     __shared__ float red[NT];
     __shared__ int misc[4];
-#if TACO_LOCAL_PRENET
-    __shared__ float w1T[T_NM * T_P1];                                 // prenet fc1 weights, [k][row]
-    __shared__ float p1[T_P1];
-#endif
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wg = blockIdx.x;
     const int gw = wg * NW + w;
@@ -417,19 +407,8 @@ __global__ __launch_bounds__(NT, 1) void wrnn_taco_resident_kernel(const TacoArg
     // ---------------- resident weights (float4 chunk c of a row: k = 4 lane + 256 c) ----------------
     const int k0 = 4 * lane;
     const bool u256 = gw < T_DD, u128 = gw < T_P2;
-#if TACO_LOCAL_PRENET
-    const bool gru_wg = wg < T_DD / NW;                               // this workgroup owns attention-GRU units: it needs the prenet output
-    float w2[T_P1 / 2];                                               // prenet fc2: row tid >> 1, columns [128 (tid & 1), +128)
-#pragma unroll
-    for (int k = 0; k < T_P1 / 2; k += 4) {
-        const float4 v = ldw4(a.w.prenet_fc2_w + (size_t)(tid >> 1) * T_P1 + (T_P1 / 2) * (tid & 1) + k, gru_wg);
-        w2[k] = v.x; w2[k + 1] = v.y; w2[k + 2] = v.z; w2[k + 3] = v.w;
-    }
-    const float b1_t = a.w.prenet_fc1_b[tid], b2_t = a.w.prenet_fc2_b[tid >> 1];
-#else
     const float4 w_fc1 = ldw4(a.w.prenet_fc1_w + (size_t)gw * T_NM + k0, u256 && k0 < T_NM);
     const float4 w_fc2 = ldw4(a.w.prenet_fc2_w + (size_t)gw * T_P1 + k0, u128);
-#endif
     float4 g_i[3][2], g_h[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -459,9 +438,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_taco_resident_kernel(const TacoArg
     for (int i = 0; i < 2; ++i) spj[i] = ldw4(a.seq_proj + (size_t)(gw + R_NWV * i) * T_DD + k0, gw + R_NWV * i < n);
     const float4 v_w = ldw4(a.w.attn_v_w + k0, true), L_b = ldw4(a.w.attn_L_b + k0, true);
     // biases of this wave's rows (wave-uniform)
-#if !TACO_LOCAL_PRENET
     const float b_fc1 = u256 ? a.w.prenet_fc1_b[gw] : 0.f, b_fc2 = u128 ? a.w.prenet_fc2_b[gw] : 0.f;
-#endif
     const float b_q = u256 ? a.w.attn_W_b[gw] : 0.f;
     float b_gi[3], b_gh[3], b_l1[4], b_l1h[4], b_l2[4], b_l2h[4];
 #pragma unroll
@@ -476,11 +453,6 @@ __global__ __launch_bounds__(NT, 1) void wrnn_taco_resident_kernel(const TacoArg
     // ---------------- LDS: attention weights (transposed: conflict-free lane strides), zero state ----------------
     for (int k = tid; k < T_AF * 2 * T_AK; k += NT) convT[(k % (2 * T_AK)) * T_AF + k / (2 * T_AK)] = a.w.attn_conv_w[k];
     for (int k = tid; k < T_DD * T_AF; k += NT) LT[(k % T_AF) * T_DD + k / T_AF] = a.w.attn_L_w[k];
-#if TACO_LOCAL_PRENET
-    if (gru_wg)
-        for (int k = tid; k < T_NM * T_P1; k += NT) w1T[(k % T_NM) * T_P1 + k / T_NM] = a.w.prenet_fc1_w[k];
-    p1[tid] = 0.f;
-#endif
     for (int k = tid; k < 1024; k += NT) { xb[0][k] = 0.f; xb[1][k] = 0.f; sc[k] = 0.f; att[k] = 0.f; cum[k] = 0.f; }
     for (int k = tid; k < VL_MEL; k += NT) melv[k] = 0.f;
     ahv[tid] = 0.f;
@@ -536,27 +508,6 @@ __global__ __launch_bounds__(NT, 1) void wrnn_taco_resident_kernel(const TacoArg
             const int any = __syncthreads_or(notbelow);
             if (step > 0 && !any && (step - 1) * r > 10) break;        // `(mel_frames < stop_threshold).all() and t > 10`, t = (step - 1) r
         }
-#if TACO_LOCAL_PRENET
-        if (gru_wg) {   // both PreNet layers (:141-155, eval: no dropout) here, for this workgroup's own GRU units
-            float s1 = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < T_NM; ++k) s1 = fmaf(w1T[k * T_P1 + tid], melv[k * r + r - 1], s1);      // row tid, the block's last frame
-            p1[tid] = fmaxf(s1 + b1_t, 0.f);
-            __syncthreads();
-            float s2 = 0.f;
-            const float *ph = p1 + (T_P1 / 2) * (tid & 1);
-#pragma unroll
-            for (int k = 0; k < T_P1 / 2; k += 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(ph + k);
-                s2 = fmaf(w2[k], v.x, s2); s2 = fmaf(w2[k + 1], v.y, s2); s2 = fmaf(w2[k + 2], v.z, s2); s2 = fmaf(w2[k + 3], v.w, s2);
-            }
-            s2 += dpp_get<0xB1>(s2);                                   // the other K half: lane ^ 1
-            if ((tid & 1) == 0) xb[1][T_DD + (tid >> 1)] = fmaxf(s2 + b2_t, 0.f);
-        }
-        PH(1);
-        PH(2);
-        PH(3);
-#else
         if (u256) {
             float s = 0.f;
             if (k0 < T_NM) {                                           // the last frame of the block: column j = r - 1 of rows m = k0 .. k0 + 3
@@ -574,15 +525,12 @@ __global__ __launch_bounds__(NT, 1) void wrnn_taco_resident_kernel(const TacoArg
         PH(2);
         if (u128) pub(V_PRE2 + p * T_P2 + gw, fmaxf(wave_total(fma4(w_fc2, xb[0] + k0, 0.f)) + b_fc2, 0.f), tag);
         PH(3);
-#endif
         // ---- L3: attention GRUCell on [context(t-1), prenet] with h = attn_h(t-1) (:233-235) ----
         if (step > 0) {
             poll_in(xb[1], V_CTX + (p ^ 1) * T_DD, T_DD, ptag, 3);
             poll_in(xb[1] + 512, V_ATTNH + (p ^ 1) * T_DD, T_DD, ptag, 3);
         }
-#if !TACO_LOCAL_PRENET
         poll_in(xb[1] + T_DD, V_PRE2 + p * T_P2, T_P2, tag, 3);
-#endif
         STAGED();
         PH(4);
         if (u256) {

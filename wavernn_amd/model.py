@@ -134,10 +134,15 @@ class WaveRNN(nn.Module):
         #: 'native' = the HIP pre-loop kernels (MFMA MelResNet + box-filter up-sampling, wrnn_pre_*);
         #: 'torch' = the nn.Modules below through PyTorch-ROCm (MIOpen)
         self.pre_algo = 'native'
-        #: True = when the call runs on wrnn_duo_kernel (and the pre-loop stage is 'native' with a last stretch factor of 11), the LAST
-        #: up-sampling stage and the crop are formed inside the loop from that stage's input (`engine.MelRows`): the [L, feat]
-        #: up-sampled mel is never written.  False = always materialise it (what every other loop kernel reads).
-        self.mel_in_loop = True
+        #: True = when the call runs on wrnn_duo_kernel / wrnn_sparse_kernel (and the pre-loop stage is 'native' with a last stretch factor of 11),
+        #: the LAST up-sampling stage and the crop are formed inside the loop from that stage's input (`engine.MelRows`): the [L, feat]
+        #: up-sampled mel is never written.  False = always materialise it (what every other loop kernel reads).  None (default) = by mode:
+        #: MOL -> True; RAW -> False -- the three-row form of that stage is another float32 rounding of the mel (<= 1e-6), and the 9-bit mode is
+        #: compared class index by class index: against the C oracle the shipped kernel parts ways in 2 of 1,024 segments of 12,100 steps
+        #: with the mel formed in the loop and in 1 with the materialised mel (profiles/r05a_raw_flips.json; no float32
+        #: implementation is flip-free against another -- the oracle itself differs from the reference's own run in 1 of 387,200 samples --
+        #: but the bit-exact mode takes the conservative default; `model.mel_in_loop = True` opts in to the faster path).
+        self.mel_in_loop = None
         #: 'native' = cross-fade / unfold / mu-law / tail fade on the device in float64 (wrnn_post_unfold);
         #: 'numpy' = the host helpers of fold.py
         self.post_algo = 'native'
@@ -217,12 +222,14 @@ class WaveRNN(nn.Module):
         """Whether a run over this many segments takes the mel one up-sampling stage short (`mel_in_loop`): it runs on wrnn_duo_kernel / wrnn_sparse_kernel and
         the HIP pre-loop stage ends with the stretch factor that kernel is built for."""
         device = next(self.parameters()).device
-        if not (self.mel_in_loop and self.pre_algo == 'native' and device.type == 'cuda'):
+        in_loop = (self.mode == 'MOL') if self.mel_in_loop is None else bool(self.mel_in_loop)
+        if not (in_loop and self.pre_algo == 'native' and device.type == 'cuda'):
             return False
         if eng.plan(n_segments, T, algo=self.loop_algo)['kernel'] not in MEL_STAGE_KERNELS:
             return False
         try:
-            return self._pre_engine().scales[2] == 11
+            pre = self._pre_engine()
+            return pre.scales[2] == 11 and pre.pad >= 1        # (pad 0: the stage's first output would need a row in front of the buffer)
         except _lib.WrnnError:
             return False
 
@@ -272,7 +279,13 @@ class WaveRNN(nn.Module):
                 B, T, stride = 1, L, 0
             eng = self._loop_engine()
             rows = self.mel_rows_ok(eng, B, T)
-            mels_up, aux, wave_len = self.conditioning(mels, rows=rows)
+            try:
+                mels_up, aux, wave_len = self.conditioning(mels, rows=rows)
+            except _lib.WrnnError:
+                if not rows:
+                    raise
+                rows = False                                 # (the rows form was refused: the materialised mel, as any other loop kernel reads it)
+                mels_up, aux, wave_len = self.conditioning(mels)
             assert (mels_up.L if rows else mels_up.size(0)) == L
             burn_ctor_draws(self.rnn_dims, self.aux_dims, self.noise_source)
             # the sampling noise is drawn and uploaded in slices of steps (RAW: B * n_classes floats per step), each slice
