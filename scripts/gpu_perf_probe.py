@@ -38,6 +38,8 @@ VARS = {'auto': dict(algo='auto'), 'stream': dict(algo='stream'), 'g1': dict(alg
         'g3': dict(algo='loop', depth=3), 'g4': dict(algo='loop', depth=4), 'g6': dict(algo='loop', depth=6), 'g8': dict(algo='loop', depth=8),
         'c1g1': dict(algo='loop', clusters=1, depth=1), 'c2g1': dict(algo='loop', clusters=2, depth=1), 'c1g2': dict(algo='loop', clusters=1, depth=2),
         'nola': dict(algo='loop', tuning=1), 'fence': dict(algo='loop', tuning=2), 'nola-fence': dict(algo='loop', tuning=3),
+        'c1': dict(algo='chain', depth=1), 'c2': dict(algo='chain', depth=2), 'c3': dict(algo='chain', depth=3), 'c4': dict(algo='chain', depth=4),
+        'c1a': dict(algo='chain', depth=1, tuning=16), 'c2b': dict(algo='chain', depth=2, tuning=32), 'c4b': dict(algo='chain', depth=4, tuning=32),
         's1': dict(algo='sparse'), 'swt': dict(algo='sparse', tuning=256),       # wrnn_sparse_kernel (needs --prune); swt: every layer written through
         # wrnn_duo_kernel (round 4): tuning bit 0 = loads first, bit 1 = publish first (default: by depth), bit 8 = every layer written through
         # (no XCD-local plain stores), bit 2 = ring re-filled before every launch
@@ -72,7 +74,7 @@ for B in [int(x) for x in args.B.split(',')]:
         opts = VARS[v]
         try:
             depth = opts.get('depth', 0)
-            if depth > 1 and B <= 64 * (depth - 1) and opts['algo'] in ('loop', 'duo'):
+            if depth > 1 and B <= 64 * (depth - 1) and opts['algo'] in ('loop', 'duo', 'chain'):
                 continue                                              # the extra slots would stay empty: same run as a shallower depth
             out = eng.run(mels_up, aux, B, T, stride, noise, hop, **opts)
             out = eng.run(mels_up, aux, B, T, stride, noise, hop, **opts)

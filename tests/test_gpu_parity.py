@@ -90,6 +90,12 @@ VARIANTS = {
     'chain': dict(algo='chain'),
     'chain-slabs': dict(algo='chain', slab_steps=97),
     'chain-wt': dict(algo='chain', tuning=256),
+    # ... with several groups in flight per cluster (the throughput form: fc1 on the rnn1 workgroups), and both fc1 placements forced
+    'chain-g2': dict(algo='chain', depth=2),
+    'chain-g2-slabs': dict(algo='chain', depth=2, slab_steps=97),
+    'chain-g4': dict(algo='chain', depth=4, slab_steps=131),
+    'chain-g1-fc1a': dict(algo='chain', depth=1, tuning=16),
+    'chain-g2-fc1b': dict(algo='chain', depth=2, tuning=32),
 }
 KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'loop': 'wrnn_loop_kernel', 'sparse': 'wrnn_sparse_kernel', 'duo': 'wrnn_duo_kernel', 'chain': 'wrnn_chain_kernel'}
 
@@ -442,7 +448,8 @@ def test_generate_end_to_end(gpu, name, pre, tmp_path):
 
 
 @pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'loop-c2-g2', 'loop-c1-g3-nofuse', 'duo', 'duo-g1', 'duo-g2-slabs',
-                                     'duo-c1-g3', 'duo-c2-g2', 'duo-g2-pf', 'duo-g3-lf-slabs', 'duo-g1-wt'])
+                                     'duo-c1-g3', 'duo-c2-g2', 'duo-g2-pf', 'duo-g3-lf-slabs', 'duo-g1-wt', 'chain', 'chain-slabs', 'chain-g2', 'chain-g2-slabs',
+                                     'chain-g1-fc1a', 'chain-g2-fc1b'])
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_many_segments_all_clusters(gpu, mode, variant):
     """46 folded segments (the last one zero-padded) = 3 groups: one per cluster, all three in flight on one cluster, two
@@ -480,7 +487,8 @@ def test_fused_stages_equal_unfused_bitwise(gpu, mode):
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
 
 
-@pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'duo', 'duo-g1', 'duo-g2-slabs', 'duo-c1-g3'])
+@pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'duo', 'duo-g1', 'duo-g2-slabs', 'duo-c1-g3', 'chain', 'chain-g2',
+                                     'chain-g2-slabs', 'chain-g4'])
 def test_more_segments_than_slots(gpu, variant):
     """114 segments x 264 steps (MoL) = 8 groups: two rounds at depth 1 (state buffers per round), one round at depth 2,
     three rounds of 3 on one cluster -- against the C oracle."""

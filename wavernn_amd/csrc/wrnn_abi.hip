@@ -36,8 +36,9 @@ size_t sparse_xbuf_bytes();
 hipError_t launch_put_floats(float *dst, const float *src, int n, hipStream_t stream);
 hipError_t launch_chain(const LoopArgs &args, hipStream_t stream);
 int chain_clusters(int n_cus);
-size_t chain_state_floats();
-size_t chain_xbuf_bytes();
+int chain_max_depth();
+size_t chain_state_floats(int G);
+size_t chain_xbuf_bytes(int G);
 int selftest_mfma(char *msg, size_t n);
 int selftest_allgather(int n_cus, char *msg, size_t n, float *us_per_round);
 int selftest_tanh(char *msg, size_t n);
@@ -383,6 +384,7 @@ int enqueue_progress(const wrnn_options *o, int done, int T, int n, hipStream_t 
 enum Kind { K_STREAM, K_LOOP, K_SPARSE, K_DUO, K_GENERIC, K_CHAIN };
 constexpr int DUO_TAB_FPS = 8;       // wrnn_duo_kernel: rows per segment of the per-slab aux tables: a slab covers at most (DUO_TAB_FPS - 2) hops + 1 steps
 constexpr bool DUO_AUTO = true;      // `auto` runs MoL on wrnn_duo_kernel at every depth (round 4, profiles/r04a_probe_new.json: 13.5 vs 16.6 us per step
+constexpr int CHAIN_AUTO_GROUPS = 4;   // `auto` runs MOL calls of up to this many groups (64 segments) on wrnn_chain_kernel (one group per cluster: profiles/r05g_chain_phase_clocks.log)
 constexpr int DUO_MIN_DEPTH = 1;     // with one group in flight, 17.9 vs 21.7 with two, 26.2 vs 36 with four; round 3's kernel paid off from depth 3 on)
 
 // what a call will run: kernel, split, rounds, slab length
@@ -439,17 +441,31 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
         pl->kind = K_GENERIC;
         return WRNN_OK;
     }
-    // <= 64 segments of a MOL model (one utterance of BASELINE config 2 / 3): the single-stream latency kernel, one group per 64-CU cluster
+    // wrnn_chain_kernel (MOL, 256 CUs): one workgroup per CU, one instruction stream per wave.  `auto`: <= 64 segments (one utterance of
+    // BASELINE config 2 / 3) -- one group per 64-CU cluster, a step is the latency of one chain --; on request (algo = chain) also with up
+    // to 4 groups in flight per cluster (wrnn_options.depth) and rounds beyond that
     const int ccl = chain_clusters(p->n_cus);
-    const bool chain_ok = p->mode == WRNN_MODE_MOL && ccl >= 1 && groups <= ccl;
-    if (algo == WRNN_ALGO_CHAIN && !chain_ok) {
-        set_err("wrnn_chain_kernel needs MOL, >= 256 CUs and <= %d segments (this call: %d segments, %d CUs)", 16 * (ccl > 0 ? ccl : 4), B, p->n_cus);
-        return (p->mode != WRNN_MODE_MOL || groups > 4) ? WRNN_ERR_ARG : WRNN_ERR_RESIDENCY;
+    const bool chain_hw = p->mode == WRNN_MODE_MOL && ccl >= 1;
+    if (algo == WRNN_ALGO_CHAIN && !chain_hw) {
+        set_err("wrnn_chain_kernel needs MOL and >= 256 CUs (device: %d CUs)", p->n_cus);
+        return p->mode != WRNN_MODE_MOL ? WRNN_ERR_ARG : WRNN_ERR_RESIDENCY;
     }
-    if (algo == WRNN_ALGO_CHAIN || (algo == WRNN_ALGO_AUTO && chain_ok && !p->sp_nbp)) {
-        pl->kind = K_CHAIN; pl->ncl = ccl; pl->G = 1; pl->rounds = 1; pl->per_round = B; pl->ngr_max = groups;
+    if (algo == WRNN_ALGO_CHAIN || (algo == WRNN_ALGO_AUTO && chain_hw && groups <= CHAIN_AUTO_GROUPS && !p->sp_nbp)) {
+        const int gmax = chain_max_depth();
+        int g = o->depth;
+        if (g < 1 || g > gmax) {
+            const int rounds = (groups + ccl * gmax - 1) / (ccl * gmax);
+            g = (groups + ccl * rounds - 1) / (ccl * rounds);
+            if (g < 1) g = 1;
+            if (g > gmax) g = gmax;
+        }
+        pl->kind = K_CHAIN; pl->ncl = ccl; pl->G = g;
+        pl->rounds = (groups + ccl * g - 1) / (ccl * g);
+        pl->per_round = (B + pl->rounds - 1) / pl->rounds;
+        pl->ngr_max = (pl->per_round + SEG - 1) / SEG;
+        if (pl->ngr_max > ccl * g) { pl->rounds += 1; pl->per_round = (B + pl->rounds - 1) / pl->rounds; pl->ngr_max = (pl->per_round + SEG - 1) / SEG; }
         int slab = o->slab_steps;
-        if (slab < 1) slab = 4096;
+        if (slab < 1) slab = (int)((32u << 20) / ((size_t)pl->per_round * 11 * sizeof(float) * pl->rounds));
         if (slab < 16) slab = 16;
         if (slab > 4096) slab = 4096;
         if (slab > T) slab = T;
@@ -556,7 +572,7 @@ WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frame
     const bool mol = p->mode == WRNN_MODE_MOL;
     if (pl.kind == K_LOOP || slabbed) {
         l.xbuf = o;  o = al(o + (slabbed ? duo_xbuf_bytes_max() : XBUF_FLOATS * sizeof(float)));
-        l.state = o; o = al(o + (size_t)pl.rounds * (pl.kind == K_SPARSE ? sparse_state_floats() : pl.kind == K_CHAIN ? chain_state_floats() : loop_state_floats(pl.G)) * sizeof(float));
+        l.state = o; o = al(o + (size_t)pl.rounds * (pl.kind == K_SPARSE ? sparse_state_floats() : pl.kind == K_CHAIN ? chain_state_floats(pl.G) : loop_state_floats(pl.G)) * sizeof(float));
         l.cIf = o;   if (pl.kind == K_LOOP) o = al(o + (size_t)pl.slab * pl.ngr_max * SEG * H * sizeof(float));      // (the duo kernel forms cI in the loop)
         l.npre = o;  if (mol) o = al(o + (size_t)pl.slab * 11 * B * sizeof(float));      // derived MOL noise of one slab
     } else {
@@ -817,9 +833,9 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                 // (every step re-arms the entries it will write two or three steps later), so it needs the fill only where a round starts: the first
                 // launch of a call that starts at step 0, or any launch when several rounds share the buffer
                 if (!duo) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, XBUF_FLOATS * sizeof(float), stream));
-                else if (s0 == 0 || pl.rounds > 1 || (o->tuning & 4)) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, chain ? chain_xbuf_bytes() : sparse ? sparse_xbuf_bytes() : duo_xbuf_bytes(pl.G), stream));
+                else if (s0 == 0 || pl.rounds > 1 || (o->tuning & 4)) HIPCHK(hipMemsetAsync(ws + l.xbuf, 0xFF, chain ? chain_xbuf_bytes(pl.G) : sparse ? sparse_xbuf_bytes() : duo_xbuf_bytes(pl.G), stream));
                 if (duo) HIPCHK(hipMemsetAsync(ws + l.xcc, 0, XCC_WORDS * sizeof(unsigned), stream));      // placement handshake of this launch
-                a.state = (float *)(ws + l.state) + (size_t)r * (sparse ? sparse_state_floats() : chain ? chain_state_floats() : loop_state_floats(pl.G));
+                a.state = (float *)(ws + l.state) + (size_t)r * (sparse ? sparse_state_floats() : chain ? chain_state_floats(pl.G) : loop_state_floats(pl.G));
                 a.t0 = s0; a.t1 = s1; a.cI_t0 = s0; a.rb0 = rb0; a.Btot = nr; a.NG = ngr; a.resume = s0 > 0 ? 1 : 0;
                 a.kind_tag = chain ? 4 : sparse ? 3 : (duo ? 2 : 1);
                 if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;

@@ -23,6 +23,12 @@
 //     behind the poll of h1(t + 1)); x_t as tagged 8-byte words in two entries.  The rules are wrnn_sparse.hip's (model:
 //     tests/test_sparse_exchange_model.py); what differs is who publishes what.
 //   * conditioning slabs, state between launches (4 floats per (unit, segment)), step-range continuation: as wrnn_duo.hip / wrnn_sparse.hip.
+//   * MORE THAN ONE GROUP per cluster (wrnn_options.depth = G <= 4; 65 .. 256 segments): every stage becomes a loop over the cluster's slots --
+//     gates(0) .. gates(G-1) | fc(0) .. | gh(0) .. -- so one slot's hops fly under the other slots' stages; the per-slot state of a thread (h, gh,
+//     W_ih . cI, its residual word: 8 floats) lives in LDS, the stage code exists once.  In that THROUGHPUT form (FC1A) the fc1 rows sit on the rnn1
+//     workgroups, as in wrnn_duo.hip: both XCDs of a cluster then issue the same number of MFMAs per slot-step (224 per wave) -- at the price
+//     of two more cross-XCD hops (x2, y1), which other slots hide; rnn1's workgroup i samples slot i, wave w forms the cI rows of slots w, w + 4.
+
 // Summation order per output: wrnn_duo.hip's (k ascending within a wave's quarter of K, the four quarters added in wave order).
 #include <type_traits>
 
@@ -31,24 +37,27 @@
 namespace wrnn {
 
 constexpr int CHCL = 4;                      // clusters of 64 CUs
-constexpr int CHWG = 64;                     // workgroups per cluster (one per CU): 32 x rnn1, 32 x rnn2 (+ fc1 / fc2 rows)
+constexpr int CHWG = 64;                     // workgroups per cluster (one per CU): 32 x rnn1, 32 x rnn2 (+ fc rows)
+constexpr int CHMAXG = 4;                    // slots (groups in flight) per cluster
 constexpr int CHPART = 2 * NW * 3 * 256;     // two ping-pong sets of [wave][tile 0..2][lane][4]
-constexpr int CHSTATE_WG = NT * 4 + SEG;     // saved state of a workgroup: per thread {h, gh_r, gh_z, gh_n}, then x_{t1-1} (rnn1)
-constexpr int CHSTATE_CL = CHWG * CHSTATE_WG;
+constexpr int CHSTATE_SLOT = NT * 4 + SEG;   // saved state of a workgroup's slot: per thread {h, gh_r, gh_z, gh_n}, then x_{t1-1} (rnn1)
 static_assert(CHCL * CHWG <= XCC_WORDS, "placement table");
+static_assert(CHCL * CHMAXG <= LMAXG * MAXCL, "one exchange-buffer region per (slot, cluster)");
 
 struct ChLds {
-    int off_seg, off_part, off_misc, off_prof, off_b3, off_f3, total;
+    int off_seg, off_geo, off_st, off_part, off_misc, off_prof, off_b3, off_f3, total;
 };
-__host__ __device__ inline ChLds ch_lds()
+__host__ __device__ inline ChLds ch_lds(int G)
 {
     ChLds l;
     int o = 0;
-    l.off_seg = o;  o += 64;                 // ints: 16 positions | 16 limits | 16 table-row bases of this slab | 16 mel offsets
+    l.off_seg = o;  o += G * 64;             // ints per slot: 16 positions | 16 limits | 16 table-row bases of this slab | 16 mel offsets
+    l.off_geo = o;  o += 2 * CHMAXG;         // ints: first segment (in the call) and segment count of every slot
+    l.off_st = o;   o += G * 8 * NT;         // per slot and thread: h, gh_r, gh_z, gh_n, (rnn1) W_ih . cI r z n, own cI word
     l.off_part = o; o += CHPART;
     l.off_misc = o; o += 64;                 // placement table of the cluster (ints)
     l.off_prof = o; o += 64;                 // [32] u64 phase clocks (profiling builds)
-    l.off_b3 = o;   o += 32;                 // the sampling workgroup: fc3.bias
+    l.off_b3 = o;   o += 32;                 // sampling workgroups: fc3.bias
     o = (o + 3) & ~3;
     l.off_f3 = o;   o += 2 * XT;             // ... fc3 (30 x 512 = two 16-row tiles) in A-fragment order
     l.total = o;
@@ -66,18 +75,20 @@ typedef unsigned ch_u32x2 __attribute__((ext_vector_type(2)));
     } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// One workgroup: units [16 J, 16 J + 16) of rnn1 (LA) or of rnn2 (+ rows [16 J, 16 J + 16) of fc1 and fc2).  rg = the cluster's region of the
-// exchange buffer = its group of the round.  loc_a / loc_b: the cluster's rnn1 / rnn2 workgroups were all seen on one XCD.
-// PROF (thread 0, shader clocks per segment of a step, program order): rnn1: 0 drain + wait x_{t-1}, 1 cell + publish, 2 wait h1(t), 3 gh stage,
-// 4 wait cI(t+1), 5 W_ih . cI stage, 6 cI(t+2) formed, 7 wait y2(t), 8 fc3 + sampling; rnn2: 0 drain + wait x1(t), 1 gate stage + cell + publish,
-// 2 wait x2, 3 fc1, 4 wait y1, 5 fc2, 6 wait h2 (there), 7 gh stage; 15 = steps
+// One workgroup: units [16 J, 16 J + 16) of rnn1 (LA) or of rnn2, + rows [16 J, 16 J + 16) of fc1 (FC1A: on the rnn1 workgroups, else on rnn2's)
+// and of fc2 (rnn2).  Slot i of cluster cl = group cl + ncl i of the round = region i CHCL + cl of the exchange buffer.
+// loc_a / loc_b: the cluster's rnn1 / rnn2 workgroups were all seen on one XCD.
+// PROF (thread 0, shader clocks per segment of a step, summed over the slots, program order): rnn1: 0 drain + wait x_{t-1}, 1 cell + publish,
+// 2 wait h1(t), 3 gh stage, 9 wait x2, 10 fc1 (FC1A), 4 wait cI(t+1), 5 W_ih . cI stage, 6 cI(t+2) formed, 7 wait y2(t), 8 fc3 + sampling; rnn2:
+// 0 drain + wait x1(t), 1 gate stage + cell + publish, 2 wait x2, 3 fc1 (not FC1A), 4 wait y1, 5 fc2, 6 wait h2 (there), 7 gh stage; 15 = steps
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <bool LA, bool PROF>
-__device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const int rg, const int J, const bool loc_a, const bool loc_b)
+template <bool LA, bool FC1A, bool PROF>
+__device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const int cl, const int ncl, const int J, const bool loc_a, const bool loc_b)
 {
-    const ChLds L = ch_lds();
-    float *PART = smem + L.off_part, *fc3b = smem + L.off_b3, *F3 = smem + L.off_f3;
-    int *SEGT = reinterpret_cast<int *>(smem + L.off_seg);
+    const int G = a.G;
+    const ChLds L = ch_lds(G);
+    float *PART = smem + L.off_part, *fc3b = smem + L.off_b3, *F3 = smem + L.off_f3, *ST = smem + L.off_st;
+    int *SEGT = reinterpret_cast<int *>(smem + L.off_seg), *GEO = reinterpret_cast<int *>(smem + L.off_geo);
     u64 *PROFL = reinterpret_cast<u64 *>(smem + L.off_prof);
     u64 plast = 0;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,22 +107,18 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
     const float *const mels_up = a.mels_up, *const aux_fr = a.aux_fr, *const mel_coef = a.mel_coef;
     const int mel_stage = a.mel_stage;
     const int NR = a.Btot, NGR = a.NG;
-    const int b0 = (int)(((long)rg * NR) / NGR), nb = (int)(((long)(rg + 1) * NR) / NGR) - b0;
-    const int b0g = a.rb0 + b0;
-    float *const state_wg = a.state + (size_t)rg * CHSTATE_CL + (size_t)((LA ? 0 : 32) + J) * CHSTATE_WG;
-    const bool sampler = LA && J == 0;
+    constexpr bool HAS_FC1 = LA == FC1A;                // this role owns the fc1 rows
+    float *const state_wg = a.state + ((size_t)(cl * CHWG + (LA ? 0 : 32) + J) * G) * CHSTATE_SLOT;
 
-    // ---- weights: three gate tiles of W_ih and of W_hh; rnn2: one tile of fc1 and of fc2
+    // ---- weights: three gate tiles of W_ih and of W_hh; one tile of fc1 (HAS_FC1) and of fc2 (rnn2)
     float A_ih[3][AF], A_hh[3][AF], A_fc1[AF], A_fc2[AF];
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
         load_afrag(A_ih[g], LA ? a.w_ih1 : a.w_ih2, LA ? H : H + AUX, g * H + LU * J + fi, true, kbase_lane);
         load_afrag(A_hh[g], LA ? a.w_hh1 : a.w_hh2, H, g * H + LU * J + fi, true, kbase_lane);
     }
-    if constexpr (!LA) {
-        load_afrag(A_fc1, a.fc1_w, H + AUX, LU * J + fi, true, kbase_lane);
-        load_afrag(A_fc2, a.fc2_w, H + AUX, LU * J + fi, true, kbase_lane);
-    }
+    if constexpr (HAS_FC1) load_afrag(A_fc1, a.fc1_w, H + AUX, LU * J + fi, true, kbase_lane);
+    if constexpr (!LA) load_afrag(A_fc2, a.fc2_w, H + AUX, LU * J + fi, true, kbase_lane);
     // constants of the pointwise role: rnn1: b_ih1, u1 = W_ih1 . w0 (the x_{t-1} term), w0 (rnn2's b_ih2 is inside c2f); b_hh
     float cb_r = 0.f, cb_z = 0.f, cb_n = 0.f, ux_r = 0.f, ux_z = 0.f, ux_n = 0.f, w0o = 0.f;
     if constexpr (LA) {
@@ -124,45 +131,54 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
     CondTile ct;
     if constexpr (LA) cond_tile_init(ct, a.I_cT, a.I_b, J, lane);
     for (int q = tid; q < L.off_f3; q += NT) smem[q] = 0.f;
+    __syncthreads();
+    int nact = 0;
+    for (int i = 0; i < G; ++i) {
+        const int g = cl + ncl * i;
+        if (g >= NGR) break;
+        nact = i + 1;
+        const int b0 = (int)(((long)g * NR) / NGR), nb = (int)(((long)(g + 1) * NR) / NGR) - b0;
+        if (tid == 0) { GEO[2 * i] = a.rb0 + b0; GEO[2 * i + 1] = nb; }
+        if (tid < SEG) {
+            const int sc = a.rb0 + b0 + (tid < nb ? tid : nb - 1);
+            const int pos = a.seg_pos[sc];
+            SEGT[i * 64 + tid] = pos;
+            SEGT[i * 64 + SEG + tid] = a.seg_lim[sc];
+            SEGT[i * 64 + 2 * SEG + tid] = sc * a.tab_fps - (pos + a.tab_t0) / a.hop;
+            SEGT[i * 64 + 3 * SEG + tid] = a.mel_stage ? a.seg_moff[sc] : 0;
+        }
+        // per-slot state of the thread: h, gh (fatchord_version.py:194-195: h = 0, so gh(0) = b_hh), or what the previous launch saved
+        float4 sv = make_float4(0.f, bh_r, bh_z, bh_n);
+        if (resume) sv = *reinterpret_cast<const float4 *>(state_wg + (size_t)i * CHSTATE_SLOT + tid * 4);
+        ST[(i * 8 + 0) * NT + tid] = sv.x; ST[(i * 8 + 1) * NT + tid] = sv.y; ST[(i * 8 + 2) * NT + tid] = sv.z; ST[(i * 8 + 3) * NT + tid] = sv.w;
+    }
+    const bool sampler = LA && J < nact;                // rnn1's workgroup i runs fc3 + the sampling of slot i
     if (sampler) {                                      // fc3 -> LDS (fragment order as in the pack)
         for (int q = tid; q < 2 * XT / 4; q += NT) reinterpret_cast<float4 *>(F3)[q] = reinterpret_cast<const float4 *>(a.fc3f)[q];
-    }
-    __syncthreads();
-    if (sampler && tid >= 32 && tid < 64) fc3b[tid - 32] = tid - 32 < 30 ? a.fc3_b[tid - 32] : 0.f;
-    if (tid < SEG) {
-        const int sc = b0g + (tid < nb ? tid : nb - 1);
-        const int pos = a.seg_pos[sc];
-        SEGT[tid] = pos;
-        SEGT[SEG + tid] = a.seg_lim[sc];
-        SEGT[2 * SEG + tid] = sc * a.tab_fps - (pos + a.tab_t0) / a.hop;
-        SEGT[3 * SEG + tid] = a.mel_stage ? a.seg_moff[sc] : 0;
+        if (tid < 32) fc3b[tid] = tid < 30 ? a.fc3_b[tid] : 0.f;
     }
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.xbuf, (unsigned)(DXBUF_FLOATS * 4));
     const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.c2f, 0x7FFFF000u);
     const __amdgpu_buffer_rsrc_t f1rs = make_rsrc(a.c3f, 0x7FFFF000u), f2rs = make_rsrc(a.c4f, 0x7FFFF000u);
-    const int cbase = rg * DSLOTB;
     const int voff_frag = frag_off(w, 0, lane) * 4;      // this lane's first fragment of a layer (bytes)
     const int voff_own = (((J * 64) + 16 * w + pj) * 4 + (tid & 3)) * 4;      // the layer word of (unit 16 J + pu, segment pj) = its publish position
-    const bool live = fi < nb;                           // this lane's segment exists (fragment polls)
-    const bool plive = pj < nb;                          // ... of the pointwise role
+    // which layers cross the XCDs (written through): x1 and y2 always (rnn2 / the samplers sit on the other XCD); x2 and y1 when fc1 is on rnn1
+    const bool loc_x2 = FC1A ? false : loc_b, loc_y1 = FC1A ? false : loc_b;
 
     bool dead = false;
     int pp = 0;
     int t = T0;
-    float h = 0.f, ghr = bh_r, ghz = bh_z, ghn = bh_n;   // (fatchord_version.py:194-195: h = 0, so gh(0) = b_hh)
-    float ga_r = 0.f, ga_z = 0.f, ga_n = 0.f, xo = 0.f;  // rnn1: W_ih1 . cI(t) of the thread's unit and its own cI word, formed at the end of step t - 1
-    if (resume) {
-        const float4 sv = *reinterpret_cast<const float4 *>(state_wg + tid * 4);
-        h = sv.x; ghr = sv.y; ghz = sv.z; ghn = sv.w;
-    }
+    auto cbase_of = [&](int i) { return (i * CHCL + cl) * DSLOTB; };
+    auto nb_of = [&](int i) { return GEO[2 * i + 1]; };
 
-    // one stage: the layer at byte offset `so` -> three (NT = 3) or one tile(s) of this workgroup x the group's 16 segments; the sums of the
+    // one stage: the layer at byte offset `so` -> three (NTL = 3) or one tile(s) of this workgroup x the slot's 16 segments; the sums of the
     // thread's (unit, segment) come back in s0..s2, `ownw` = the thread's own word of that layer (the residual input of the gate stages)
-    auto stage = [&](auto NTC, const float (&A0)[AF], const float (&A1)[AF], const float (&A2)[AF], int so, unsigned code, int ts, int px_wait,
+    auto stage = [&](auto NTC, const float (&A0)[AF], const float (&A1)[AF], const float (&A2)[AF], int so, int nb, unsigned code, int ts, int px_wait,
                      float &s0, float &s1, float &s2, unsigned &ownw, bool want_own) {
         constexpr int NTL = decltype(NTC)::value;
+        const bool live = fi < nb, plive = pj < nb;
         u32x4 x[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, so, 16 /* sc1 */);
@@ -195,46 +211,98 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
     };
     using N1 = std::integral_constant<int, 1>;
     using N3 = std::integral_constant<int, 3>;
-    // re-arm this wave's quarter of the workgroup's 1 KB block of `layer` in entry (t + 2) % 4 (lanes 16 slot .. 16 slot + 15)
-    auto rearm1 = [&](int layer, int slot, bool local) {
-        if (kq == slot) {
-            const u32x4 q = {SENT, SENT, SENT, SENT};
-            const int vo = layer * DLAYERB + J * 1024 + w * 256 + fi * 16, so = cbase + ((t + DAHEAD_IH) & (DRING - 1)) * XTB;
-            if (local) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, vo, so, 0);
-            else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, vo, so, 16 /* sc1 */);
+    // re-arm this wave's quarter of the workgroup's 1 KB block of `layer` of slot i in entry (t + 2) % 4 (lanes 16 q .. 16 q + 15)
+    auto rearm1 = [&](int i, int layer, int q, bool local) {
+        if (kq == q) {
+            const u32x4 sv = {SENT, SENT, SENT, SENT};
+            const int vo = layer * DLAYERB + J * 1024 + w * 256 + fi * 16, so = cbase_of(i) + ((t + DAHEAD_IH) & (DRING - 1)) * XTB;
+            if (local) __builtin_amdgcn_raw_buffer_store_b128(sv, xrs, vo, so, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(sv, xrs, vo, so, 16 /* sc1 */);
         }
     };
-    unsigned dummy = 0u;
+    // fc1 + relu (:216-218) -> y1 of slot i (this workgroup's 16 rows)
+    auto fc1_stage = [&](int i) {
+        if constexpr (HAS_FC1) {
+            const int nb = nb_of(i), sb = cbase_of(i) + (t & (DRING - 1)) * XTB;
+            const int fr = table_row(SEGT[i * 64 + pj] + t, SEGT[i * 64 + SEG + pj], SEGT[i * 64 + 2 * SEG + pj], magic, mshift, hop, zrow);
+            const float cv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(f1rs, (fr * H + prow) * 4, 0, 0));
+            float s0, s1, s2;
+            unsigned dummy = 0u;
+            stage(N1{}, A_fc1, A_fc1, A_fc1, sb + 6 * DLAYERB, nb, 0x801u, t, LA ? 9 : 2, s0, s1, s2, dummy, false);
+            publish4l(xrs, sb + 2 * DLAYERB + J * 1024, tid, fmaxf(s0 + cv, 0.f), pj < nb, loc_y1);
+            CHX(LA ? 10 : 3);
+        }
+    };
+    // gh(t + 1) = W_hh . h(t) + b_hh of slot i: stays with the thread
+    auto gh_stage = [&](int i) {
+        float s0, s1, s2;
+        unsigned dummy = 0u;
+        stage(N3{}, A_hh[0], A_hh[1], A_hh[2], cbase_of(i) + (LA ? 0 : 1) * DLAYERB + (t & (DRING - 1)) * XTB, nb_of(i), 0x840u | (LA ? 0u : 8u), t, LA ? 2 : 6, s0, s1, s2,
+              dummy, false);
+        ST[(i * 8 + 1) * NT + tid] = s0 + bh_r; ST[(i * 8 + 2) * NT + tid] = s1 + bh_z; ST[(i * 8 + 3) * NT + tid] = s2 + bh_n;
+        CHX(LA ? 3 : 7);
+    };
 
     if (PROF && tid == 0) plast = __builtin_amdgcn_s_memtime();
     if constexpr (LA) {
         // ---------------- rnn1 ----------------
-        auto cond_step = [&](int tt) {                  // wave 0: cI(tt) of the workgroup's 16 rows (fatchord_version.py:203-209 without the x_{t-1} column)
-            if (w == 0) {
-                const int p = SEGT[fi] + tt;
-                const bool valid = live && p < SEGT[SEG + fi];
+        auto cond_step = [&](int tt) {                  // wave w: cI(tt) of the workgroup's 16 rows for slots w, w + 4 (fatchord_version.py:203-209 without the x_{t-1} column)
+#pragma unroll 1
+            for (int i = w; i < nact; i += NW) {
+                const int p = SEGT[i * 64 + fi] + tt;
+                const bool valid = fi < nb_of(i) && p < SEGT[i * 64 + SEG + fi];
                 const int fr = magic ? (int)(__umulhi((unsigned)p, magic) >> mshift) : p / hop;
                 f32x4 v;
                 if (mel_stage) {
-                    const int j = p + SEGT[3 * SEG + fi];
+                    const int j = p + SEGT[i * 64 + 3 * SEG + fi];
                     const int row = j / LAST_SCALE;
                     v = cond_tile_rows(ct, mels_up + (size_t)(row - 1) * MEL, mel_coef + 3 * (j - row * LAST_SCALE), aux_fr + (size_t)fr * (4 * AUX), valid, lane);
                 } else v = cond_tile(ct, mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane);
                 const u32x4 q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                const int so = cbase + 4 * DLAYERB + (tt & (DRING - 1)) * XTB;
+                const int so = cbase_of(i) + 4 * DLAYERB + (tt & (DRING - 1)) * XTB;
                 if (loc_a) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 0);
                 else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 16 /* sc1 */);
             }
         };
-        auto front = [&](int ts) {                      // W_ih1 . cI(ts) + the thread's own cI word (xi - w0 x)
+        auto front = [&](int i, int ts) {               // W_ih1 . cI(ts) of slot i + the thread's own cI word (xi - w0 x)
             unsigned ow = 0u;
             float s0, s1, s2;
-            stage(N3{}, A_ih[0], A_ih[1], A_ih[2], cbase + 4 * DLAYERB + (ts & (DRING - 1)) * XTB, 0x820u, ts, 4, s0, s1, s2, ow, true);
-            ga_r = s0; ga_z = s1; ga_n = s2; xo = __uint_as_float(ow);
+            stage(N3{}, A_ih[0], A_ih[1], A_ih[2], cbase_of(i) + 4 * DLAYERB + (ts & (DRING - 1)) * XTB, nb_of(i), 0x820u, ts, 4, s0, s1, s2, ow, true);
+            ST[(i * 8 + 4) * NT + tid] = s0; ST[(i * 8 + 5) * NT + tid] = s1; ST[(i * 8 + 6) * NT + tid] = s2; ST[(i * 8 + 7) * NT + tid] = __uint_as_float(ow);
             CHX(5);
         };
-        auto sample = [&]() {
-            const int sb = cbase + (t & (DRING - 1)) * XTB;
+        auto back = [&](int i) {                        // the chain: sampling of slot i -> here
+            const int nb = nb_of(i), cb = cbase_of(i);
+            const bool plive = pj < nb;
+            float xv = 0.f;
+            if (t > T0) {                               // x_{t-1}: a tagged word {x, tag = t} from the slot's sampling workgroup
+                const int sx = cb + 7 * DLAYERB + ((t - 1) & 1) * XTB;
+                ch_u32x2 xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, pj * 8, sx, 16 /* sc1 */);
+                if (__builtin_expect(__any(plive && xq.y != (unsigned)t), 0))
+                    wait_for([&] { return !__any(plive && xq.y != (unsigned)t); }, [&] { xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, pj * 8, sx, 16 /* sc1 */); },
+                             status, dead, 0x830u, t);
+                xv = __uint_as_float(xq.x);
+            } else if (resume) xv = state_wg[(size_t)i * CHSTATE_SLOT + NT * 4 + pj];
+            CHX(0);
+            // the GRU cell of (unit 16 J + pu, segment pj) (ATen gru_cell; hardware exp / rcp as the duo kernel's MoL path) -> x1 (to rnn2's XCD), h1
+            const float gir = ST[(i * 8 + 4) * NT + tid] + fmaf(xv, ux_r, cb_r), giz = ST[(i * 8 + 5) * NT + tid] + fmaf(xv, ux_z, cb_z),
+                        gin = ST[(i * 8 + 6) * NT + tid] + fmaf(xv, ux_n, cb_n);
+            const float xin = fmaf(w0o, xv, ST[(i * 8 + 7) * NT + tid]);      // xi of the owned unit (:208-209)
+            const float h = gru_update_fast(gir, giz, gin, ST[(i * 8 + 1) * NT + tid], ST[(i * 8 + 2) * NT + tid], ST[(i * 8 + 3) * NT + tid], ST[(i * 8 + 0) * NT + tid]);
+            ST[(i * 8 + 0) * NT + tid] = h;
+            const int sb = cb + (t & (DRING - 1)) * XTB;
+            publish4l(xrs, sb + 5 * DLAYERB + J * 1024, tid, xin + h, plive, false);      // x1 = xi + h1 (:212)
+            publish4l(xrs, sb + 0 * DLAYERB + J * 1024, tid, h, plive, loc_a);
+            // ring hygiene: behind the poll of x_{t-1}, which needed everything of step t - 1: every reader is past the data of step t - 2
+            rearm1(i, 0, 0, loc_a);
+            rearm1(i, 5, 1, false);
+            if constexpr (FC1A) rearm1(i, 2, 2, false);
+            CHX(1);
+        };
+        auto sample = [&](int i) {
+            const int nb = nb_of(i), b0g = GEO[2 * i], cb = cbase_of(i);
+            const bool live = fi < nb, plive = pj < nb;
+            const int sb = cb + (t & (DRING - 1)) * XTB;
             u32x4 x[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 3 * DLAYERB, 16 /* sc1 */);
@@ -273,8 +341,8 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
                     outp[(size_t)(b0g + su) * Tall + t] = xv;
                     if (forcex) xv = forcex[(size_t)(b0g + su) * Tall + t];
                     const ch_u32x2 q = {__float_as_uint(xv), (unsigned)t + 1u};       // one 8-byte word {x_t, tag}: its own flag, two entries, no re-arm
-                    if (loc_a) __builtin_amdgcn_raw_buffer_store_b64(q, xrs, su * 8, cbase + 7 * DLAYERB + (t & 1) * XTB, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b64(q, xrs, su * 8, cbase + 7 * DLAYERB + (t & 1) * XTB, 16 /* sc1 */);
+                    if (loc_a) __builtin_amdgcn_raw_buffer_store_b64(q, xrs, su * 8, cb + 7 * DLAYERB + (t & 1) * XTB, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b64(q, xrs, su * 8, cb + 7 * DLAYERB + (t & 1) * XTB, 16 /* sc1 */);
                 }
             }
             pp ^= 1;
@@ -283,115 +351,107 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
 
         cond_step(T0);                                  // the two steps a launch starts with; every later cI is formed at the end of step t for t + 2
         if (T0 + 1 < T1) cond_step(T0 + 1);
-        front(T0);
+#pragma unroll 1
+        for (int i = 0; i < nact; ++i) front(i, T0);
         for (; t < T1; ++t) {
             if (PROF && tid == 0) PROFL[15] += 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // last step's re-arm stores and the cI formed at its end are out before this step publishes
-            float xv = 0.f;
-            if (t > T0) {                               // x_{t-1}: a tagged word {x, tag = t} from this cluster's sampling workgroup
-                const int sx = cbase + 7 * DLAYERB + ((t - 1) & 1) * XTB;
-                ch_u32x2 xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, pj * 8, sx, 16 /* sc1 */);
-                if (__builtin_expect(__any(plive && xq.y != (unsigned)t), 0))
-                    wait_for([&] { return !__any(plive && xq.y != (unsigned)t); }, [&] { xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, pj * 8, sx, 16 /* sc1 */); },
-                             status, dead, 0x830u, t);
-                xv = __uint_as_float(xq.x);
-            } else if (resume) xv = state_wg[NT * 4 + pj];
-            CHX(0);
-            {   // the GRU cell of (unit 16 J + pu, segment pj) (ATen gru_cell; hardware exp / rcp as the duo kernel's MoL path) -> x1 (to rnn2's XCD), h1
-                const float gir = ga_r + fmaf(xv, ux_r, cb_r), giz = ga_z + fmaf(xv, ux_z, cb_z), gin = ga_n + fmaf(xv, ux_n, cb_n);
-                const float xin = fmaf(w0o, xv, xo);    // xi of the owned unit (:208-209)
-                h = gru_update_fast(gir, giz, gin, ghr, ghz, ghn, h);
-                const int sb = cbase + (t & (DRING - 1)) * XTB;
-                publish4l(xrs, sb + 5 * DLAYERB + J * 1024, tid, xin + h, plive, false);      // x1 = xi + h1 (:212)
-                publish4l(xrs, sb + 0 * DLAYERB + J * 1024, tid, h, plive, loc_a);
+#pragma unroll 1
+            for (int i = 0; i < nact; ++i) back(i);
+#pragma unroll 1
+            for (int i = 0; i < nact; ++i) gh_stage(i); // (needs h1(t) of every rnn1 workgroup: one hop behind the publications above)
+            if constexpr (FC1A) {
+#pragma unroll 1
+                for (int i = 0; i < nact; ++i) fc1_stage(i);
             }
-            rearm1(0, 0, loc_a);                        // (behind the poll of x_{t-1}, which needed everything of step t - 1: every reader is past step t - 2)
-            rearm1(5, 1, false);
-            CHX(1);
-            {   // gh(t + 1) = W_hh . h1(t) + b_hh: one hop behind the publication above, long before anything else is due
-                float s0, s1, s2;
-                stage(N3{}, A_hh[0], A_hh[1], A_hh[2], cbase + 0 * DLAYERB + (t & (DRING - 1)) * XTB, 0x840u, t, 2, s0, s1, s2, dummy, false);
-                ghr = s0 + bh_r; ghz = s1 + bh_z; ghn = s2 + bh_n;
-                CHX(3);
+            if (t + 1 < T1) {
+#pragma unroll 1
+                for (int i = 0; i < nact; ++i) front(i, t + 1);
             }
-            if (t + 1 < T1) front(t + 1);
             if (t + 2 < T1) { cond_step(t + 2); CHX(6); }
-            if (sampler) sample();
+            if (sampler) sample(J);
         }
-        // ---- what the next launch needs: x_{T1-1}; the sentinel in the cI entries of steps T1 and T1 + 1 (its first two steps are polled)
-        {
-            const int sx = cbase + 7 * DLAYERB + ((T1 - 1) & 1) * XTB;
+        // ---- what the next launch needs: x_{T1-1} of every slot; the sentinel in the cI entries of steps T1 and T1 + 1 (its first two steps are polled)
+#pragma unroll 1
+        for (int i = 0; i < nact; ++i) {
+            const int nb = nb_of(i);
+            const int sx = cbase_of(i) + 7 * DLAYERB + ((T1 - 1) & 1) * XTB;
             ch_u32x2 xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, fi * 8, sx, 16 /* sc1 */);
-            wait_for([&] { return !__any(live && xq.y != (unsigned)T1); }, [&] { xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, fi * 8, sx, 16 /* sc1 */); },
+            wait_for([&] { return !__any(fi < nb && xq.y != (unsigned)T1); }, [&] { xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, fi * 8, sx, 16 /* sc1 */); },
                      status, dead, 0x861u, T1);
-            if (tid < SEG) state_wg[NT * 4 + tid] = live ? __uint_as_float(xq.x) : 0.f;
-            if (w == 0) {
-                const u32x4 q = {SENT, SENT, SENT, SENT};
+            if (tid < SEG) state_wg[(size_t)i * CHSTATE_SLOT + NT * 4 + tid] = fi < nb ? __uint_as_float(xq.x) : 0.f;
+        }
+#pragma unroll 1
+        for (int i = w; i < nact; i += NW) {
+            const u32x4 q = {SENT, SENT, SENT, SENT};
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    if (loc_a) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, cbase + 4 * DLAYERB + ((T1 + e) & (DRING - 1)) * XTB, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, cbase + 4 * DLAYERB + ((T1 + e) & (DRING - 1)) * XTB, 16 /* sc1 */);
-                }
+            for (int e = 0; e < 2; ++e) {
+                const int so = cbase_of(i) + 4 * DLAYERB + ((T1 + e) & (DRING - 1)) * XTB;
+                if (loc_a) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 16 /* sc1 */);
             }
         }
     } else {
-        // ---------------- rnn2 (+ fc1, fc2) ----------------
+        // ---------------- rnn2 (+ fc2; fc1 unless FC1A) ----------------
+        auto gates = [&](int i) {                       // the whole gate stage is on the slot's chain (x1 -> here)
+            const int nb = nb_of(i), sb = cbase_of(i) + (t & (DRING - 1)) * XTB;
+            const int fr = table_row(SEGT[i * 64 + pj] + t, SEGT[i * 64 + SEG + pj], SEGT[i * 64 + 2 * SEG + pj], magic, mshift, hop, zrow);
+            const int vo = (fr * 3 * H + prow) * 4;
+            const float c0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, 0, 0));
+            const float c1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, H * 4, 0));
+            const float c2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, 2 * H * 4, 0));
+            unsigned ow = 0u;
+            float s0, s1, s2;
+            stage(N3{}, A_ih[0], A_ih[1], A_ih[2], sb + 5 * DLAYERB, nb, 0x828u, t, 0, s0, s1, s2, ow, true);
+            const float h = gru_update_fast(s0 + c0, s1 + c1, s2 + c2, ST[(i * 8 + 1) * NT + tid], ST[(i * 8 + 2) * NT + tid], ST[(i * 8 + 3) * NT + tid], ST[(i * 8 + 0) * NT + tid]);
+            ST[(i * 8 + 0) * NT + tid] = h;
+            publish4l(xrs, sb + 6 * DLAYERB + J * 1024, tid, __uint_as_float(ow) + h, pj < nb, loc_x2);      // x2 = x1 + h2 (:216)
+            publish4l(xrs, sb + 1 * DLAYERB + J * 1024, tid, h, pj < nb, loc_b);
+            CHX(1);
+        };
+        auto fc2_stage = [&](int i) {                   // fc2 + relu (:220-221) -> y2 (to the sampling workgroup on the other XCD)
+            const int nb = nb_of(i), sb = cbase_of(i) + (t & (DRING - 1)) * XTB;
+            const int fr = table_row(SEGT[i * 64 + pj] + t, SEGT[i * 64 + SEG + pj], SEGT[i * 64 + 2 * SEG + pj], magic, mshift, hop, zrow);
+            const float cv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(f2rs, (fr * H + prow) * 4, 0, 0));
+            float s0, s1, s2;
+            unsigned dummy = 0u;
+            stage(N1{}, A_fc2, A_fc2, A_fc2, sb + 2 * DLAYERB, nb, 0x802u, t, 4, s0, s1, s2, dummy, false);
+            publish4l(xrs, sb + 3 * DLAYERB + J * 1024, tid, fmaxf(s0 + cv, 0.f), pj < nb, false);
+            // ring hygiene: behind the last poll of the slot's step (y1(t): everybody is past the readers of step t - 2) and behind the publication
+            rearm1(i, 1, 0, loc_b);
+            rearm1(i, 6, 1, loc_x2);
+            if constexpr (!FC1A) rearm1(i, 2, 2, loc_y1);
+            rearm1(i, 3, 3, false);
+            CHX(5);
+        };
         for (; t < T1; ++t) {
             if (PROF && tid == 0) PROFL[15] += 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int sb = cbase + (t & (DRING - 1)) * XTB;
-            const int fr = table_row(SEGT[pj] + t, SEGT[SEG + pj], SEGT[2 * SEG + pj], magic, mshift, hop, zrow);
-            {   // the gate stage: the whole of it is on the chain (x1 -> here)
-                const int vo = (fr * 3 * H + prow) * 4;
-                const float c0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, 0, 0));
-                const float c1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, H * 4, 0));
-                const float c2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, 2 * H * 4, 0));
-                unsigned ow = 0u;
-                float s0, s1, s2;
-                stage(N3{}, A_ih[0], A_ih[1], A_ih[2], sb + 5 * DLAYERB, 0x828u, t, 0, s0, s1, s2, ow, true);
-                h = gru_update_fast(s0 + c0, s1 + c1, s2 + c2, ghr, ghz, ghn, h);
-                publish4l(xrs, sb + 6 * DLAYERB + J * 1024, tid, __uint_as_float(ow) + h, plive, loc_b);      // x2 = x1 + h2 (:216)
-                publish4l(xrs, sb + 1 * DLAYERB + J * 1024, tid, h, plive, loc_b);
-                CHX(1);
+#pragma unroll 1
+            for (int i = 0; i < nact; ++i) gates(i);
+            if constexpr (!FC1A) {
+#pragma unroll 1
+                for (int i = 0; i < nact; ++i) fc1_stage(i);
             }
-            {   // fc1 + relu (:216-218) -> y1
-                const float cv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(f1rs, (fr * H + prow) * 4, 0, 0));
-                float s0, s1, s2;
-                stage(N1{}, A_fc1, A_fc1, A_fc1, sb + 6 * DLAYERB, 0x801u, t, 2, s0, s1, s2, dummy, false);
-                publish4l(xrs, sb + 2 * DLAYERB + J * 1024, tid, fmaxf(s0 + cv, 0.f), plive, loc_b);
-                CHX(3);
-            }
-            {   // fc2 + relu (:220-221) -> y2 (to the sampling workgroup on the other XCD)
-                const float cv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(f2rs, (fr * H + prow) * 4, 0, 0));
-                float s0, s1, s2;
-                stage(N1{}, A_fc2, A_fc2, A_fc2, sb + 2 * DLAYERB, 0x802u, t, 4, s0, s1, s2, dummy, false);
-                publish4l(xrs, sb + 3 * DLAYERB + J * 1024, tid, fmaxf(s0 + cv, 0.f), plive, false);
-                // ring hygiene: behind the last poll of the step (y1(t): everybody is past step t - 1's readers of step t - 2) and behind the publication
-                rearm1(1, 0, loc_b);
-                rearm1(6, 1, loc_b);
-                rearm1(2, 2, loc_b);
-                rearm1(3, 3, false);
-                CHX(5);
-            }
-            {   // gh(t + 1) = W_hh . h2(t) + b_hh: h2(t) arrived with x2(t); needed at the cell of step t + 1 -- under the sampling and the x_t / x1 hops
-                float s0, s1, s2;
-                stage(N3{}, A_hh[0], A_hh[1], A_hh[2], sb + 1 * DLAYERB, 0x848u, t, 6, s0, s1, s2, dummy, false);
-                ghr = s0 + bh_r; ghz = s1 + bh_z; ghn = s2 + bh_n;
-                CHX(7);
-            }
+#pragma unroll 1
+            for (int i = 0; i < nact; ++i) fc2_stage(i);
+#pragma unroll 1
+            for (int i = 0; i < nact; ++i) gh_stage(i); // (h2(t) arrived with x2(t); needed at the cell of step t + 1: under the sampling and the x_t / x1 hops)
         }
     }
     if (PROF && tid == 0 && a.prof) {
         for (int k = 0; k < 16; ++k) a.prof[(size_t)(blockIdx.x & 255) * 32 + k] += PROFL[k];
     }
-    *reinterpret_cast<float4 *>(state_wg + tid * 4) = make_float4(h, ghr, ghz, ghn);
+    for (int i = 0; i < nact; ++i)
+        *reinterpret_cast<float4 *>(state_wg + (size_t)i * CHSTATE_SLOT + tid * 4) =
+            make_float4(ST[(i * 8 + 0) * NT + tid], ST[(i * 8 + 1) * NT + tid], ST[(i * 8 + 2) * NT + tid], ST[(i * 8 + 3) * NT + tid]);
 }
 #undef CHX
 
 // Grid = 4 clusters x 64 workgroups of 256 threads (one per CU), cooperative launch; a cluster without a group leaves at once.  Placement
 // (speed only, verified at run time): block b is observed to run on XCD b % 8; cluster cl = XCDs 2 cl (its rnn1 workgroups) and 2 cl + 1
-// (rnn2, fc1, fc2); the 32 blocks of an XCD: unit blocks J = 0 .. 31.
-template <bool PROF>
+// (rnn2 + fc2, and fc1 in the latency form); the 32 blocks of an XCD: unit blocks J = 0 .. 31.
+template <bool FC1A, bool PROF>
 __global__ __launch_bounds__(NT, 1) void wrnn_chain_kernel(const LoopArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -403,7 +463,7 @@ __global__ __launch_bounds__(NT, 1) void wrnn_chain_kernel(const LoopArgs a)
     const int wgi = layer * 32 + J;
     bool loc_a = false, loc_b = false;
     {   // placement handshake (as wrnn_duo.hip): a half of the cluster seen on ONE XCD exchanges its own layers through that XCD's L2 with plain stores
-        int *TAB = reinterpret_cast<int *>(smem) + ch_lds().off_misc;
+        int *TAB = reinterpret_cast<int *>(smem) + ch_lds(a.G).off_misc;
         const int tid = threadIdx.x;
         unsigned *tab = a.xcc_tab + cl * CHWG;
         if (tid == 0) {
@@ -428,20 +488,25 @@ __global__ __launch_bounds__(NT, 1) void wrnn_chain_kernel(const LoopArgs a)
         if (a.tuning & 256) { loc_a = false; loc_b = false; }       // A/B: everything written through
         __syncthreads();
     }
-    if (layer == 0) ch_role<true, PROF>(a, smem, cl, J, loc_a, loc_b);
-    else ch_role<false, PROF>(a, smem, cl, J, loc_a, loc_b);
+    const int ncl = CHCL;
+    if (layer == 0) ch_role<true, FC1A, PROF>(a, smem, cl, ncl, J, loc_a, loc_b);
+    else ch_role<false, FC1A, PROF>(a, smem, cl, ncl, J, loc_a, loc_b);
 }
 
 int chain_clusters(int n_cus) { return n_cus >= CHCL * CHWG ? CHCL : 0; }
-size_t chain_state_floats() { return (size_t)CHCL * CHSTATE_CL; }
-size_t chain_xbuf_bytes() { return (size_t)CHCL * DSLOTB; }
+int chain_max_depth() { return CHMAXG; }
+size_t chain_state_floats(int G) { return (size_t)CHCL * CHWG * G * CHSTATE_SLOT; }
+size_t chain_xbuf_bytes(int G) { return (size_t)G * CHCL * DSLOTB; }
 
+// G = 1: the latency form (fc1 beside rnn2); G >= 2: the throughput form (fc1 on the rnn1 workgroups); wrnn_options.tuning bit 4 / bit 5 force one
 hipError_t launch_chain(const LoopArgs &args, hipStream_t stream)
 {
-    if (!args.fc3f || !args.u1 || !args.xcc_tab || args.NG < 1 || args.NG > CHCL) return hipErrorInvalidValue;
-    const size_t lds = (size_t)ch_lds().total * sizeof(float);
+    if (!args.fc3f || !args.u1 || !args.xcc_tab || args.NG < 1 || args.G < 1 || args.G > CHMAXG || args.NG > CHCL * args.G) return hipErrorInvalidValue;
+    const size_t lds = (size_t)ch_lds(args.G).total * sizeof(float);
     const bool prof = args.prof && !(args.tuning & 64);
-    const void *fn = prof ? (const void *)wrnn_chain_kernel<true> : (const void *)wrnn_chain_kernel<false>;
+    const bool fc1a = (args.tuning & 16) ? true : ((args.tuning & 32) ? false : args.G >= 2);
+    const void *fn = fc1a ? (prof ? (const void *)wrnn_chain_kernel<true, true> : (const void *)wrnn_chain_kernel<true, false>)
+                          : (prof ? (const void *)wrnn_chain_kernel<false, true> : (const void *)wrnn_chain_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     LoopArgs a = args;
