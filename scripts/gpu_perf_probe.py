@@ -39,7 +39,6 @@ VARS = {'auto': dict(algo='auto'), 'stream': dict(algo='stream'), 'g1': dict(alg
         'c1g1': dict(algo='loop', clusters=1, depth=1), 'c2g1': dict(algo='loop', clusters=2, depth=1), 'c1g2': dict(algo='loop', clusters=1, depth=2),
         'nola': dict(algo='loop', tuning=1), 'fence': dict(algo='loop', tuning=2), 'nola-fence': dict(algo='loop', tuning=3),
         'c1': dict(algo='chain', depth=1), 'c2': dict(algo='chain', depth=2), 'c3': dict(algo='chain', depth=3), 'c4': dict(algo='chain', depth=4),
-        'c1a': dict(algo='chain', depth=1, tuning=16), 'c2b': dict(algo='chain', depth=2, tuning=32), 'c4b': dict(algo='chain', depth=4, tuning=32),
         's1': dict(algo='sparse'), 'swt': dict(algo='sparse', tuning=256),       # wrnn_sparse_kernel (needs --prune); swt: every layer written through
         # wrnn_duo_kernel (round 4): tuning bit 0 = loads first, bit 1 = publish first (default: by depth), bit 8 = every layer written through
         # (no XCD-local plain stores), bit 2 = ring re-filled before every launch

@@ -90,12 +90,10 @@ VARIANTS = {
     'chain': dict(algo='chain'),
     'chain-slabs': dict(algo='chain', slab_steps=97),
     'chain-wt': dict(algo='chain', tuning=256),
-    # ... with several groups in flight per cluster (the throughput form: fc1 on the rnn1 workgroups), and both fc1 placements forced
+    # ... with several groups in flight per cluster
     'chain-g2': dict(algo='chain', depth=2),
     'chain-g2-slabs': dict(algo='chain', depth=2, slab_steps=97),
     'chain-g4': dict(algo='chain', depth=4, slab_steps=131),
-    'chain-g1-fc1a': dict(algo='chain', depth=1, tuning=16),
-    'chain-g2-fc1b': dict(algo='chain', depth=2, tuning=32),
 }
 KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'loop': 'wrnn_loop_kernel', 'sparse': 'wrnn_sparse_kernel', 'duo': 'wrnn_duo_kernel', 'chain': 'wrnn_chain_kernel'}
 
@@ -448,8 +446,7 @@ def test_generate_end_to_end(gpu, name, pre, tmp_path):
 
 
 @pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'loop-c2-g2', 'loop-c1-g3-nofuse', 'duo', 'duo-g1', 'duo-g2-slabs',
-                                     'duo-c1-g3', 'duo-c2-g2', 'duo-g2-pf', 'duo-g3-lf-slabs', 'duo-g1-wt', 'chain', 'chain-slabs', 'chain-g2', 'chain-g2-slabs',
-                                     'chain-g1-fc1a', 'chain-g2-fc1b'])
+                                     'duo-c1-g3', 'duo-c2-g2', 'duo-g2-pf', 'duo-g3-lf-slabs', 'duo-g1-wt', 'chain', 'chain-slabs', 'chain-g2', 'chain-g2-slabs'])
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_many_segments_all_clusters(gpu, mode, variant):
     """46 folded segments (the last one zero-padded) = 3 groups: one per cluster, all three in flight on one cluster, two
@@ -743,7 +740,7 @@ def test_full_size_loop_kernel_vs_stream(gpu):
     noise = torch.empty(T, 11 * B).uniform_(1e-5, 1 - 1e-5, generator=torch.Generator().manual_seed(6)).to(gpu)
     eng = LoopEngine(sd, 'MOL', device=gpu)
     a = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='auto').cpu().numpy()
-    assert eng.last_loop_kernel() == 'wrnn_duo_kernel' and eng.last_loop_split() == (16, 4, 2)      # round 4: `auto` runs MoL on the duo kernel at every depth
+    assert eng.last_loop_kernel() == 'wrnn_chain_kernel' and eng.last_loop_split() == (16, 4, 2)    # round 5: <= 128 segments of a MoL model run on wrnn_chain_kernel
     ms = eng.last_loop_ms()
     print(eng.last_run_info())
     b = eng.run(mels_up, aux, B, T, stride, noise, hop, algo='auto').cpu().numpy()

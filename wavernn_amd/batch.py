@@ -78,9 +78,10 @@ def shard_bounds(n_segments: int, world: int, active: Optional[int] = None):
     return [((r * n_segments) // active, ((r + 1) * n_segments) // active) if r < active else (n_segments, n_segments) for r in range(world)]
 
 
-#: measured step time (us) of the dense loop kernel by groups in flight per cluster (4 clusters x depth x 16 segments per GPU; one MI355X,
-#: profiles/r04p_probe.json): what `choose_ranks` weighs a split with
-STEP_US_BY_DEPTH = {1: 12.2, 2: 16.9, 3: 20.9, 4: 23.7, 5: 28.0, 6: 32.0, 7: 36.5, 8: 40.5}
+#: measured step time (us) of the dense loop kernels by groups in flight per cluster (4 clusters x depth x 16 segments per GPU; one MI355X:
+#: wrnn_chain_kernel at depth 1-2, wrnn_duo_kernel from 3 on; profiles/r05i_probe_chain_depths.json, r04p_probe.json): what
+#: `choose_ranks` weighs a split with
+STEP_US_BY_DEPTH = {1: 10.4, 2: 13.8, 3: 19.8, 4: 23.5, 5: 28.0, 6: 32.0, 7: 36.5, 8: 40.5}
 
 
 def estimate_step_us(n_segments: int) -> float:

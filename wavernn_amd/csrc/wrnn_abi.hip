@@ -384,7 +384,8 @@ int enqueue_progress(const wrnn_options *o, int done, int T, int n, hipStream_t 
 enum Kind { K_STREAM, K_LOOP, K_SPARSE, K_DUO, K_GENERIC, K_CHAIN };
 constexpr int DUO_TAB_FPS = 8;       // wrnn_duo_kernel: rows per segment of the per-slab aux tables: a slab covers at most (DUO_TAB_FPS - 2) hops + 1 steps
 constexpr bool DUO_AUTO = true;      // `auto` runs MoL on wrnn_duo_kernel at every depth (round 4, profiles/r04a_probe_new.json: 13.5 vs 16.6 us per step
-constexpr int CHAIN_AUTO_GROUPS = 4;   // `auto` runs MOL calls of up to this many groups (64 segments) on wrnn_chain_kernel (one group per cluster: profiles/r05g_chain_phase_clocks.log)
+constexpr int CHAIN_AUTO_GROUPS = 8;   // `auto` runs MOL calls of up to this many groups (128 segments) on wrnn_chain_kernel: one / two groups per cluster, 10.4 / 13.8 us
+                                       // per step against wrnn_duo_kernel's 12.2 / 16.9; from three groups on the duo kernel wins (profiles/r05i_probe_chain_depths.json)
 constexpr int DUO_MIN_DEPTH = 1;     // with one group in flight, 17.9 vs 21.7 with two, 26.2 vs 36 with four; round 3's kernel paid off from depth 3 on)
 
 // what a call will run: kernel, split, rounds, slab length
@@ -441,9 +442,9 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
         pl->kind = K_GENERIC;
         return WRNN_OK;
     }
-    // wrnn_chain_kernel (MOL, 256 CUs): one workgroup per CU, one instruction stream per wave.  `auto`: <= 64 segments (one utterance of
-    // BASELINE config 2 / 3) -- one group per 64-CU cluster, a step is the latency of one chain --; on request (algo = chain) also with up
-    // to 4 groups in flight per cluster (wrnn_options.depth) and rounds beyond that
+    // wrnn_chain_kernel (MOL, 256 CUs): one workgroup per CU, one instruction stream per wave.  `auto`: <= 128 segments -- <= 64 (one utterance
+    // of BASELINE config 2 / 3): one group per 64-CU cluster, a step is the latency of one chain; <= 128: two groups per cluster --; on
+    // request (algo = chain) also with up to 4 groups in flight per cluster (wrnn_options.depth) and rounds beyond that
     const int ccl = chain_clusters(p->n_cus);
     const bool chain_hw = p->mode == WRNN_MODE_MOL && ccl >= 1;
     if (algo == WRNN_ALGO_CHAIN && !chain_hw) {

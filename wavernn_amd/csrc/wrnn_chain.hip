@@ -23,12 +23,12 @@
 //     behind the poll of h1(t + 1)); x_t as tagged 8-byte words in two entries.  The rules are wrnn_sparse.hip's (model:
 //     tests/test_sparse_exchange_model.py); what differs is who publishes what.
 //   * conditioning slabs, state between launches (4 floats per (unit, segment)), step-range continuation: as wrnn_duo.hip / wrnn_sparse.hip.
-//   * MORE THAN ONE GROUP per cluster (wrnn_options.depth = G <= 4; 65 .. 256 segments): every stage becomes a loop over the cluster's slots --
-//     gates(0) .. gates(G-1) | fc(0) .. | gh(0) .. -- so one slot's hops fly under the other slots' stages; the per-slot state of a thread (h, gh,
-//     W_ih . cI, its residual word: 8 floats) lives in LDS, the stage code exists once.  In that THROUGHPUT form (FC1A) the fc1 rows sit on the rnn1
-//     workgroups, as in wrnn_duo.hip: both XCDs of a cluster then issue the same number of MFMAs per slot-step (224 per wave) -- at the price
-//     of two more cross-XCD hops (x2, y1), which other slots hide; rnn1's workgroup i samples slot i, wave w forms the cI rows of slots w, w + 4.
-
+//   * TWO (up to four) groups per cluster (wrnn_options.depth; `auto`: 65 .. 128 segments): every stage becomes a loop over the cluster's slots --
+//     gates(0) gates(1) | fc1(0) fc1(1) | fc2(0) .. | gh(0) .. -- so one slot's hops fly under the other slot's stages; the per-slot state of a
+//     thread (h, gh, W_ih . cI, its residual word: 8 floats) lives in LDS, the stage code exists once; rnn1's workgroup i samples slot i, wave w
+//     forms the cI rows of slots w, w + 4.  Measured (profiles/r05i_probe_chain_depths.json): 13.8 us per step for 128 segments (wrnn_duo_kernel:
+//     16.9); with three / four slots the single instruction stream per SIMD loses to the duo kernel's two (21.8 / 27.8 vs 19.8 / 23.5 us), and
+//     so does moving the fc1 rows to the rnn1 workgroups to balance the MFMA count of the two XCDs (15.7 us at two slots: two more cross-XCD hops).
 // Summation order per output: wrnn_duo.hip's (k ascending within a wave's quarter of K, the four quarters added in wave order).
 #include <type_traits>
 
@@ -75,14 +75,13 @@ typedef unsigned ch_u32x2 __attribute__((ext_vector_type(2)));
     } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// One workgroup: units [16 J, 16 J + 16) of rnn1 (LA) or of rnn2, + rows [16 J, 16 J + 16) of fc1 (FC1A: on the rnn1 workgroups, else on rnn2's)
-// and of fc2 (rnn2).  Slot i of cluster cl = group cl + ncl i of the round = region i CHCL + cl of the exchange buffer.
+// One workgroup: units [16 J, 16 J + 16) of rnn1 (LA) or of rnn2 + rows [16 J, 16 J + 16) of fc1 and of fc2.  Slot i of cluster cl = group cl + ncl i of the round = region i CHCL + cl of the exchange buffer.
 // loc_a / loc_b: the cluster's rnn1 / rnn2 workgroups were all seen on one XCD.
 // PROF (thread 0, shader clocks per segment of a step, summed over the slots, program order): rnn1: 0 drain + wait x_{t-1}, 1 cell + publish,
-// 2 wait h1(t), 3 gh stage, 9 wait x2, 10 fc1 (FC1A), 4 wait cI(t+1), 5 W_ih . cI stage, 6 cI(t+2) formed, 7 wait y2(t), 8 fc3 + sampling; rnn2:
-// 0 drain + wait x1(t), 1 gate stage + cell + publish, 2 wait x2, 3 fc1 (not FC1A), 4 wait y1, 5 fc2, 6 wait h2 (there), 7 gh stage; 15 = steps
+// 2 wait h1(t), 3 gh stage, 4 wait cI(t+1), 5 W_ih . cI stage, 6 cI(t+2) formed, 7 wait y2(t), 8 fc3 + sampling; rnn2:
+// 0 drain + wait x1(t), 1 gate stage + cell + publish, 2 wait x2, 3 fc1, 4 wait y1, 5 fc2, 6 wait h2 (there), 7 gh stage; 15 = steps
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <bool LA, bool FC1A, bool PROF>
+template <bool LA, bool PROF>
 __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const int cl, const int ncl, const int J, const bool loc_a, const bool loc_b)
 {
     const int G = a.G;
@@ -107,7 +106,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
     const float *const mels_up = a.mels_up, *const aux_fr = a.aux_fr, *const mel_coef = a.mel_coef;
     const int mel_stage = a.mel_stage;
     const int NR = a.Btot, NGR = a.NG;
-    constexpr bool HAS_FC1 = LA == FC1A;                // this role owns the fc1 rows
+    constexpr bool HAS_FC1 = !LA;
     float *const state_wg = a.state + ((size_t)(cl * CHWG + (LA ? 0 : 32) + J) * G) * CHSTATE_SLOT;
 
     // ---- weights: three gate tiles of W_ih and of W_hh; one tile of fc1 (HAS_FC1) and of fc2 (rnn2)
@@ -164,8 +163,8 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
     const __amdgpu_buffer_rsrc_t f1rs = make_rsrc(a.c3f, 0x7FFFF000u), f2rs = make_rsrc(a.c4f, 0x7FFFF000u);
     const int voff_frag = frag_off(w, 0, lane) * 4;      // this lane's first fragment of a layer (bytes)
     const int voff_own = (((J * 64) + 16 * w + pj) * 4 + (tid & 3)) * 4;      // the layer word of (unit 16 J + pu, segment pj) = its publish position
-    // which layers cross the XCDs (written through): x1 and y2 always (rnn2 / the samplers sit on the other XCD); x2 and y1 when fc1 is on rnn1
-    const bool loc_x2 = FC1A ? false : loc_b, loc_y1 = FC1A ? false : loc_b;
+    // (x1 and y2 cross the XCDs -- rnn2 / the samplers sit on the other one -- and are written through; x2 and y1 stay in rnn2's L2)
+    const bool loc_x2 = loc_b, loc_y1 = loc_b;
 
     bool dead = false;
     int pp = 0;
@@ -228,9 +227,9 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             const float cv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(f1rs, (fr * H + prow) * 4, 0, 0));
             float s0, s1, s2;
             unsigned dummy = 0u;
-            stage(N1{}, A_fc1, A_fc1, A_fc1, sb + 6 * DLAYERB, nb, 0x801u, t, LA ? 9 : 2, s0, s1, s2, dummy, false);
+            stage(N1{}, A_fc1, A_fc1, A_fc1, sb + 6 * DLAYERB, nb, 0x801u, t, 2, s0, s1, s2, dummy, false);
             publish4l(xrs, sb + 2 * DLAYERB + J * 1024, tid, fmaxf(s0 + cv, 0.f), pj < nb, loc_y1);
-            CHX(LA ? 10 : 3);
+            CHX(3);
         }
     };
     // gh(t + 1) = W_hh . h(t) + b_hh of slot i: stays with the thread
@@ -296,7 +295,6 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             // ring hygiene: behind the poll of x_{t-1}, which needed everything of step t - 1: every reader is past the data of step t - 2
             rearm1(i, 0, 0, loc_a);
             rearm1(i, 5, 1, false);
-            if constexpr (FC1A) rearm1(i, 2, 2, false);
             CHX(1);
         };
         auto sample = [&](int i) {
@@ -360,10 +358,6 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             for (int i = 0; i < nact; ++i) back(i);
 #pragma unroll 1
             for (int i = 0; i < nact; ++i) gh_stage(i); // (needs h1(t) of every rnn1 workgroup: one hop behind the publications above)
-            if constexpr (FC1A) {
-#pragma unroll 1
-                for (int i = 0; i < nact; ++i) fc1_stage(i);
-            }
             if (t + 1 < T1) {
 #pragma unroll 1
                 for (int i = 0; i < nact; ++i) front(i, t + 1);
@@ -392,7 +386,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             }
         }
     } else {
-        // ---------------- rnn2 (+ fc2; fc1 unless FC1A) ----------------
+        // ---------------- rnn2 (+ fc1, fc2) ----------------
         auto gates = [&](int i) {                       // the whole gate stage is on the slot's chain (x1 -> here)
             const int nb = nb_of(i), sb = cbase_of(i) + (t & (DRING - 1)) * XTB;
             const int fr = table_row(SEGT[i * 64 + pj] + t, SEGT[i * 64 + SEG + pj], SEGT[i * 64 + 2 * SEG + pj], magic, mshift, hop, zrow);
@@ -420,7 +414,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             // ring hygiene: behind the last poll of the slot's step (y1(t): everybody is past the readers of step t - 2) and behind the publication
             rearm1(i, 1, 0, loc_b);
             rearm1(i, 6, 1, loc_x2);
-            if constexpr (!FC1A) rearm1(i, 2, 2, loc_y1);
+            rearm1(i, 2, 2, loc_y1);
             rearm1(i, 3, 3, false);
             CHX(5);
         };
@@ -429,10 +423,8 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
             for (int i = 0; i < nact; ++i) gates(i);
-            if constexpr (!FC1A) {
 #pragma unroll 1
-                for (int i = 0; i < nact; ++i) fc1_stage(i);
-            }
+            for (int i = 0; i < nact; ++i) fc1_stage(i);
 #pragma unroll 1
             for (int i = 0; i < nact; ++i) fc2_stage(i);
 #pragma unroll 1
@@ -450,8 +442,8 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
 
 // Grid = 4 clusters x 64 workgroups of 256 threads (one per CU), cooperative launch; a cluster without a group leaves at once.  Placement
 // (speed only, verified at run time): block b is observed to run on XCD b % 8; cluster cl = XCDs 2 cl (its rnn1 workgroups) and 2 cl + 1
-// (rnn2 + fc2, and fc1 in the latency form); the 32 blocks of an XCD: unit blocks J = 0 .. 31.
-template <bool FC1A, bool PROF>
+// (rnn2, fc1, fc2); the 32 blocks of an XCD: unit blocks J = 0 .. 31.
+template <bool PROF>
 __global__ __launch_bounds__(NT, 1) void wrnn_chain_kernel(const LoopArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -489,8 +481,8 @@ __global__ __launch_bounds__(NT, 1) void wrnn_chain_kernel(const LoopArgs a)
         __syncthreads();
     }
     const int ncl = CHCL;
-    if (layer == 0) ch_role<true, FC1A, PROF>(a, smem, cl, ncl, J, loc_a, loc_b);
-    else ch_role<false, FC1A, PROF>(a, smem, cl, ncl, J, loc_a, loc_b);
+    if (layer == 0) ch_role<true, PROF>(a, smem, cl, ncl, J, loc_a, loc_b);
+    else ch_role<false, PROF>(a, smem, cl, ncl, J, loc_a, loc_b);
 }
 
 int chain_clusters(int n_cus) { return n_cus >= CHCL * CHWG ? CHCL : 0; }
@@ -498,15 +490,12 @@ int chain_max_depth() { return CHMAXG; }
 size_t chain_state_floats(int G) { return (size_t)CHCL * CHWG * G * CHSTATE_SLOT; }
 size_t chain_xbuf_bytes(int G) { return (size_t)G * CHCL * DSLOTB; }
 
-// G = 1: the latency form (fc1 beside rnn2); G >= 2: the throughput form (fc1 on the rnn1 workgroups); wrnn_options.tuning bit 4 / bit 5 force one
 hipError_t launch_chain(const LoopArgs &args, hipStream_t stream)
 {
     if (!args.fc3f || !args.u1 || !args.xcc_tab || args.NG < 1 || args.G < 1 || args.G > CHMAXG || args.NG > CHCL * args.G) return hipErrorInvalidValue;
     const size_t lds = (size_t)ch_lds(args.G).total * sizeof(float);
     const bool prof = args.prof && !(args.tuning & 64);
-    const bool fc1a = (args.tuning & 16) ? true : ((args.tuning & 32) ? false : args.G >= 2);
-    const void *fn = fc1a ? (prof ? (const void *)wrnn_chain_kernel<true, true> : (const void *)wrnn_chain_kernel<true, false>)
-                          : (prof ? (const void *)wrnn_chain_kernel<false, true> : (const void *)wrnn_chain_kernel<false, false>);
+    const void *fn = prof ? (const void *)wrnn_chain_kernel<true> : (const void *)wrnn_chain_kernel<false>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     LoopArgs a = args;
