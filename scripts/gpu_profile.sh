@@ -5,7 +5,7 @@ TAG=${1:-r01}; shift
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
-BENCH="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single $*"
+BENCH="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single --no-config4-leg $*"     # (only the main loop's launches under the profiler)
 echo "== smoke"; timeout 300 python __graft_entry__.py smoke 2>&1 | tee $OUT/smoke_$TAG.log | tail -3
 echo "== bench"; timeout 600 python bench.py --steps 3 --warmup 1 "$@" 2>&1 | tee $OUT/bench_$TAG.log | tail -2
 cd /tmp

@@ -76,7 +76,8 @@ if bj is not None:
                       note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per dispatch x launches per pass; fabric-side '
                            '(L2 <-> Infinity Fabric / MALL) bytes = the inter-CU activation exchange + conditioning slabs; FETCH_SIZE doubled per '
                            'MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads)')
-            json.dump(tr, open(os.path.join(dst, 'traffic_latest.json'), 'w'), indent=1)
+            # (the default line's figure is what bench.py reads back; a --prune run keeps its own file)
+            json.dump(tr, open(os.path.join(dst, 'traffic_config5.json' if 'BASELINE config 5' in bj['config'].get('workload', '') else 'traffic_latest.json'), 'w'), indent=1)
 for k, cs in pmc.items():
     g = lambda c: cs.get(c, (None,))[0]
     lines += [f'## {k}', '', f'launch geometry / registers: {meta[k]}', '']
