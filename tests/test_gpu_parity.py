@@ -634,7 +634,7 @@ def test_block_sparse_kernel_matches_oracle(gpu, frames, target, overlap, opts):
     args = (torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride)
     with pytest.raises(Exception):
         dense.run(*args, torch.from_numpy(flat).to(gpu), 275, algo='sparse')
-    assert dense.plan(B, T)['kernel'] == ('wrnn_chain_kernel' if B <= 64 else 'wrnn_duo_kernel') and eng.plan(B, T)['kernel'] == 'wrnn_sparse_kernel'
+    assert dense.plan(B, T)['kernel'] == ('wrnn_chain_kernel' if B <= 128 else 'wrnn_duo_kernel') and eng.plan(B, T)['kernel'] == 'wrnn_sparse_kernel'
     if opts == 'slices':
         out = None
         for t0, t1 in ((0, 200), (200, 201), (201, T)):
