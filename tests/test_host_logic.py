@@ -300,7 +300,7 @@ def test_bench_self_launches_two_ranks_dry_host(tmp_path):
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--utterances', '2',
-           '--frames', '30', '--target', '550', '--overlap', '55', '--dry-host', 'helpers:oracle_loop_fn']
+           '--frames', '30', '--target', '550', '--overlap', '55', '--no-config4-leg', '--dry-host', 'helpers:oracle_loop_fn']      # (the config-4 leg: its own test below)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
