@@ -648,6 +648,37 @@ def test_block_sparse_kernel_matches_oracle(gpu, frames, target, overlap, opts):
     assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
 
 
+def test_planner_picks_the_kernel_by_pack_and_batch(gpu):
+    """`wrnn_plan_segments` (no launch): a dense MoL pack runs on wrnn_chain_kernel up to 128 segments (one / two groups per cluster) and on
+    wrnn_duo_kernel beyond; RAW on wrnn_duo_kernel at every batch size; a block-sparse MoL pack on wrnn_sparse_kernel at every batch size
+    (16 clusters, rounds beyond 256 segments); asking a kernel for what it cannot run is an argument error with a message, not a fallback."""
+    from wavernn_amd import _lib
+    from wavernn_amd.engine import LoopEngine
+    from wavernn_amd.prune import block_prune_state_dict
+    from wavernn_amd.synthetic import random_state_dict
+    sd = random_state_dict(3, mode='MOL')
+    dense = LoopEngine(sd, 'MOL', device=gpu)
+    for n, kernel, depth in ((1, 'wrnn_chain_kernel', 1), (12, 'wrnn_chain_kernel', 1), (64, 'wrnn_chain_kernel', 1), (65, 'wrnn_chain_kernel', 2),
+                             (128, 'wrnn_chain_kernel', 2), (129, 'wrnn_duo_kernel', 3), (256, 'wrnn_duo_kernel', 4), (512, 'wrnn_duo_kernel', 8)):
+        pl = dense.plan(n, 12100)
+        assert (pl['kernel'], pl['clusters'], pl['depth'], pl['rounds']) == (kernel, 4, depth, 1), (n, pl)
+    assert dense.plan(256, 12100, algo='chain')['depth'] == 4 and dense.plan(300, 12100, algo='chain')['rounds'] == 2
+    with pytest.raises(_lib.WrnnError, match='block-sparse kernel needs'):
+        dense.plan(16, 100, algo='sparse')
+    raw = LoopEngine(random_state_dict(3, mode='RAW'), 'RAW', device=gpu)
+    assert raw.plan(12, 12100)['kernel'] == 'wrnn_duo_kernel' and raw.plan(256, 12100)['kernel'] == 'wrnn_duo_kernel'
+    with pytest.raises(_lib.WrnnError, match='wrnn_chain_kernel needs MOL'):
+        raw.plan(12, 100, algo='chain')
+    sparse = LoopEngine(block_prune_state_dict(sd, 0.95, (16, 1))[0], 'MOL', device=gpu)
+    for n, rounds in ((12, 1), (256, 1), (257, 2), (942, 4)):
+        pl = sparse.plan(n, 12100)
+        assert (pl['kernel'], pl['units_per_wg'], pl['clusters'], pl['depth'], pl['rounds']) == ('wrnn_sparse_kernel', 64, 16, 1, rounds), (n, pl)
+    assert sparse.plan(256, 12100, algo='duo')['kernel'] == 'wrnn_duo_kernel' and sparse.plan(12, 12100, algo='chain')['kernel'] == 'wrnn_chain_kernel'
+    # the workspace of either new kernel depends on neither T nor the corpus' frame count
+    for eng, n in ((dense, 12), (sparse, 256)):
+        assert eng.workspace_bytes(n, 12100, 700) == eng.workspace_bytes(n, 121000, 70000) < 300e6
+
+
 def test_config1_raw_unbatched_one_second(gpu, tmp_path):
     """BASELINE config 1 geometry: 9-bit mu-law WaveRNN, unbatched generate on 1 s of random mel (81 frames -> 22,275
     steps, one segment) -- `generate()` end to end against the oracle's end-to-end restatement, bit-exact."""
