@@ -398,11 +398,10 @@ struct Plan {
 
 struct WsLayout {
     size_t status, xcc, segs, melc, c2f, c3f, c4f;
-    size_t gran, cI, npre;              // stream kernel: granules, whole-T conditioning; persistent kernels: one slab of derived MOL noise
+    size_t cI, npre;                    // stream kernel: whole-T conditioning; persistent kernels: one slab of derived MOL noise
     size_t xbuf, state, cIf;            // loop kernel: exchange buffer, per-round state, conditioning slab
     size_t total;
 };
-constexpr size_t GRAN_BYTES = (size_t)GRAN_WORDS * sizeof(u64);
 size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
 const wrnn_options *norm_options(const wrnn_options *opt, wrnn_options *tmp)
@@ -577,7 +576,6 @@ WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frame
         l.cIf = o;   if (pl.kind == K_LOOP) o = al(o + (size_t)pl.slab * pl.ngr_max * SEG * H * sizeof(float));      // (the duo kernel forms cI in the loop)
         l.npre = o;  if (mol) o = al(o + (size_t)pl.slab * 11 * B * sizeof(float));      // derived MOL noise of one slab
     } else {
-        l.gran = o;  o = al(o + GRAN_BYTES);
         l.cI = o;    o = al(o + (size_t)T * B * H * sizeof(float));
         l.npre = o;
     }
@@ -857,7 +855,6 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
         // ---- stream kernel: whole-T conditioning in [t][segment][H] order, one launch --------------------
         c.cI = (float *)(ws + l.cI);
         a.cI = c.cI;
-        a.gran = (u64 *)(ws + l.gran);
         HIPCHK(launch_cond(c, p->n_cus, o->cond_valu != 0, stream));
         info.kernel = "wrnn_stream_kernel";
         a.b0 = 0;

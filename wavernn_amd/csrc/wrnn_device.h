@@ -33,12 +33,7 @@ constexpr int KCOND = MEL + AUX;   // conditioning inputs of the I layer (112)
 constexpr int LAST_SCALE = 11;     // stretch factor of the last up-sampling stage when wrnn_duo_kernel forms it in the loop (hparams.py: voc_upsample_factors[2])
 constexpr int SEG = 16;       // segments per persistent launch group (= MFMA N)
 constexpr int LDA = 516;      // padded row stride (floats) of the LDS activation tiles
-constexpr int NGRAN = 5;      // granule buffers: h1, h2, y1, y2, (RAW) logits
 constexpr int MAXCL = 4;      // cluster kernels: at most 4 independent clusters per chip
-constexpr int MAXG = 3;       // pipelined kernel: at most 3 groups in flight per cluster
-constexpr int SPCL = 8, SPG = 2;      // (sizing of the stream kernel's granule workspace; the round-1 block-sparse kernel's split)
-constexpr int GRAN_WORDS = SPCL * SPG * NGRAN * SEG * H;     // u64 granules in the workspace (>= MAXCL * MAXG * ...)
-static_assert(SPCL * SPG >= MAXCL * MAXG, "granule workspace");
 // role-split loop kernel (wrnn_loop.hip): tag-free exchange buffer [cluster][slot][layer h1 h2 y1 y2 lg x1 x2][ring][SEG*H floats]
 constexpr int LMAXG = 8;      // slots (groups in flight) per cluster the exchange buffer is sized for
 constexpr int NXLAYER = 8;      // h1, h2, y1, y2, RAW logits, x1 = xi + h1, x2 = x1 + h2, x_t (16 words: samples drawn by role B)
@@ -46,7 +41,6 @@ constexpr int XRING = 4;
 constexpr size_t XBUF_FLOATS = (size_t)MAXCL * LMAXG * NXLAYER * XRING * SEG * H;
 constexpr int STATUS_WORDS = 16;    // 0 abort flag, 1 code, 2 wg, 3 step, 4 detail; 8 = the loop kernel kind a call settled on at step 0 (continuations must match)
 constexpr int XCC_WORDS = MAXCL * 128; // wrnn_duo.hip placement handshake
-constexpr int NPROF = 16;     // phase counters per workgroup (wrnn_pipe.hip PROF builds)
 constexpr int MAXWG = 256;    // workgroups of a persistent launch
 
 // Everything the loop kernels read.  All pointers are device pointers.
@@ -75,9 +69,8 @@ struct LoopArgs {
     const float *force_x;               // optional [Btot][T]
     float *out;                         // [Btot][T]
     float *dbg_logits;                  // optional [T][Btot][C]
-    u64 *gran;                          // [GRAN_WORDS] {tag,value} granules: cluster kernel [cl][layer][SEG][H], pipe kernel [cl][slot][layer][SEG][H]
     unsigned *status;                   // [STATUS_WORDS]: 0 abort flag, 1 code, 2 wg, 3 step, 4 detail
-    u64 *prof;                          // optional [workgroups][NPROF] shader-clock totals per phase (profiling builds)
+    u64 *prof;                          // optional [256 workgroups][32] shader-clock totals per phase (wrnn_options.phase_clocks; layouts: the kernels' "PROF" notes)
     // segment table: segment b, step t reads conditioning position p = seg_pos[b] + t; p >= seg_lim[b] is the
     // fold's zero padding (fatchord_version.py:326-330).  One utterance: seg_pos[b] = b*(target+overlap),
     // seg_lim[b] = L.  Several utterances: positions in the concatenated conditioning (each utterance starts
