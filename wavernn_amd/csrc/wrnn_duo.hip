@@ -523,9 +523,8 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     // rnn2's hh workgroup J samples slot J (y2 comes from rnn2's ih workgroups: the same XCD under the placement above)
     const bool sampler = !LA && J < nact;
     const int my_slot = J;
-    if (MOL && sampler) {                               // fc3's first tile -> LDS (fragment order as in the pack), fc3.bias -> LOG[0..29]
+    if (MOL && sampler) {                               // fc3's first tile -> LDS (fragment order as in the pack)
         for (int q = tid; q < XT / 4; q += NT) reinterpret_cast<float4 *>(F3)[q] = reinterpret_cast<const float4 *>(a.fc3f)[q];
-        if (tid < 32) LOG[tid] = tid < 30 ? a.fc3_b[tid] : 0.f;
     }
     float *const LGT = F3;                              // RAW: the gathered logits of the slot being sampled, [segment][class] rows of stride LDC
     __syncthreads();
@@ -576,21 +575,24 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         const int b0 = GEO[2 * bi];
         lds_barrier();
         PHX(cur + 1);
-        if (dbgl && pj < nb) {                          // test hook: the 30 logits of every segment (thread: rows pu and 16 + pu, segment pj)
-            dbgl[((size_t)bt * Nall + b0 + pj) * C + pu] = get_partial<3>(PB, 0, pu, pj) + b3a;
-            if (pu < 14) dbgl[((size_t)bt * Nall + b0 + pj) * C + 16 + pu] = get_partial<3>(PB, 1, pu, pj) + b3b;
+        {   // 30 logit rows x 16 segments: thread (rows pu and 16 + pu, segment pj) -- the partial tiles' conflict-free reader mapping
+            const float lg = get_partial<3>(PB, 0, pu, pj) + b3a;
+            const float lg2 = get_partial<3>(PB, 1, pu, pj) + b3b;
+            LOG[pj * DLOGS + pu] = lg;
+            if (dbgl && pj < nb) dbgl[((size_t)bt * Nall + b0 + pj) * C + pu] = lg;
+            if (pu < 14) {
+                LOG[pj * DLOGS + 16 + pu] = lg2;
+                if (dbgl && pj < nb) dbgl[((size_t)bt * Nall + b0 + pj) * C + 16 + pu] = lg2;
+            }
         }
-        {   // 16-lane row = one segment (su), lane sm = mixture; c0 / c1 = this thread's pre-transformed noise.  Lane sm < 10 sums the partial
-            // tiles of ITS mixture logit straight from LDS (round 5: no second pass through LDS, no second barrier -- it sat on the slot's
-            // chain), Gumbel-max over the row, then lane 0 fetches mean and log-scale of the winner (LOG[0..29] = fc3.bias)
+        lds_barrier();
+        {   // 16-lane row = one segment (su), lane sm = mixture; c0 / c1 = this thread's pre-transformed noise
             const int su = tid >> 4, sm = tid & 15;
-            float best = (sm < 10) ? mol_gumbel_pre(get_partial<3>(PB, 0, sm < 10 ? sm : 0, su) + LOG[sm < 10 ? sm : 0], c.c0) : -INFINITY;
+            float best = (sm < 10) ? mol_gumbel_pre(LOG[su * DLOGS + sm], c.c0) : -INFINITY;
             int bidx = sm;
             argmax_row16(best, bidx);
             if (sm == 0 && su < nb) {
-                const float mean = get_partial<3>(PB, (10 + bidx) >> 4, (10 + bidx) & 15, su) + LOG[10 + bidx];
-                const float ls = get_partial<3>(PB, (20 + bidx) >> 4, (20 + bidx) & 15, su) + LOG[20 + bidx];
-                float xv = mol_sample_pre(mean, ls, c.c1);
+                float xv = mol_sample_pre(LOG[su * DLOGS + 10 + bidx], LOG[su * DLOGS + 20 + bidx], c.c1);
                 outp[(size_t)(b0 + su) * Tall + bt] = xv;
                 if (forcex) xv = forcex[(size_t)(b0 + su) * Tall + bt];
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xv), xrs, su * 4, cbase + bi * (MAXCL * DSLOTB) + 7 * DLAYERB + (bt & (DRING - 1)) * XTB, 16 /* sc1 */);
