@@ -91,6 +91,7 @@ VARIANTS = {
     'chain-slabs': dict(algo='chain', slab_steps=97),
     'chain-wt': dict(algo='chain', tuning=256),
     # ... with several groups in flight per cluster
+    'chain-g1': dict(algo='chain', depth=1),
     'chain-g2': dict(algo='chain', depth=2),
     'chain-g2-slabs': dict(algo='chain', depth=2, slab_steps=97),
     'chain-g4': dict(algo='chain', depth=4, slab_steps=131),
@@ -484,7 +485,7 @@ def test_fused_stages_equal_unfused_bitwise(gpu, mode):
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
 
 
-@pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'duo', 'duo-g1', 'duo-g2-slabs', 'duo-c1-g3', 'chain', 'chain-g2',
+@pytest.mark.parametrize('variant', ['loop', 'loop-g1', 'loop-g2-slabs', 'loop-c1-g3', 'duo', 'duo-g1', 'duo-g2-slabs', 'duo-c1-g3', 'chain', 'chain-g1', 'chain-g2',
                                      'chain-g2-slabs', 'chain-g4'])
 def test_more_segments_than_slots(gpu, variant):
     """114 segments x 264 steps (MoL) = 8 groups: two rounds at depth 1 (state buffers per round), one round at depth 2,
