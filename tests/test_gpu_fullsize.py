@@ -164,7 +164,7 @@ def _sweep_case(sd, mode, n, T, seed):
     return _SWEEP[key]
 
 
-@pytest.mark.parametrize('mode,algo', [('MOL', 'loop'), ('RAW', 'loop'), ('MOL', 'duo'), ('RAW', 'duo'), ('MOL', 'chain')])
+@pytest.mark.parametrize('mode,algo', [('MOL', 'loop'), ('RAW', 'loop'), ('MOL', 'duo'), ('RAW', 'duo'), ('MOL', 'chain'), ('RAW', 'chain')])
 @pytest.mark.parametrize('clusters', [1, 4])
 def test_every_depth_the_planner_can_pick(gpu, mode, clusters, algo):
     """Depth 4, 5, 6, 7, 8 groups in flight per cluster (and 3 for wrnn_duo_kernel, the shallowest depth `auto` picks it

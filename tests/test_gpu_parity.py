@@ -100,8 +100,7 @@ KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'loop': 'wrnn_loop_kernel', 'spar
 
 
 def _skip_unless_supported(mode, opts):
-    if opts.get('algo') == 'chain' and mode != 'MOL':
-        pytest.skip('wrnn_chain_kernel is the MoL latency kernel (RAW runs on wrnn_duo_kernel)')
+    pass            # (every kernel of VARIANTS runs both modes: the duo kernel since round 4, wrnn_chain_kernel since round 5)
 
 
 def test_device_selftests(gpu):
@@ -151,7 +150,7 @@ def test_exchange_layers_match_oracle(gpu, mode):
         assert np.abs(out.cpu().numpy() - ref).max() <= MOL_TOL
 
 
-@pytest.mark.parametrize('mode,algo', [('MOL', 'loop'), ('RAW', 'loop'), ('MOL', 'duo'), ('RAW', 'duo'), ('MOL', 'chain')])
+@pytest.mark.parametrize('mode,algo', [('MOL', 'loop'), ('RAW', 'loop'), ('MOL', 'duo'), ('RAW', 'duo'), ('MOL', 'chain'), ('RAW', 'chain')])
 def test_step_ranges_continue_bit_exactly(gpu, mode, algo):
     """`wrnn_options.t_begin / t_end`: the loop run as calls over [0, 200), [200, 201), [201, 203), [203, T), each with only its
     own rows of noise, equals the single call bit for bit (the per-group state lives in the workspace between calls; the duo
@@ -651,7 +650,7 @@ def test_block_sparse_kernel_matches_oracle(gpu, frames, target, overlap, opts):
 
 def test_planner_picks_the_kernel_by_pack_and_batch(gpu):
     """`wrnn_plan_segments` (no launch): a dense MoL pack runs on wrnn_chain_kernel up to 128 segments (one / two groups per cluster) and on
-    wrnn_duo_kernel beyond; RAW on wrnn_duo_kernel at every batch size; a block-sparse MoL pack on wrnn_sparse_kernel at every batch size
+    wrnn_duo_kernel beyond, and so does 9-bit RAW; a block-sparse MoL pack on wrnn_sparse_kernel at every batch size
     (16 clusters, rounds beyond 256 segments); asking a kernel for what it cannot run is an argument error with a message, not a fallback."""
     from wavernn_amd import _lib
     from wavernn_amd.engine import LoopEngine
@@ -667,9 +666,11 @@ def test_planner_picks_the_kernel_by_pack_and_batch(gpu):
     with pytest.raises(_lib.WrnnError, match='block-sparse kernel needs'):
         dense.plan(16, 100, algo='sparse')
     raw = LoopEngine(random_state_dict(3, mode='RAW'), 'RAW', device=gpu)
-    assert raw.plan(12, 12100)['kernel'] == 'wrnn_duo_kernel' and raw.plan(256, 12100)['kernel'] == 'wrnn_duo_kernel'
-    with pytest.raises(_lib.WrnnError, match='wrnn_chain_kernel needs MOL'):
-        raw.plan(12, 100, algo='chain')
+    assert raw.plan(12, 12100)['kernel'] == 'wrnn_chain_kernel' and raw.plan(128, 12100)['depth'] == 2 and raw.plan(256, 12100)['kernel'] == 'wrnn_duo_kernel'
+    raw8 = LoopEngine(random_state_dict(3, mode='RAW', bits=8), 'RAW', device=gpu)          # 256 classes: the MFMA kernels' RAW sampler is built for 512
+    assert raw8.plan(12, 100)['kernel'] == 'wrnn_stream_kernel'
+    with pytest.raises(_lib.WrnnError, match='wrnn_chain_kernel needs MOL or RAW with 512 classes'):
+        raw8.plan(12, 100, algo='chain')
     sparse = LoopEngine(block_prune_state_dict(sd, 0.95, (16, 1))[0], 'MOL', device=gpu)
     for n, rounds in ((12, 1), (256, 1), (257, 2), (942, 4)):
         pl = sparse.plan(n, 12100)

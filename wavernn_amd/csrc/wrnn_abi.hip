@@ -34,7 +34,7 @@ int sparse_clusters(int n_cus);
 size_t sparse_state_floats();
 size_t sparse_xbuf_bytes();
 hipError_t launch_put_floats(float *dst, const float *src, int n, hipStream_t stream);
-hipError_t launch_chain(const LoopArgs &args, hipStream_t stream);
+hipError_t launch_chain(const LoopArgs &args, int mode, hipStream_t stream);
 int chain_clusters(int n_cus);
 int chain_max_depth();
 size_t chain_state_floats(int G);
@@ -445,10 +445,10 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
     // of BASELINE config 2 / 3): one group per 64-CU cluster, a step is the latency of one chain; <= 128: two groups per cluster --; on
     // request (algo = chain) also with up to 4 groups in flight per cluster (wrnn_options.depth) and rounds beyond that
     const int ccl = chain_clusters(p->n_cus);
-    const bool chain_hw = p->mode == WRNN_MODE_MOL && ccl >= 1;
+    const bool chain_hw = shape_ok && ccl >= 1;
     if (algo == WRNN_ALGO_CHAIN && !chain_hw) {
-        set_err("wrnn_chain_kernel needs MOL and >= 256 CUs (device: %d CUs)", p->n_cus);
-        return p->mode != WRNN_MODE_MOL ? WRNN_ERR_ARG : WRNN_ERR_RESIDENCY;
+        set_err("wrnn_chain_kernel needs MOL or RAW with 512 classes, and >= 256 CUs (C = %d, device: %d CUs)", p->C, p->n_cus);
+        return !shape_ok ? WRNN_ERR_ARG : WRNN_ERR_RESIDENCY;
     }
     if (algo == WRNN_ALGO_CHAIN || (algo == WRNN_ALGO_AUTO && chain_hw && groups <= CHAIN_AUTO_GROUPS && !p->sp_nbp)) {
         const int gmax = chain_max_depth();
@@ -465,7 +465,7 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
         pl->ngr_max = (pl->per_round + SEG - 1) / SEG;
         if (pl->ngr_max > ccl * g) { pl->rounds += 1; pl->per_round = (B + pl->rounds - 1) / pl->rounds; pl->ngr_max = (pl->per_round + SEG - 1) / SEG; }
         int slab = o->slab_steps;
-        if (slab < 1) slab = (int)((32u << 20) / ((size_t)pl->per_round * 11 * sizeof(float) * pl->rounds));
+        if (slab < 1) slab = p->mode == WRNN_MODE_MOL ? (int)((32u << 20) / ((size_t)pl->per_round * 11 * sizeof(float) * pl->rounds)) : 4096;
         if (slab < 16) slab = 16;
         if (slab > 4096) slab = 4096;
         if (slab > T) slab = T;
@@ -838,7 +838,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                 a.t0 = s0; a.t1 = s1; a.cI_t0 = s0; a.rb0 = rb0; a.Btot = nr; a.NG = ngr; a.resume = s0 > 0 ? 1 : 0;
                 a.kind_tag = chain ? 4 : sparse ? 3 : (duo ? 2 : 1);
                 if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
-                hipError_t e = chain ? launch_chain(a, stream) : sparse ? launch_sparse(a, p->sp_nbp, stream) : (duo ? launch_duo(a, pl.ncl, p->mode, stream) : launch_loop(a, pl.ncl, p->mode, stream));
+                hipError_t e = chain ? launch_chain(a, p->mode, stream) : sparse ? launch_sparse(a, p->sp_nbp, stream) : (duo ? launch_duo(a, pl.ncl, p->mode, stream) : launch_loop(a, pl.ncl, p->mode, stream));
                 // (two workgroups per CU not co-resident right now: WRNN_ERR_RESIDENCY -- the caller re-plans with WRNN_ALGO_LOOP, whose
                 // workspace layout is another one: wavernn_amd/engine.py does)
                 if (e != hipSuccess) {

@@ -1,4 +1,4 @@
-// wrnn_chain.hip -- the persistent WaveRNN loop kernel (MOL, dense weights) for SMALL batches: <= 64 folded segments = one utterance of
+// wrnn_chain.hip -- the persistent WaveRNN loop kernel (MOL and 9-bit RAW, dense weights) for SMALL batches: <= 64 folded segments = one utterance of
 // BASELINE config 2 (N = 481 -> 12 segments; N = 1001 -> 24) or config 3's sentence (19), on MI355X (gfx950 / CDNA4).  Round 5.
 //
 // With one group of <= 16 segments per cluster nothing can be pipelined: a step of reference models/fatchord_version.py:201-241 IS the
@@ -22,6 +22,10 @@
 //     step; cI without a sentinel inside a launch (formed at the end of step t for step t + 2, drained at the top of step t + 1, read
 //     behind the poll of h1(t + 1)); x_t as tagged 8-byte words in two entries.  The rules are wrnn_sparse.hip's (model:
 //     tests/test_sparse_exchange_model.py); what differs is who publishes what.
+//   * 9-bit RAW (fatchord_version.py:231-237): fc3 has 512 rows -- rnn1's workgroup J (idle while the chain runs through rnn2) owns rows [16 J, 16 J + 16): one
+//     more stage (32 MFMAs on y2) and one more same-XCD hop (the 512 logits, layer 16) in front of the sampling, which is wrnn_duo.hip's: softmax ->
+//     Categorical (renormalise) -> argmax(p / q) in the reference's operation order, one wave per 4 segments; the GRU cells use the library exp / tanh.
+//     Bit-identical to wrnn_duo_kernel's RAW output (same stage arithmetic), i.e. to the reference on every fixture.
 //   * conditioning slabs, state between launches (4 floats per (unit, segment)), step-range continuation: as wrnn_duo.hip / wrnn_sparse.hip.
 //   * TWO (up to four) groups per cluster (wrnn_options.depth; `auto`: 65 .. 128 segments): every stage becomes a loop over the cluster's slots --
 //     gates(0) gates(1) | fc1(0) fc1(1) | fc2(0) .. | gh(0) .. -- so one slot's hops fly under the other slot's stages; the per-slot state of a
@@ -43,6 +47,7 @@ constexpr int CHPART = 2 * NW * 3 * 256;     // two ping-pong sets of [wave][til
 constexpr int CHSTATE_SLOT = NT * 4 + SEG;   // saved state of a workgroup's slot: per thread {h, gh_r, gh_z, gh_n}, then x_{t1-1} (rnn1)
 static_assert(CHCL * CHWG <= XCC_WORDS, "placement table");
 static_assert(CHCL * CHMAXG <= LMAXG * MAXCL, "one exchange-buffer region per (slot, cluster)");
+static_assert(SEG * LDC <= 2 * XT, "RAW logits fit the fc3 region");
 
 struct ChLds {
     int off_seg, off_geo, off_st, off_part, off_misc, off_prof, off_b3, off_f3, total;
@@ -59,7 +64,7 @@ __host__ __device__ inline ChLds ch_lds(int G)
     l.off_prof = o; o += 64;                 // [32] u64 phase clocks (profiling builds)
     l.off_b3 = o;   o += 32;                 // sampling workgroups: fc3.bias
     o = (o + 3) & ~3;
-    l.off_f3 = o;   o += 2 * XT;             // ... fc3 (30 x 512 = two 16-row tiles) in A-fragment order
+    l.off_f3 = o;   o += 2 * XT;             // ... MOL: fc3 (30 x 512 = two 16-row tiles) in A-fragment order; RAW: the gathered logits [segment][class], stride LDC
     l.total = o;
     return l;
 }
@@ -78,10 +83,10 @@ typedef unsigned ch_u32x2 __attribute__((ext_vector_type(2)));
 // One workgroup: units [16 J, 16 J + 16) of rnn1 (LA) or of rnn2 + rows [16 J, 16 J + 16) of fc1 and of fc2.  Slot i of cluster cl = group cl + ncl i of the round = region i CHCL + cl of the exchange buffer.
 // loc_a / loc_b: the cluster's rnn1 / rnn2 workgroups were all seen on one XCD.
 // PROF (thread 0, shader clocks per segment of a step, summed over the slots, program order): rnn1: 0 drain + wait x_{t-1}, 1 cell + publish,
-// 2 wait h1(t), 3 gh stage, 4 wait cI(t+1), 5 W_ih . cI stage, 6 cI(t+2) formed, 7 wait y2(t), 8 fc3 + sampling; rnn2:
+// 2 wait h1(t), 3 gh stage, 4 wait cI(t+1), 5 W_ih . cI stage, 6 cI(t+2) formed, 7 wait y2(t), 8 fc3 + sampling (RAW: the logits stages; the sampling is not clocked); rnn2:
 // 0 drain + wait x1(t), 1 gate stage + cell + publish, 2 wait x2, 3 fc1, 4 wait y1, 5 fc2, 6 wait h2 (there), 7 gh stage; 15 = steps
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <bool LA, bool PROF>
+template <int MODE, bool LA, bool PROF>
 __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const int cl, const int ncl, const int J, const bool loc_a, const bool loc_b)
 {
     const int G = a.G;
@@ -102,11 +107,12 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
     const int mshift = a.hop_shift;
     const int zrow = a.Nall * a.tab_fps;
     float *const outp = a.out, *const dbgl = a.dbg_logits;
-    const float *const forcex = a.force_x, *const noise_pre = a.noise_pre;
+    const float *const forcex = a.force_x, *const noise_pre = a.noise_pre, *const noise_raw = a.noise;
     const float *const mels_up = a.mels_up, *const aux_fr = a.aux_fr, *const mel_coef = a.mel_coef;
     const int mel_stage = a.mel_stage;
     const int NR = a.Btot, NGR = a.NG;
     constexpr bool HAS_FC1 = !LA;
+    constexpr bool MOL = MODE == 1;
     float *const state_wg = a.state + ((size_t)(cl * CHWG + (LA ? 0 : 32) + J) * G) * CHSTATE_SLOT;
 
     // ---- weights: three gate tiles of W_ih and of W_hh; one tile of fc1 (HAS_FC1) and of fc2 (rnn2)
@@ -118,6 +124,12 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
     }
     if constexpr (HAS_FC1) load_afrag(A_fc1, a.fc1_w, H + AUX, LU * J + fi, true, kbase_lane);
     if constexpr (!LA) load_afrag(A_fc2, a.fc2_w, H + AUX, LU * J + fi, true, kbase_lane);
+    float A_f3[AF];                                     // RAW, rnn1: fc3 rows (classes) [16 J, 16 J + 16)
+    float b3 = 0.f;
+    if constexpr (LA && !MOL) {
+        load_afrag(A_f3, a.fc3_w, H, LU * J + fi, true, kbase_lane);
+        b3 = a.fc3_b[prow];
+    }
     // constants of the pointwise role: rnn1: b_ih1, u1 = W_ih1 . w0 (the x_{t-1} term), w0 (rnn2's b_ih2 is inside c2f); b_hh
     float cb_r = 0.f, cb_z = 0.f, cb_n = 0.f, ux_r = 0.f, ux_z = 0.f, ux_n = 0.f, w0o = 0.f;
     if constexpr (LA) {
@@ -152,10 +164,11 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
         ST[(i * 8 + 0) * NT + tid] = sv.x; ST[(i * 8 + 1) * NT + tid] = sv.y; ST[(i * 8 + 2) * NT + tid] = sv.z; ST[(i * 8 + 3) * NT + tid] = sv.w;
     }
     const bool sampler = LA && J < nact;                // rnn1's workgroup i runs fc3 + the sampling of slot i
-    if (sampler) {                                      // fc3 -> LDS (fragment order as in the pack)
+    if (MOL && sampler) {                               // fc3 -> LDS (fragment order as in the pack)
         for (int q = tid; q < 2 * XT / 4; q += NT) reinterpret_cast<float4 *>(F3)[q] = reinterpret_cast<const float4 *>(a.fc3f)[q];
         if (tid < 32) fc3b[tid] = tid < 30 ? a.fc3_b[tid] : 0.f;
     }
+    float *const LGT = F3;                              // RAW: the gathered logits of the slot being sampled
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.xbuf, (unsigned)(DXBUF_FLOATS * 4));
@@ -287,7 +300,9 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             const float gir = ST[(i * 8 + 4) * NT + tid] + fmaf(xv, ux_r, cb_r), giz = ST[(i * 8 + 5) * NT + tid] + fmaf(xv, ux_z, cb_z),
                         gin = ST[(i * 8 + 6) * NT + tid] + fmaf(xv, ux_n, cb_n);
             const float xin = fmaf(w0o, xv, ST[(i * 8 + 7) * NT + tid]);      // xi of the owned unit (:208-209)
-            const float h = gru_update_fast(gir, giz, gin, ST[(i * 8 + 1) * NT + tid], ST[(i * 8 + 2) * NT + tid], ST[(i * 8 + 3) * NT + tid], ST[(i * 8 + 0) * NT + tid]);
+            // MoL: hardware exp / rcp (inside the 1e-5 tolerance); RAW (class indices compared bit for bit): the library forms
+            const float h = MOL ? gru_update_fast(gir, giz, gin, ST[(i * 8 + 1) * NT + tid], ST[(i * 8 + 2) * NT + tid], ST[(i * 8 + 3) * NT + tid], ST[(i * 8 + 0) * NT + tid])
+                                : gru_update(gir, giz, gin, ST[(i * 8 + 1) * NT + tid], ST[(i * 8 + 2) * NT + tid], ST[(i * 8 + 3) * NT + tid], ST[(i * 8 + 0) * NT + tid]);
             ST[(i * 8 + 0) * NT + tid] = h;
             const int sb = cb + (t & (DRING - 1)) * XTB;
             publish4l(xrs, sb + 5 * DLAYERB + J * 1024, tid, xin + h, plive, false);      // x1 = xi + h1 (:212)
@@ -295,6 +310,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             // ring hygiene: behind the poll of x_{t-1}, which needed everything of step t - 1: every reader is past the data of step t - 2
             rearm1(i, 0, 0, loc_a);
             rearm1(i, 5, 1, false);
+            if constexpr (!MOL) rearm1(i, 16, 2, loc_a);
             CHX(1);
         };
         auto sample = [&](int i) {
@@ -347,6 +363,122 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             CHX(8);
         };
 
+        // ---- RAW: the workgroup's 16 logit rows of slot i (fc3 on y2, :223) -> layer 16, read by the slot's sampling workgroup
+        auto logits = [&](int i) {
+            const int nb = nb_of(i), sb = cbase_of(i) + (t & (DRING - 1)) * XTB;
+            float s0, s1, s2;
+            unsigned dummy = 0u;
+            stage(N1{}, A_f3, A_f3, A_f3, sb + 3 * DLAYERB, nb, 0x851u, t, 7, s0, s1, s2, dummy, false);
+            publish4l(xrs, sb + 16 * DLAYERB + J * 1024, tid, s0 + b3, pj < nb, loc_a);
+            CHX(8);
+        };
+        // ---- RAW: fatchord_version.py:231-237: softmax -> Categorical (renormalise) -> argmax(p / q) -- wrnn_duo.hip's code: one wave per 4 segments, the
+        //      four handled in lock step; per segment the operation order is the reference's (class indices compared bit for bit)
+        auto sample_raw = [&](int i) {
+            const int nb = nb_of(i), b0g = GEO[2 * i], cb = cbase_of(i);
+            const bool live = fi < nb;
+            const int so = cb + 16 * DLAYERB + (t & (DRING - 1)) * XTB;
+            u32x4 x[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, so, 16 /* sc1 */);
+            if (__builtin_expect(!frag_there(x, live), 0))
+                wait_for([&] { return frag_there(x, live); },
+                         [&] {
+#pragma unroll
+                             for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, so, 16 /* sc1 */);
+                         },
+                         status, dead, 0x852u, t);
+            {
+                float *lp = LGT + fi * LDC + kbase_lane;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    *reinterpret_cast<float4 *>(lp + 16 * r) = make_float4(__uint_as_float(x[r].x), __uint_as_float(x[r].y), __uint_as_float(x[r].z), __uint_as_float(x[r].w));
+            }
+            lds_barrier();
+            {
+                constexpr int NS = 4;
+                float qn[NS][8], lg[NS][8], mx[NS], sum[NS], sum2[NS], best[NS];
+                int bidx[NS];
+                const size_t tn = (size_t)(t - noise_t0);
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    const int sjc = (4 * w + s4 < nb) ? 4 * w + s4 : nb - 1;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qn[s4][e] = noise_raw[(tn * Nall + b0g + sjc) * C + lane + 64 * e];
+                    mx[s4] = -INFINITY;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        lg[s4][e] = LGT[sjc * LDC + lane + 64 * e];
+                        mx[s4] = fmaxf(mx[s4], lg[s4][e]);
+                    }
+                }
+                if (dbgl) {
+#pragma unroll
+                    for (int s4 = 0; s4 < NS; ++s4)
+                        if (4 * w + s4 < nb)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) dbgl[((size_t)t * Nall + b0g + 4 * w + s4) * C + lane + 64 * e] = lg[s4][e];
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                    for (int s4 = 0; s4 < NS; ++s4) mx[s4] = fmaxf(mx[s4], __shfl_xor(mx[s4], m, 64));
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    sum[s4] = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { lg[s4][e] = expf(lg[s4][e] - mx[s4]); sum[s4] += lg[s4][e]; }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                    for (int s4 = 0; s4 < NS; ++s4) sum[s4] += __shfl_xor(sum[s4], m, 64);
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    sum2[s4] = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { lg[s4][e] = lg[s4][e] / sum[s4]; sum2[s4] += lg[s4][e]; }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                    for (int s4 = 0; s4 < NS; ++s4) sum2[s4] += __shfl_xor(sum2[s4], m, 64);
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    best[s4] = -INFINITY;
+                    bidx[s4] = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float rr = (lg[s4][e] / sum2[s4]) / qn[s4][e];
+                        if (rr > best[s4]) { best[s4] = rr; bidx[s4] = lane + 64 * e; }
+                    }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                    for (int s4 = 0; s4 < NS; ++s4) {
+                        const float ob = __shfl_xor(best[s4], m, 64);
+                        const int oi = __shfl_xor(bidx[s4], m, 64);
+                        if (ob > best[s4] || (ob == best[s4] && oi < bidx[s4])) { best[s4] = ob; bidx[s4] = oi; }
+                    }
+                if (lane == 0) {
+#pragma unroll
+                    for (int s4 = 0; s4 < NS; ++s4) {
+                        const int sj = 4 * w + s4;
+                        if (sj < nb) {
+                            float xv = 2.f * (float)bidx[s4] / ((float)C - 1.f) - 1.f;
+                            outp[(size_t)(b0g + sj) * Tall + t] = xv;
+                            if (forcex) xv = forcex[(size_t)(b0g + sj) * Tall + t];
+                            const ch_u32x2 q = {__float_as_uint(xv), (unsigned)t + 1u};
+                            if (loc_a) __builtin_amdgcn_raw_buffer_store_b64(q, xrs, sj * 8, cb + 7 * DLAYERB + (t & 1) * XTB, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b64(q, xrs, sj * 8, cb + 7 * DLAYERB + (t & 1) * XTB, 16 /* sc1 */);
+                        }
+                    }
+                }
+            }
+            lds_barrier();                              // LGT is read by every wave before the next step's gather overwrites it
+        };
+
         cond_step(T0);                                  // the two steps a launch starts with; every later cI is formed at the end of step t for t + 2
         if (T0 + 1 < T1) cond_step(T0 + 1);
 #pragma unroll 1
@@ -363,7 +495,13 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
                 for (int i = 0; i < nact; ++i) front(i, t + 1);
             }
             if (t + 2 < T1) { cond_step(t + 2); CHX(6); }
-            if (sampler) sample(J);
+            if constexpr (MOL) {
+                if (sampler) sample(J);
+            } else {
+#pragma unroll 1
+                for (int i = 0; i < nact; ++i) logits(i);
+                if (sampler) sample_raw(J);
+            }
         }
         // ---- what the next launch needs: x_{T1-1} of every slot; the sentinel in the cI entries of steps T1 and T1 + 1 (its first two steps are polled)
 #pragma unroll 1
@@ -397,7 +535,8 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             unsigned ow = 0u;
             float s0, s1, s2;
             stage(N3{}, A_ih[0], A_ih[1], A_ih[2], sb + 5 * DLAYERB, nb, 0x828u, t, 0, s0, s1, s2, ow, true);
-            const float h = gru_update_fast(s0 + c0, s1 + c1, s2 + c2, ST[(i * 8 + 1) * NT + tid], ST[(i * 8 + 2) * NT + tid], ST[(i * 8 + 3) * NT + tid], ST[(i * 8 + 0) * NT + tid]);
+            const float h = MOL ? gru_update_fast(s0 + c0, s1 + c1, s2 + c2, ST[(i * 8 + 1) * NT + tid], ST[(i * 8 + 2) * NT + tid], ST[(i * 8 + 3) * NT + tid], ST[(i * 8 + 0) * NT + tid])
+                                : gru_update(s0 + c0, s1 + c1, s2 + c2, ST[(i * 8 + 1) * NT + tid], ST[(i * 8 + 2) * NT + tid], ST[(i * 8 + 3) * NT + tid], ST[(i * 8 + 0) * NT + tid]);
             ST[(i * 8 + 0) * NT + tid] = h;
             publish4l(xrs, sb + 6 * DLAYERB + J * 1024, tid, __uint_as_float(ow) + h, pj < nb, loc_x2);      // x2 = x1 + h2 (:216)
             publish4l(xrs, sb + 1 * DLAYERB + J * 1024, tid, h, pj < nb, loc_b);
@@ -443,7 +582,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
 // Grid = 4 clusters x 64 workgroups of 256 threads (one per CU), cooperative launch; a cluster without a group leaves at once.  Placement
 // (speed only, verified at run time): block b is observed to run on XCD b % 8; cluster cl = XCDs 2 cl (its rnn1 workgroups) and 2 cl + 1
 // (rnn2, fc1, fc2); the 32 blocks of an XCD: unit blocks J = 0 .. 31.
-template <bool PROF>
+template <int MODE, bool PROF>
 __global__ __launch_bounds__(NT, 1) void wrnn_chain_kernel(const LoopArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -481,8 +620,8 @@ __global__ __launch_bounds__(NT, 1) void wrnn_chain_kernel(const LoopArgs a)
         __syncthreads();
     }
     const int ncl = CHCL;
-    if (layer == 0) ch_role<true, PROF>(a, smem, cl, ncl, J, loc_a, loc_b);
-    else ch_role<false, PROF>(a, smem, cl, ncl, J, loc_a, loc_b);
+    if (layer == 0) ch_role<MODE, true, PROF>(a, smem, cl, ncl, J, loc_a, loc_b);
+    else ch_role<MODE, false, PROF>(a, smem, cl, ncl, J, loc_a, loc_b);
 }
 
 int chain_clusters(int n_cus) { return n_cus >= CHCL * CHWG ? CHCL : 0; }
@@ -490,12 +629,13 @@ int chain_max_depth() { return CHMAXG; }
 size_t chain_state_floats(int G) { return (size_t)CHCL * CHWG * G * CHSTATE_SLOT; }
 size_t chain_xbuf_bytes(int G) { return (size_t)G * CHCL * DSLOTB; }
 
-hipError_t launch_chain(const LoopArgs &args, hipStream_t stream)
+hipError_t launch_chain(const LoopArgs &args, int mode, hipStream_t stream)
 {
-    if (!args.fc3f || !args.u1 || !args.xcc_tab || args.NG < 1 || args.G < 1 || args.G > CHMAXG || args.NG > CHCL * args.G) return hipErrorInvalidValue;
+    if ((mode == 1 && !args.fc3f) || !args.u1 || !args.xcc_tab || args.NG < 1 || args.G < 1 || args.G > CHMAXG || args.NG > CHCL * args.G) return hipErrorInvalidValue;
     const size_t lds = (size_t)ch_lds(args.G).total * sizeof(float);
     const bool prof = args.prof && !(args.tuning & 64);
-    const void *fn = prof ? (const void *)wrnn_chain_kernel<true> : (const void *)wrnn_chain_kernel<false>;
+    const void *fn = mode == 1 ? (prof ? (const void *)wrnn_chain_kernel<1, true> : (const void *)wrnn_chain_kernel<1, false>)
+                               : (prof ? (const void *)wrnn_chain_kernel<0, true> : (const void *)wrnn_chain_kernel<0, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     LoopArgs a = args;
