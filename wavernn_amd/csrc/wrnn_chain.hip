@@ -163,7 +163,9 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
         if (resume) sv = *reinterpret_cast<const float4 *>(state_wg + (size_t)i * CHSTATE_SLOT + tid * 4);
         ST[(i * 8 + 0) * NT + tid] = sv.x; ST[(i * 8 + 1) * NT + tid] = sv.y; ST[(i * 8 + 2) * NT + tid] = sv.z; ST[(i * 8 + 3) * NT + tid] = sv.w;
     }
-    const bool sampler = LA && J < nact;                // rnn1's workgroup i runs fc3 + the sampling of slot i
+    // MOL: rnn1's workgroup i runs fc3 + the sampling of slot i.  RAW: FOUR workgroups per slot -- workgroup J samples segments 4 (J & 3) .. + 3 of slot
+    // J >> 2, one segment per wave (the 512-class softmax of 16 segments on one workgroup took ~8 us of the chain: profiles/r05k_probe_raw_chain.json)
+    const bool sampler = LA && J < (MOL ? nact : 4 * nact);
     if (MOL && sampler) {                               // fc3 -> LDS (fragment order as in the pack)
         for (int q = tid; q < 2 * XT / 4; q += NT) reinterpret_cast<float4 *>(F3)[q] = reinterpret_cast<const float4 *>(a.fc3f)[q];
         if (tid < 32) fc3b[tid] = tid < 30 ? a.fc3_b[tid] : 0.f;
@@ -372,8 +374,8 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             publish4l(xrs, sb + 16 * DLAYERB + J * 1024, tid, s0 + b3, pj < nb, loc_a);
             CHX(8);
         };
-        // ---- RAW: fatchord_version.py:231-237: softmax -> Categorical (renormalise) -> argmax(p / q) -- wrnn_duo.hip's code: one wave per 4 segments, the
-        //      four handled in lock step; per segment the operation order is the reference's (class indices compared bit for bit)
+        // ---- RAW: fatchord_version.py:231-237: softmax -> Categorical (renormalise) -> argmax(p / q) -- wrnn_duo.hip's code: one segment per wave;
+        //      per segment the operation order is the reference's (class indices compared bit for bit); wave w of sampling workgroup J: segment 4 (J & 3) + w
         auto sample_raw = [&](int i) {
             const int nb = nb_of(i), b0g = GEO[2 * i], cb = cbase_of(i);
             const bool live = fi < nb;
@@ -396,13 +398,14 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             }
             lds_barrier();
             {
-                constexpr int NS = 4;
+                constexpr int NS = 1;
+                const int h0 = 4 * (J & 3) + w;         // this wave's segment
                 float qn[NS][8], lg[NS][8], mx[NS], sum[NS], sum2[NS], best[NS];
                 int bidx[NS];
                 const size_t tn = (size_t)(t - noise_t0);
 #pragma unroll
                 for (int s4 = 0; s4 < NS; ++s4) {
-                    const int sjc = (4 * w + s4 < nb) ? 4 * w + s4 : nb - 1;
+                    const int sjc = (h0 + s4 < nb) ? h0 + s4 : nb - 1;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) qn[s4][e] = noise_raw[(tn * Nall + b0g + sjc) * C + lane + 64 * e];
                     mx[s4] = -INFINITY;
@@ -415,9 +418,9 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
                 if (dbgl) {
 #pragma unroll
                     for (int s4 = 0; s4 < NS; ++s4)
-                        if (4 * w + s4 < nb)
+                        if (h0 + s4 < nb)
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) dbgl[((size_t)t * Nall + b0g + 4 * w + s4) * C + lane + 64 * e] = lg[s4][e];
+                            for (int e = 0; e < 8; ++e) dbgl[((size_t)t * Nall + b0g + h0 + s4) * C + lane + 64 * e] = lg[s4][e];
                 }
 #pragma unroll
                 for (int m = 32; m >= 1; m >>= 1)
@@ -464,7 +467,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
                 if (lane == 0) {
 #pragma unroll
                     for (int s4 = 0; s4 < NS; ++s4) {
-                        const int sj = 4 * w + s4;
+                        const int sj = h0 + s4;
                         if (sj < nb) {
                             float xv = 2.f * (float)bidx[s4] / ((float)C - 1.f) - 1.f;
                             outp[(size_t)(b0g + sj) * Tall + t] = xv;
@@ -500,7 +503,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             } else {
 #pragma unroll 1
                 for (int i = 0; i < nact; ++i) logits(i);
-                if (sampler) sample_raw(J);
+                if (sampler) sample_raw(J >> 2);
             }
         }
         // ---- what the next launch needs: x_{T1-1} of every slot; the sentinel in the cI entries of steps T1 and T1 + 1 (its first two steps are polled)

@@ -71,9 +71,6 @@
 namespace wrnn {
 
 // A/B build switches (measured: profiles/r04c_*, r04g_*, r04p_*)
-#ifndef DUO_RAW_LOCK
-#define DUO_RAW_LOCK 4                       // RAW sampler: segments of a wave handled in lock step (4 = all of them: 13 VGPR spills in that role; 2: none?)
-#endif
 #ifndef DUO_XR_FIRST
 #define DUO_XR_FIRST 1                       // 1 = the residual sum (on a slot's chain) is published before h (read a step later)
 #endif
@@ -521,8 +518,12 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     }
     __syncthreads();
     // rnn2's hh workgroup J samples slot J (y2 comes from rnn2's ih workgroups: the same XCD under the placement above)
-    const bool sampler = !LA && J < nact;
-    const int my_slot = J;
+    // MOL: rnn2's hh workgroup J samples slot J.  RAW (round 5): FOUR workgroups per slot -- workgroup J samples segments 4 (J & 3) .. + 3 of slot
+    // J >> 2, one segment per wave: the 512-class softmax -> Categorical -> argmax(p / q) of 16 segments took one workgroup ~8 us on the slot's chain
+    // (4 segments per wave in lock step; profiles/r05k_probe_raw_chain.json), the other hh workgroups were waiting meanwhile
+    const bool sampler = !LA && J < (MOL ? nact : 4 * nact);
+    const int my_slot = MOL ? J : (J >> 2);
+    const int quad = J & 3;
     if (MOL && sampler) {                               // fc3's first tile -> LDS (fragment order as in the pack)
         for (int q = tid; q < XT / 4; q += NT) reinterpret_cast<float4 *>(F3)[q] = reinterpret_cast<const float4 *>(a.fc3f)[q];
     }
@@ -714,9 +715,13 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             // ring hygiene (see the header): drain, then re-arm the x_t words of the slot this workgroup samples in entry (t + 3) % 4
             // (the gh words carry a step tag instead of relying on a sentinel: nothing to re-arm)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 48) {                           // the 4 x_t words of segments 4 w ..
-                const u32x4 q = {SENT, SENT, SENT, SENT};
-                __builtin_amdgcn_raw_buffer_store_b128(q, xrs, 16 * w, sbase + 7 * DLAYERB + ((t + DAHEAD_HH) & (DRING - 1)) * XTB, 16 /* sc1 */);
+            if (MOL) {
+                if (lane == 48) {                       // the 4 x_t words of segments 4 w ..
+                    const u32x4 q = {SENT, SENT, SENT, SENT};
+                    __builtin_amdgcn_raw_buffer_store_b128(q, xrs, 16 * w, sbase + 7 * DLAYERB + ((t + DAHEAD_HH) & (DRING - 1)) * XTB, 16 /* sc1 */);
+                }
+            } else if (lane == 48) {                    // RAW: this wave's ONE word (segment 4 quad + w)
+                __builtin_amdgcn_raw_buffer_store_b32(SENT, xrs, (4 * quad + w) * 4, sbase + 7 * DLAYERB + ((t + DAHEAD_HH) & (DRING - 1)) * XTB, 16 /* sc1 */);
             }
         }
         float b[32];
@@ -749,8 +754,8 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             put_partial<3>(PW, w, 0, lane, mfma1(A_f3, b));
             pend = BK_LG;
         } else if constexpr (kind == 4) {
-            // fatchord_version.py:231-237: softmax -> Categorical (renormalise) -> argmax(p / q) -- the loop kernel's code: one wave per 4 segments,
-            // the four handled in lock step; per segment the operation order is the reference's (class indices compared bit for bit)
+            // fatchord_version.py:231-237: softmax -> Categorical (renormalise) -> argmax(p / q) -- the loop kernel's code, ONE segment per wave (4 quad + w);
+            // per segment the operation order is the reference's (class indices compared bit for bit)
             const int b0 = GEO[2 * i];
             {
                 float *lp = LGT + fi * LDC + kbase_lane;
@@ -758,18 +763,16 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
                 for (int r = 0; r < 8; ++r) *reinterpret_cast<float4 *>(lp + 16 * r) = make_float4(b[4 * r], b[4 * r + 1], b[4 * r + 2], b[4 * r + 3]);
             }
             lds_barrier();
-            // One wave per 4 segments, DUO_RAW_LOCK of them in lock step (straight-line code: that many independent butterfly chains in
-            // flight); per segment the operation order is the reference's.  The Exp(1) variates (2 KB per segment and step, streamed
-            // from HBM) are requested before the softmax passes that do not need them yet.
-#pragma unroll
-            for (int h0 = 0; h0 < 4; h0 += DUO_RAW_LOCK) {
-                constexpr int NS = DUO_RAW_LOCK;
+            // The Exp(1) variates (2 KB per segment and step, streamed from HBM) are requested before the softmax passes that do not need them yet.
+            {
+                constexpr int NS = 1;
+                const int h0 = 4 * quad + w;            // this wave's segment
                 float qn[NS][8], lg[NS][8], mx[NS], sum[NS], sum2[NS], best[NS];
                 int bidx[NS];
                 const size_t tn = (size_t)(t - noise_t0);
 #pragma unroll
                 for (int s4 = 0; s4 < NS; ++s4) {
-                    const int sjc = (4 * w + h0 + s4 < nb) ? 4 * w + h0 + s4 : nb - 1;
+                    const int sjc = (h0 + s4 < nb) ? h0 + s4 : nb - 1;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) qn[s4][e] = noise_raw[(tn * Nall + b0 + sjc) * C + lane + 64 * e];
                     mx[s4] = -INFINITY;
@@ -782,9 +785,9 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
                 if (dbgl) {
 #pragma unroll
                     for (int s4 = 0; s4 < NS; ++s4)
-                        if (4 * w + h0 + s4 < nb)
+                        if (h0 + s4 < nb)
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) dbgl[((size_t)t * Nall + b0 + 4 * w + h0 + s4) * C + lane + 64 * e] = lg[s4][e];
+                            for (int e = 0; e < 8; ++e) dbgl[((size_t)t * Nall + b0 + h0 + s4) * C + lane + 64 * e] = lg[s4][e];
                 }
 #pragma unroll
                 for (int m = 32; m >= 1; m >>= 1)
@@ -831,7 +834,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
                 if (lane == 0) {
 #pragma unroll
                     for (int s4 = 0; s4 < NS; ++s4) {
-                        const int sj = 4 * w + h0 + s4;
+                        const int sj = h0 + s4;
                         if (sj < nb) {
                             float xv = 2.f * (float)bidx[s4] / ((float)C - 1.f) - 1.f;
                             outp[(size_t)(b0 + sj) * Tall + t] = xv;
