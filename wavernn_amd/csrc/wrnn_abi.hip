@@ -384,7 +384,7 @@ int enqueue_progress(const wrnn_options *o, int done, int T, int n, hipStream_t 
 enum Kind { K_STREAM, K_LOOP, K_SPARSE, K_DUO, K_GENERIC, K_CHAIN };
 constexpr int DUO_TAB_FPS = 8;       // wrnn_duo_kernel: rows per segment of the per-slab aux tables: a slab covers at most (DUO_TAB_FPS - 2) hops + 1 steps
 constexpr bool DUO_AUTO = true;      // `auto` runs MoL on wrnn_duo_kernel at every depth (round 4, profiles/r04a_probe_new.json: 13.5 vs 16.6 us per step
-constexpr int CHAIN_AUTO_GROUPS = 8;   // `auto` runs MOL calls of up to this many groups (128 segments) on wrnn_chain_kernel: one / two groups per cluster, 10.4 / 13.8 us
+constexpr int CHAIN_AUTO_GROUPS = 8;   // `auto` runs calls of up to this many groups (128 segments) on wrnn_chain_kernel: one / two groups per cluster, 10.4 / 13.8 us (RAW: 12.8 / 16.3)
                                        // per step against wrnn_duo_kernel's 12.2 / 16.9; from three groups on the duo kernel wins (profiles/r05i_probe_chain_depths.json)
 constexpr int DUO_MIN_DEPTH = 1;     // with one group in flight, 17.9 vs 21.7 with two, 26.2 vs 36 with four; round 3's kernel paid off from depth 3 on)
 
@@ -441,7 +441,7 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
         pl->kind = K_GENERIC;
         return WRNN_OK;
     }
-    // wrnn_chain_kernel (MOL, 256 CUs): one workgroup per CU, one instruction stream per wave.  `auto`: <= 128 segments -- <= 64 (one utterance
+    // wrnn_chain_kernel (MOL and 9-bit RAW, 256 CUs): one workgroup per CU, one instruction stream per wave.  `auto`: <= 128 segments -- <= 64 (one utterance
     // of BASELINE config 2 / 3): one group per 64-CU cluster, a step is the latency of one chain; <= 128: two groups per cluster --; on
     // request (algo = chain) also with up to 4 groups in flight per cluster (wrnn_options.depth) and rounds beyond that
     const int ccl = chain_clusters(p->n_cus);

@@ -24,7 +24,7 @@
 //     tests/test_sparse_exchange_model.py); what differs is who publishes what.
 //   * 9-bit RAW (fatchord_version.py:231-237): fc3 has 512 rows -- rnn1's workgroup J (idle while the chain runs through rnn2) owns rows [16 J, 16 J + 16): one
 //     more stage (32 MFMAs on y2) and one more same-XCD hop (the 512 logits, layer 16) in front of the sampling, which is wrnn_duo.hip's: softmax ->
-//     Categorical (renormalise) -> argmax(p / q) in the reference's operation order, one wave per 4 segments; the GRU cells use the library exp / tanh.
+//     Categorical (renormalise) -> argmax(p / q) in the reference's operation order, on rnn1's workgroups 4 s .. 4 s + 3 for slot s, one segment per wave; the GRU cells use the library exp / tanh.
 //     Bit-identical to wrnn_duo_kernel's RAW output (same stage arithmetic), i.e. to the reference on every fixture.
 //   * conditioning slabs, state between launches (4 floats per (unit, segment)), step-range continuation: as wrnn_duo.hip / wrnn_sparse.hip.
 //   * TWO (up to four) groups per cluster (wrnn_options.depth; `auto`: 65 .. 128 segments): every stage becomes a loop over the cluster's slots --
