@@ -15,7 +15,10 @@ The arguments for those distances are statements about how far workgroups can dr
 timing instead: stores become visible after random delays, out of program order, now and then later than several whole steps (only a
 drain waits for them); every stage takes a random time.  Checked: whatever a consumer accepts carries the tag of ITS step in every word,
 a re-arm never lands on data that is still to be read or that is newer than the turn it was issued for (a dead-lock, also caught as "no
-progress"), nobody overwrites a gh word that is still to be read, everybody finishes.  The broken variants at the end show that the model
+progress"), nobody overwrites a gh word that is still to be read, everybody finishes.  `raw=True` adds what 9-bit RAW adds (round 5's form): a
+sixth sentinel layer -- the logit rows every rnn2 hh workgroup publishes for every slot behind its poll of y2, re-armed THREE ahead behind the
+step's last y2 poll and a drain -- and `spp` sampling workgroups per slot (the kernel: four), each polling all logit rows of its slot and
+publishing / re-arming ITS OWN x_t words.  The broken variants at the end show that the model
 is not vacuous: each of the shortcuts the header argues against is caught for some timing.  A model of the protocol, not of the HIP code
 -- tests/test_gpu_parity.py covers that."""
 import heapq
@@ -27,8 +30,9 @@ SENT = None
 
 class DuoSim:
     def __init__(self, seed, n_wg=3, slots=2, steps=24, ahead_ih=2, ahead_hh=3, cond_ahead=2, cond_drain=True, ih_drain=True,
-                 ih_drain_at_rearm=False, gh_shift=True):
-        assert slots <= n_wg                                # rnn2's hh workgroup j samples slot j
+                 ih_drain_at_rearm=False, gh_shift=True, raw=False, spp=1, ahead_lg=3, lg_drain=True):
+        assert spp * slots <= n_wg                          # rnn2's hh workgroup j samples slot j (RAW: slot j // spp, as its sampler j % spp)
+        self.raw, self.spp, self.ahead_lg, self.lg_drain = raw, (spp if raw else 1), ahead_lg, lg_drain
         self.rng = random.Random(seed)
         self.n_wg, self.G, self.steps = n_wg, slots, steps
         self.ahead_ih, self.ahead_hh, self.cond_ahead, self.cond_drain = ahead_ih, ahead_hh, cond_ahead, cond_drain
@@ -37,7 +41,8 @@ class DuoSim:
         ring = lambda n: [[[SENT] * n_wg for _ in range(n)] for _ in range(slots)]          # [slot][entry][producer]
         self.mem = {l: ring(RING) for l in ('h1', 'x1', 'y1', 'h2', 'x2', 'y2', 'cI')}
         self.mem['gh1'], self.mem['gh2'] = ring(GHRING), ring(GHRING)
-        self.mem['xt'] = [[[SENT] for _ in range(RING)] for _ in range(slots)]              # one producer: the slot's sampler
+        self.mem['xt'] = [[[SENT] * self.spp for _ in range(RING)] for _ in range(slots)]   # one producer per sampler of the slot (MOL: one)
+        self.mem['lg'] = ring(RING)                                                         # RAW: the logit rows of every rnn2 hh workgroup
         self.now, self.events, self.seq = 0.0, [], 0
         self.pending, self.violations, self.done = {}, [], 0
         self.rearm_turn = {}
@@ -116,13 +121,16 @@ class DuoSim:
     def program(self, role, j):
         who, G, n = (role, j), self.G, self.n_wg
 
+        def word(layer):
+            return j if layer != 'xt' else j % self.spp
+
         def publish(layer, i, t):
-            self.store(who, layer, i, t % RING, j if layer != 'xt' else 0, t)
+            self.store(who, layer, i, t % RING, word(layer), t)
 
         def rearm(layers, t, ahead, slots):
             for layer in layers:
                 for i in slots:
-                    self.store(who, layer, i, (t + ahead) % RING, j if layer != 'xt' else 0, SENT, rearm_turn=t + ahead - RING + 1)
+                    self.store(who, layer, i, (t + ahead) % RING, word(layer), SENT, rearm_turn=t + ahead - RING + 1)
 
         if role in ('Aih', 'Bih'):
             a = role == 'Aih'
@@ -178,7 +186,23 @@ class DuoSim:
                         self.store(who, 'gh2', i, (tt + 1) % GHRING, j, tt + 1)
                 if t == self.steps:
                     break
-                if j < G:                                    # the sampler of slot j
+                if self.raw:
+                    for i in range(G):                       # logits stages: this workgroup's rows of fc3 for every slot
+                        yield ('poll', ('y2', i, t))
+                        if i == G - 1:                       # behind the last y2 poll of the step: drain, re-arm the own rows of every slot
+                            if self.lg_drain:
+                                yield ('drain', who)
+                            rearm(('lg',), t, self.ahead_lg, range(G))
+                        yield ('work', 0.4)
+                        publish('lg', i, t)
+                    if j < self.spp * G:                     # sampler j % spp of slot j // spp: its own x_t words
+                        slot = j // self.spp
+                        yield ('poll', ('lg', slot, t))
+                        yield ('drain', who)
+                        rearm(('xt',), t, self.ahead_hh, [slot])
+                        yield ('work', 0.6)
+                        publish('xt', slot, t)
+                elif j < G:                                  # the sampler of slot j
                     yield ('poll', ('y2', j, t))
                     yield ('drain', who)
                     rearm(('xt',), t, self.ahead_hh, [j])
@@ -191,6 +215,14 @@ def test_duo_exchange_is_safe_under_adversarial_timing():
         for slots in (1, 2, 3):
             v = DuoSim(seed, n_wg=3, slots=slots, steps=24).run()
             assert not v, (seed, slots, v[:3])
+
+
+def test_duo_exchange_raw_form_is_safe_under_adversarial_timing():
+    """9-bit RAW: the logits layer and several sampling workgroups per slot (csrc/wrnn_duo.hip: kind-2 and kind-4 stages)."""
+    for seed in range(30):
+        for n_wg, slots, spp in ((4, 2, 2), (4, 1, 4), (3, 3, 1), (6, 3, 2)):
+            v = DuoSim(seed, n_wg=n_wg, slots=slots, steps=24, raw=True, spp=spp).run()
+            assert not v, (seed, n_wg, slots, spp, v[:3])
 
 
 def test_other_safe_distances():
@@ -216,3 +248,7 @@ def test_duo_model_detects_the_shortcuts():
     assert broken(cond_drain=False)
     # the sampler's x_t one ahead: its publication of this step can overtake the re-arm
     assert broken(ahead_hh=1)
+    # RAW: the same for the logit rows; and their re-arm without the drain in front of it
+    # (seen on a workgroup that does not sample: a sampler's own drain, in front of its x_t re-arm, happens to cover the logit rows too)
+    assert broken(raw=True, n_wg=6, slots=2, spp=2, ahead_lg=1)
+    assert broken(raw=True, n_wg=4, slots=2, spp=2, ahead_hh=1)
