@@ -82,6 +82,71 @@ def simulate(G, steps=60, a_order=None, b_order=None, s_order=None):
     return (done_step[(0, b)] - done_step[(0, a)]) / (b - a)
 
 
+def simulate_v2(G, steps=60, hh_order=None, bs_order=None, look=0.5):
+    """The OTHER cut of the four roles (not built): the fc stages on the hh workgroups (A-hh: gh1 + fc1, B-hh: gh2 + fc2), the sampling on rnn2's ih
+    workgroups (B-ih s: gates + sample(s)), rnn1's ih workgroups: gates only.  Busy time per slot-step 3.5 | 3.6 (+ 2.2 once) | 4.55 | 4.55 us instead
+    of 5.55 | 5.65 | 2.5 | 2.5 (+ 2.2).  hh_order: the hh workgroups' stage order, [('h' | 'f', slot)]."""
+    ev = {}   # (name, slot, step) -> time available at consumer
+    for i in range(G): ev[('xt', i, -1)] = 0.0; ev[('h1', i, -1)] = 0.0; ev[('h2', i, -1)] = 0.0
+    def ord_hh(): return hh_order(G) if hh_order else [('h', i) for i in range(G)] + [('f', i) for i in range(G)]
+    prog = {'A': [(t,'g',i) for t in range(steps) for i in range(G)]}
+    for s in range(G):
+        o = bs_order(s, G) if bs_order else [('g', i) for i in range(G)] + [('s', s)]
+        prog[('B', s)] = [(t,k,i) for t in range(steps) for k,i in o]
+    prog['AH'] = [(t,k,i) for t in range(steps) for k,i in ord_hh()]
+    prog['BH'] = [(t,k,i) for t in range(steps) for k,i in ord_hh()]
+    free = {k: 0.0 for k in prog}; pos = {k: 0 for k in prog}
+    done = {}
+    # x2 of a slot needs ALL B-ih servers' gates of that slot: track per server and take max
+    bdone = {}
+    progress = True
+    while progress:
+        progress = False
+        for srv in prog:
+            while pos[srv] < len(prog[srv]):
+                t,k,i = prog[srv][pos[srv]]; now = free[srv]
+                if srv == 'A':
+                    need = ev.get(('xt', i, t-1)); gh = ev.get(('gh1', i, t)) if t > 0 else 0.0
+                    if need is None or gh is None: break
+                    end = max(now + A_G_MFMA, need, gh) + A_G_BACK
+                    ev[('x1', i, t)] = end + HOP; ev[('h1', i, t)] = end + HOP
+                elif isinstance(srv, tuple) and k == 'g':
+                    need = ev.get(('x1', i, t)); gh = ev.get(('gh2', i, t)) if t > 0 else 0.0
+                    if need is None or gh is None: break
+                    end = max(max(now, need) + B_G_MFMA, gh) + B_G_BACK
+                    bdone[(srv, i, t)] = end + HOP
+                    if all((('B', s), i, t) in bdone for s in range(G)):
+                        v = max(bdone[(('B', s), i, t)] for s in range(G))
+                        ev[('x2', i, t)] = v; ev[('h2', i, t)] = v
+                elif isinstance(srv, tuple):
+                    need = ev.get(('y2', i, t))
+                    if need is None: break
+                    end = max(now, need - look) + SAMPLE
+                    ev[('xt', i, t)] = end + HOP; done[(i, t)] = end
+                elif srv == 'AH' and k == 'h':
+                    need = ev.get(('h1', i, t))
+                    if need is None: break
+                    end = max(now, need - look) + GH
+                    ev[('gh1', i, t+1)] = end + 0.7
+                elif srv == 'AH':
+                    need = ev.get(('x2', i, t))
+                    if need is None: break
+                    end = max(now, need - look) + FC_MFMA + FC_BACK
+                    ev[('y1', i, t)] = end + HOP
+                elif srv == 'BH' and k == 'h':
+                    need = ev.get(('h2', i, t))
+                    if need is None: break
+                    end = max(now, need - look) + GH
+                    ev[('gh2', i, t+1)] = end + 0.7
+                else:
+                    need = ev.get(('y1', i, t))
+                    if need is None: break
+                    end = max(now, need - look) + FC_MFMA + FC_BACK
+                    ev[('y2', i, t)] = end + 0.7
+                free[srv] = end; pos[srv] += 1; progress = True
+    a, b = steps//3, steps-2
+    return (done[(0,b)] - done[(0,a)])/(b-a)
+
 def sampler_early(s, G):
     """sample before the last gh stage (when the slot is not the last one)"""
     o = [('h', i) for i in range(G)]
@@ -102,9 +167,14 @@ def interleaved(G, lag):
 if __name__ == '__main__':
     # (the kernel's order since the end of round 4 is the second column: the last slot's gh stage deferred behind the sampling stage;
     # measured: 24.8 -> 23.7 us at depth 4, 41.2 -> 40.5 at depth 8, profiles/r04p_probe.json)
-    print('depth: us per step (model) for gh(0..n-1) | sample | the last gh stage behind the sampling stage | ih stages interleaved with lag 1, 2, 3')
+    print('depth: us per step (model) for gh(0..n-1) | sample | the last gh stage behind the sampling stage | ih stages interleaved with lag 1, 2, 3 | fc stages on the hh workgroups, sampling on B-ih (not built)')
     for G in range(1, 9):
         base = simulate(G)
         early = simulate(G, s_order=sampler_early)
         inter = [simulate(G, a_order=interleaved(G, l), b_order=interleaved(G, l), s_order=sampler_early) if l < G or G == 1 else float('nan') for l in (1, 2, 3)]
-        print(f'{G}: {base:6.2f} | {early:6.2f} | ' + ' '.join(f'{x:6.2f}' for x in inter))
+        fc_first = simulate_v2(G, hh_order=lambda n: [('f', i) for i in range(n)] + [('h', i) for i in range(n)])
+        print(f'{G}: {base:6.2f} | {early:6.2f} | ' + ' '.join(f'{x:6.2f}' for x in inter) + f' | {fc_first:6.2f}')
+    # Round 5's reading of the last column: with four slots in flight a step is as much the latency of a slot's chain behind the other slots'
+    # stages as it is the busiest workgroup's work (no single duration moves it: -20 % on any one of them is -0 .. -3 %), so re-balancing the
+    # roles buys ~3 % at depth 4 (22.3 us with the best of the 70 interleavings of gh and fc stages) and 18 % at depth 8 -- not what the
+    # 256-segment workload needs.
