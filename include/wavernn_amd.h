@@ -259,10 +259,11 @@ int wrnn_timer_launches(const wrnn_timer *t);
  */
 typedef struct wrnn_pre_weights {
     int32_t feat_dims;            /* 80 */
-    int32_t compute_dims;         /* C: 128 in this build */
-    int32_t res_out_dims;         /* R: 128 in this build */
+    int32_t compute_dims;         /* C (shipped: 128) */
+    int32_t res_out_dims;         /* R (shipped: 128) */
     int32_t res_blocks;           /* number of ResBlocks */
-    int32_t pad;                  /* 2 */
+    int32_t pad;                  /* 2.  Any dims the reference's constructor takes (fatchord_version.py:64-71): (80, 128, 128, pad 2) run the f32-MFMA
+                                     MelResNet kernel, everything else wrnn_resnet_generic_kernel (round 5) */
     int32_t upsample_factors[3];  /* (5, 5, 11) */
     const float *conv_in_w;       /* upsample.resnet.conv_in.weight (C, feat, 2*pad+1) */
     const float *bn_in;           /* upsample.resnet.batch_norm.{weight,bias,running_mean,running_var}: [4][C] */

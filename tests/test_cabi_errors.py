@@ -61,9 +61,14 @@ def test_no_device_is_an_error_not_a_fallback(L):
         setattr(pw, n, z.ctypes.data)
     pre = ctypes.c_void_p()
     assert L.wrnn_pre_create(ctypes.byref(pw), 0, ctypes.byref(pre)) == ERR_NO_DEVICE
-    pw.compute_dims = 64
+    pw.compute_dims = 64                                    # (round 5: any UpsampleNetwork dims are taken -- the next check is the device)
+    assert L.wrnn_pre_create(ctypes.byref(pw), 0, ctypes.byref(pre)) == ERR_NO_DEVICE
+    pw.compute_dims = 0
     assert L.wrnn_pre_create(ctypes.byref(pw), 0, ctypes.byref(pre)) == ERR_ARG
     assert b'compute_dims' in L.wrnn_pre_last_error()
+    pw.compute_dims, pw.feat_dims = 4096, 4096              # not even one frame of such a network fits a workgroup's LDS
+    assert L.wrnn_pre_create(ctypes.byref(pw), 0, ctypes.byref(pre)) == ERR_ARG
+    assert b'too wide' in L.wrnn_pre_last_error()
 
 
 def test_null_handles_are_rejected(L):

@@ -10,6 +10,10 @@
 //          rows [32w, 32w+32) with the full K, so there is no cross-wave reduction; weights stream from L2 per layer.
 // K-pre-2  wrnn_upstage_kernel x 3: Stretch2d(s,1) + Conv2d(1,1,(1,2s+1), padding (0,s)) per mel channel, the last
 //          stage writes [sample][channel] and applies the `indent` crop (:88).
+// K-pre-1g wrnn_resnet_generic_kernel (round 5): the same network for ANY feat_dims / compute_dims / res_out_dims / pad / res_blocks the
+//          reference's constructor takes (:64-71; hparams.py:38-44 are only defaults) -- a tile of frames per workgroup in LDS, one output
+//          per thread and trip, k ascending in one fmaf chain; the up-sampling stages take the channel count at run time (F = 0).  The
+//          shipped dims keep the MFMA kernel.
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -20,7 +24,7 @@
 
 namespace wrnn {
 
-constexpr int PC = 128;           // compute_dims == res_out_dims (this build)
+constexpr int PC = 128;           // compute_dims == res_out_dims of the MFMA kernel (other dims: wrnn_resnet_generic_kernel)
 constexpr int PFEAT = MEL;        // 80
 constexpr int PK = 5;             // conv_in taps = 2*pad + 1
 constexpr int PPAD = 2;
@@ -138,23 +142,81 @@ __global__ __launch_bounds__(256) void wrnn_resnet_kernel(const PreArgs a)
     }
 }
 
+// MelResNet for any dims (see the header).  Dynamic LDS: MW[feat][gf + 2 pad] (the zero-padded mel window of the tile: :185 pads `pad` frames
+// each side, conv_in has no padding of its own, :35), XA[gf][C], XB[gf][C].  Thread -> (row c, frame j) with j fastest: a wave reads one or a
+// few weight rows (broadcast) and consecutive LDS words.
+struct GenPreArgs {
+    PreArgs p;
+    int feat, C, R, pad, gf;
+};
+__global__ __launch_bounds__(256) void wrnn_resnet_generic_kernel(const GenPreArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    const PreArgs &a = g.p;
+    const int feat = g.feat, C = g.C, R = g.R, pad = g.pad, GF = g.gf, K = 2 * pad + 1, WW = GF + 2 * pad;
+    float *MW = gsm, *XA = MW + feat * WW, *XB = XA + GF * C;
+    const int tid = threadIdx.x, N = a.N;
+    const int j0 = blockIdx.x * GF;
+    for (int q = tid; q < feat * WW; q += 256) {
+        const int c = q / WW, f = j0 + q % WW - pad;
+        MW[q] = (f >= 0 && f < N) ? a.mel[(size_t)c * N + f] : 0.f;
+    }
+    __syncthreads();
+    // conv_in -> BN -> ReLU (:43-44): weight [C][feat][K]
+    for (int o = tid; o < C * GF; o += 256) {
+        const int c = o / GF, j = o % GF;
+        const float *wr = a.conv_in_w + (size_t)c * feat * K;
+        float acc = 0.f;
+        for (int ci = 0; ci < feat; ++ci)
+            for (int t = 0; t < K; ++t) acc = fmaf(wr[ci * K + t], MW[ci * WW + j + t], acc);
+        XA[j * C + c] = fmaxf(fmaf(acc, a.bn_in[c], a.bn_in[C + c]), 0.f);
+    }
+    __syncthreads();
+    for (int b = 0; b < a.blocks; ++b) {                  // residual blocks (:21-28)
+        const float *W1 = a.res_w + (size_t)(2 * b) * C * C, *W2 = W1 + (size_t)C * C;
+        const float *bn1 = a.res_bn + (size_t)(2 * b) * 2 * C, *bn2 = bn1 + 2 * C;
+        for (int o = tid; o < C * GF; o += 256) {
+            const int c = o / GF, j = o % GF;
+            float acc = 0.f;
+            for (int k = 0; k < C; ++k) acc = fmaf(W1[(size_t)c * C + k], XA[j * C + k], acc);
+            XB[j * C + c] = fmaxf(fmaf(acc, bn1[c], bn1[C + c]), 0.f);
+        }
+        __syncthreads();
+        for (int o = tid; o < C * GF; o += 256) {         // XA[j][c] is read and written by this thread only
+            const int c = o / GF, j = o % GF;
+            float acc = 0.f;
+            for (int k = 0; k < C; ++k) acc = fmaf(W2[(size_t)c * C + k], XB[j * C + k], acc);
+            XA[j * C + c] += fmaf(acc, bn2[c], bn2[C + c]);
+        }
+        __syncthreads();
+    }
+    for (int o = tid; o < R * GF; o += 256) {             // conv_out + bias (:47) -> aux[frame][channel]
+        const int r = o / GF, j = o % GF;
+        float acc = 0.f;
+        for (int k = 0; k < C; ++k) acc = fmaf(a.conv_out_w[(size_t)r * C + k], XA[j * C + k], acc);
+        if (j0 + j < N) a.aux[(size_t)(j0 + j) * R + r] = acc + a.conv_out_b[r];
+    }
+}
+
 // One Stretch2d(s,1) + Conv2d(1,1,(1,2s+1), padding (0,s), bias=False) stage (:73-80, :86-87) on [PFEAT][n_in] rows.
 //   out[c][q] = sum_j w[j] * rep(q + j - s),  rep(u) = in[c][u / s] for 0 <= u < n_in*s, else 0 (the conv's zero padding)
 // FIRST: `in` is the un-padded mel [PFEAT][n_in - 2*pad]; frames outside it are the zero padding of :185.
 // LAST:  writes out_t[q - indent][c] for indent <= q < n_out - indent (the crop of :88, transposed to [sample][channel]).
-// S > 0: the stretch factor as a compile-time constant (the divisions become multiplies); S = 0: runtime `s_rt`.
-template <bool FIRST, bool LAST, int S>
+// S > 0: the stretch factor as a compile-time constant (the divisions become multiplies); S = 0: runtime `s_rt`.  F: the channel count
+// (PFEAT), F = 0: runtime `feat_rt`.
+template <bool FIRST, bool LAST, int S, int F = PFEAT>
 __global__ __launch_bounds__(256) void wrnn_upstage_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                           const float *__restrict__ taps, int n_in, int s_rt, int pad, int indent)
+                                                           const float *__restrict__ taps, int n_in, int s_rt, int pad, int indent, int feat_rt = PFEAT)
 {
     const int s = S > 0 ? S : s_rt;
+    const int feat = F > 0 ? F : feat_rt;
     const long n_out = (long)n_in * s;
-    const long total = LAST ? (n_out - 2L * indent) * PFEAT : n_out * PFEAT;
+    const long total = LAST ? (n_out - 2L * indent) * feat : n_out * feat;
     const int ld_in = FIRST ? n_in - 2 * pad : n_in;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         int c;
         long q;
-        if (LAST) { c = (int)(idx % PFEAT); q = idx / PFEAT + indent; }
+        if (LAST) { c = (int)(idx % feat); q = idx / feat + indent; }
         else { c = (int)(idx / n_out); q = idx % n_out; }
         float acc = 0.f;
 #pragma unroll
@@ -168,7 +230,7 @@ __global__ __launch_bounds__(256) void wrnn_upstage_kernel(const float *__restri
             }
             acc = fmaf(taps[j], v, acc);
         }
-        if (LAST) out[(size_t)(q - indent) * PFEAT + c] = acc;
+        if (LAST) out[(size_t)(q - indent) * feat + c] = acc;
         else out[(size_t)c * n_out + q] = acc;
     }
 }
@@ -233,21 +295,32 @@ extern "C" const char *wrnn_pre_last_error(void) { return g_pre_err; }
 
 struct wrnn_pre {
     int device, blocks, scales[3], total_scale;
+    int feat, C, R, pad;            // feat_dims, compute_dims, res_out_dims, pad
+    int gf;                         // 0: the shipped dims (MFMA kernel); else frames per workgroup of wrnn_resnet_generic_kernel
     float *dev;
     const float *conv_in_w, *bn_in, *res_w, *res_bn, *conv_out_w, *conv_out_b, *taps[3];
 };
 
+static size_t generic_lds_bytes(int feat, int C, int pad, int gf) { return ((size_t)feat * (gf + 2 * pad) + 2 * (size_t)gf * C) * sizeof(float); }
+
 extern "C" int wrnn_pre_create(const wrnn_pre_weights *w, int device, wrnn_pre **out)
 {
     if (!w || !out) PRE_FAIL(WRNN_ERR_ARG, "NULL argument");
-    if (w->feat_dims != PFEAT || w->compute_dims != PC || w->res_out_dims != PC || w->pad != PPAD || w->res_blocks < 0 ||
-        w->res_blocks > 64)
-        PRE_FAIL(WRNN_ERR_ARG, "this build supports feat_dims=80, compute_dims=res_out_dims=128, pad=2 (got %d,%d,%d,%d)",
-                 w->feat_dims, w->compute_dims, w->res_out_dims, w->pad);
+    if (w->feat_dims < 1 || w->feat_dims > 4096 || w->compute_dims < 1 || w->compute_dims > 4096 || w->res_out_dims < 1 || w->res_out_dims > 4096 ||
+        w->pad < 0 || w->pad > 64 || w->res_blocks < 0 || w->res_blocks > 64)
+        PRE_FAIL(WRNN_ERR_ARG, "bad UpsampleNetwork dims: feat_dims %d, compute_dims %d, res_out_dims %d, pad %d, res_blocks %d", w->feat_dims,
+                 w->compute_dims, w->res_out_dims, w->pad, w->res_blocks);
     for (int i = 0; i < 3; ++i)
         if (w->upsample_factors[i] < 1 || w->upsample_factors[i] > 64) PRE_FAIL(WRNN_ERR_ARG, "bad upsample factor %d", w->upsample_factors[i]);
     if (!w->conv_in_w || !w->bn_in || (w->res_blocks && (!w->res_w || !w->res_bn)) || !w->conv_out_w || !w->conv_out_b || !w->up_w)
         PRE_FAIL(WRNN_ERR_ARG, "NULL weight pointer");
+    const int FE = w->feat_dims, C = w->compute_dims, R = w->res_out_dims, PD = w->pad, KT = 2 * PD + 1;
+    const bool shipped_dims = FE == PFEAT && C == PC && R == PC && PD == PPAD;
+    int gf = 0;
+    if (!shipped_dims) {                                        // the largest frame tile whose LDS fits the default 64 KB
+        for (gf = 16; gf >= 1 && generic_lds_bytes(FE, C, PD, gf) > 65536; gf >>= 1) {}
+        if (gf < 1) PRE_FAIL(WRNN_ERR_ARG, "UpsampleNetwork too wide for the pre-loop kernel (feat_dims %d, compute_dims %d, pad %d)", FE, C, PD);
+    }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) PRE_FAIL(WRNN_ERR_NO_DEVICE, "no HIP device %d (count %d)", device, n);
     DeviceGuard dg(device);
@@ -257,25 +330,26 @@ extern "C" int wrnn_pre_create(const wrnn_pre_weights *w, int device, wrnn_pre *
     std::vector<float> h;
     auto put = [&](const float *src, size_t cnt) { size_t o = (h.size() + 63) / 64 * 64; h.resize(o + cnt); if (src) memcpy(h.data() + o, src, cnt * 4); return o; };
     // eval-mode BN folded to scale/shift in float32 arithmetic: s = w / sqrt(var + eps), t = b - mean * s
-    auto fold = [&](const float *bn, size_t o) {               // bn: [4][PC] weight, bias, running_mean, running_var
-        for (int c = 0; c < PC; ++c) {
-            const float s = bn[c] / sqrtf(bn[3 * PC + c] + (float)eps);
+    auto fold = [&](const float *bn, size_t o) {               // bn: [4][C] weight, bias, running_mean, running_var
+        for (int c = 0; c < C; ++c) {
+            const float s = bn[c] / sqrtf(bn[3 * C + c] + (float)eps);
             h[o + c] = s;
-            h[o + PC + c] = bn[PC + c] - bn[2 * PC + c] * s;
+            h[o + C + c] = bn[C + c] - bn[2 * C + c] * s;
         }
     };
-    const size_t o_cin = put(w->conv_in_w, (size_t)PC * PKIN);
-    const size_t o_bnin = put(nullptr, 2 * PC);
+    const size_t o_cin = put(w->conv_in_w, (size_t)C * FE * KT);
+    const size_t o_bnin = put(nullptr, 2 * (size_t)C);
     fold(w->bn_in, o_bnin);
-    const size_t o_resw = put(w->res_w, (size_t)B * 2 * PC * PC);
-    const size_t o_resbn = put(nullptr, (size_t)B * 2 * 2 * PC);
-    for (int i = 0; i < 2 * B; ++i) fold(w->res_bn + (size_t)i * 4 * PC, o_resbn + (size_t)i * 2 * PC);
-    const size_t o_cow = put(w->conv_out_w, (size_t)PC * PC), o_cob = put(w->conv_out_b, PC);
+    const size_t o_resw = put(w->res_w, (size_t)B * 2 * C * C);
+    const size_t o_resbn = put(nullptr, (size_t)B * 2 * 2 * C);
+    for (int i = 0; i < 2 * B; ++i) fold(w->res_bn + (size_t)i * 4 * C, o_resbn + (size_t)i * 2 * C);
+    const size_t o_cow = put(w->conv_out_w, (size_t)R * C), o_cob = put(w->conv_out_b, R);
     size_t o_t[3], toff = 0;
     for (int i = 0; i < 3; ++i) { o_t[i] = put(w->up_w + toff, 2 * w->upsample_factors[i] + 1); toff += 2 * w->upsample_factors[i] + 1; }
     put(nullptr, 64);
     wrnn_pre *p = new wrnn_pre();
     p->device = device; p->blocks = B; p->total_scale = 1;
+    p->feat = FE; p->C = C; p->R = R; p->pad = PD; p->gf = gf;
     for (int i = 0; i < 3; ++i) { p->scales[i] = w->upsample_factors[i]; p->total_scale *= w->upsample_factors[i]; }
     hipError_t e = hipMalloc((void **)&p->dev, h.size() * 4);
     if (e != hipSuccess) { delete p; PRE_FAIL(WRNN_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
@@ -300,8 +374,8 @@ extern "C" int wrnn_pre_hop(const wrnn_pre *p) { return p ? p->total_scale : 0; 
 extern "C" size_t wrnn_pre_workspace_bytes(const wrnn_pre *p, int32_t n_frames)
 {
     if (!p || n_frames < 1) return 0;
-    const size_t nf = (size_t)n_frames + 2 * PPAD;
-    return (nf * p->scales[0] + nf * p->scales[0] * p->scales[1]) * PFEAT * sizeof(float) + 512;
+    const size_t nf = (size_t)n_frames + 2 * p->pad;
+    return (nf * p->scales[0] + nf * p->scales[0] * p->scales[1]) * p->feat * sizeof(float) + 512;
 }
 
 // rows_only: stop in front of the last stage and write its input as [row][channel] (wrnn_pre_upsample_rows)
@@ -318,32 +392,41 @@ static int pre_run(const wrnn_pre *p, const float *mel, int32_t n_frames, float 
     PreArgs a;
     a.mel = mel; a.conv_in_w = p->conv_in_w; a.bn_in = p->bn_in; a.res_w = p->res_w; a.res_bn = p->res_bn;
     a.conv_out_w = p->conv_out_w; a.conv_out_b = p->conv_out_b; a.aux = aux; a.N = n_frames; a.blocks = p->blocks;
-    hipLaunchKernelGGL(wrnn_resnet_kernel, dim3((n_frames + PNF - 1) / PNF), dim3(256), 0, stream, a);
-    const int nf = n_frames + 2 * PPAD;
-    float *s1 = (float *)workspace;                                     // [PFEAT][nf*s0]
-    float *s2 = s1 + (size_t)nf * p->scales[0] * PFEAT;                 // [PFEAT][nf*s0*s1]
+    const int FE = p->feat, PD = p->pad;
+    if (p->gf == 0) hipLaunchKernelGGL(wrnn_resnet_kernel, dim3((n_frames + PNF - 1) / PNF), dim3(256), 0, stream, a);
+    else {
+        GenPreArgs g;
+        g.p = a; g.feat = FE; g.C = p->C; g.R = p->R; g.pad = PD; g.gf = p->gf;
+        hipLaunchKernelGGL(wrnn_resnet_generic_kernel, dim3((n_frames + p->gf - 1) / p->gf), dim3(256), generic_lds_bytes(FE, p->C, PD, p->gf), stream, g);
+    }
+    const int nf = n_frames + 2 * PD;
+    float *s1 = (float *)workspace;                                     // [feat][nf*s0]
+    float *s2 = s1 + (size_t)nf * p->scales[0] * FE;                    // [feat][nf*s0*s1]
     auto grid = [](long total) { long b = (total + 255) / 256; return (unsigned)(b > 65535 ? 65535 : (b < 1 ? 1 : b)); };
-    const bool shipped = p->scales[0] == 5 && p->scales[1] == 5 && p->scales[2] == 11;       // hparams.py: voc_upsample_factors
-    const unsigned g1 = grid((long)nf * p->scales[0] * PFEAT), g2 = grid((long)nf * p->scales[0] * p->scales[1] * PFEAT);
+    const bool feat80 = FE == PFEAT;
+    const bool shipped = feat80 && PD == PPAD && p->scales[0] == 5 && p->scales[1] == 5 && p->scales[2] == 11;       // hparams.py: voc_upsample_factors
+    const unsigned g1 = grid((long)nf * p->scales[0] * FE), g2 = grid((long)nf * p->scales[0] * p->scales[1] * FE);
     const unsigned g3 = grid((long)n_frames * p->total_scale * 4);      // one 64-sample x 80-channel tile per workgroup and trip
-    const int n2 = nf * p->scales[0], n3 = n2 * p->scales[1], indent = PPAD * p->total_scale;
+    const int n2 = nf * p->scales[0], n3 = n2 * p->scales[1], indent = PD * p->total_scale;
     if (rows_only) {
         // (LAST = true with indent 0: no crop, the [sample][channel] transpose only)
         if (shipped) {
-            hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 5>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, 5, PPAD, 0);
-            hipLaunchKernelGGL((wrnn_upstage_kernel<false, true, 5>), dim3(g2), dim3(256), 0, stream, s1, mels_up, p->taps[1], n2, 5, 0, 0);
+            hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 5>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, 5, PD, 0, PFEAT);
+            hipLaunchKernelGGL((wrnn_upstage_kernel<false, true, 5>), dim3(g2), dim3(256), 0, stream, s1, mels_up, p->taps[1], n2, 5, 0, 0, PFEAT);
         } else {
-            hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 0>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, p->scales[0], PPAD, 0);
-            hipLaunchKernelGGL((wrnn_upstage_kernel<false, true, 0>), dim3(g2), dim3(256), 0, stream, s1, mels_up, p->taps[1], n2, p->scales[1], 0, 0);
+            hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 0, 0>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, p->scales[0], PD, 0, FE);
+            hipLaunchKernelGGL((wrnn_upstage_kernel<false, true, 0, 0>), dim3(g2), dim3(256), 0, stream, s1, mels_up, p->taps[1], n2, p->scales[1], 0, 0, FE);
         }
     } else if (shipped) {
-        hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 5>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, 5, PPAD, 0);
-        hipLaunchKernelGGL((wrnn_upstage_kernel<false, false, 5>), dim3(g2), dim3(256), 0, stream, s1, s2, p->taps[1], n2, 5, 0, 0);
+        hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 5>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, 5, PD, 0, PFEAT);
+        hipLaunchKernelGGL((wrnn_upstage_kernel<false, false, 5>), dim3(g2), dim3(256), 0, stream, s1, s2, p->taps[1], n2, 5, 0, 0, PFEAT);
         hipLaunchKernelGGL((wrnn_upstage_last_kernel<11>), dim3(g3), dim3(256), 0, stream, s2, mels_up, p->taps[2], n3, 11, indent);
     } else {
-        hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 0>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, p->scales[0], PPAD, 0);
-        hipLaunchKernelGGL((wrnn_upstage_kernel<false, false, 0>), dim3(g2), dim3(256), 0, stream, s1, s2, p->taps[1], n2, p->scales[1], 0, 0);
-        hipLaunchKernelGGL((wrnn_upstage_last_kernel<0>), dim3(g3), dim3(256), 0, stream, s2, mels_up, p->taps[2], n3, p->scales[2], indent);
+        hipLaunchKernelGGL((wrnn_upstage_kernel<true, false, 0, 0>), dim3(g1), dim3(256), 0, stream, mel, s1, p->taps[0], nf, p->scales[0], PD, 0, FE);
+        hipLaunchKernelGGL((wrnn_upstage_kernel<false, false, 0, 0>), dim3(g2), dim3(256), 0, stream, s1, s2, p->taps[1], n2, p->scales[1], 0, 0, FE);
+        // the last stage: the LDS-tile kernel is built for 80 channels; any other count: the plain stage kernel (LAST: crop + [sample][channel])
+        if (feat80) hipLaunchKernelGGL((wrnn_upstage_last_kernel<0>), dim3(g3), dim3(256), 0, stream, s2, mels_up, p->taps[2], n3, p->scales[2], indent);
+        else hipLaunchKernelGGL((wrnn_upstage_kernel<false, true, 0, 0>), dim3(grid((long)n_frames * p->total_scale * FE)), dim3(256), 0, stream, s2, mels_up, p->taps[2], n3, p->scales[2], 0, indent, FE);
     }
     PRE_HIP(hipGetLastError());
     return WRNN_OK;

@@ -250,9 +250,10 @@ class WaveRNN(nn.Module):
                 mels_up, aux = self._pre_engine().upsample(mels.float())
                 return mels_up, aux, wave_len
             except _lib.WrnnError as e:
-                # the HIP pre-loop kernels are built for the shipped upsample hparams (feat 80, compute = res_out = 128, pad 2); any
-                # other UpsampleNetwork runs through the nn.Modules below on the device (PyTorch-ROCm / MIOpen) -- still no CPU path
-                if 'this build supports' not in str(e):
+                # the HIP pre-loop kernels take any UpsampleNetwork dims (round 5: wrnn_resnet_generic_kernel beside the MFMA kernel of the
+                # shipped ones) up to what one workgroup's LDS holds; a wider network runs through the nn.Modules below on the device
+                # (PyTorch-ROCm / MIOpen) -- still no CPU path
+                if 'too wide for the pre-loop kernel' not in str(e):
                     raise
                 import warnings
                 warnings.warn(f'wavernn_amd: {e}; up-sampling with the PyTorch-ROCm modules instead')
