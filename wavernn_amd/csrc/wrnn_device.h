@@ -256,7 +256,11 @@ __device__ __forceinline__ unsigned ld_agent32(const unsigned *p)
 __device__ __forceinline__ void report_failure(unsigned *status, unsigned code, unsigned wg, unsigned step,
                                                unsigned detail)
 {
-    if (atomicCAS(status + 1, 0u, code) == 0u) {
+    // (the compare-and-swap wants its operand pair in VGPRs; built HERE -- the optimiser was seen to build it in the kernel's prologue, far
+    // outside the step loop, and to spill it: the only VGPR spill of the RAW duo kernel)
+    unsigned c;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "s"(code));
+    if (atomicCAS(status + 1, 0u, c) == 0u) {
         status[2] = wg;
         status[3] = step;
         status[4] = detail;
