@@ -21,7 +21,7 @@
 //     poll of x_{t-1}: that x needed everything of step t - 1) and h2 x2 y1 y2 (behind the poll of y1(t)), drained at the top of the next
 //     step; cI without a sentinel inside a launch (formed at the end of step t for step t + 2, drained at the top of step t + 1, read
 //     behind the poll of h1(t + 1)); x_t as tagged 8-byte words in two entries.  The rules are wrnn_sparse.hip's (model:
-//     tests/test_sparse_exchange_model.py); what differs is who publishes what.
+//     tests/test_sparse_exchange_model.py); what differs is who publishes what (modelled with 1-4 slots and the RAW form in tests/test_chain_exchange_model.py).
 //   * 9-bit RAW (fatchord_version.py:231-237): fc3 has 512 rows -- rnn1's workgroup J (idle while the chain runs through rnn2) owns rows [16 J, 16 J + 16): one
 //     more stage (32 MFMAs on y2) and one more same-XCD hop (the 512 logits, layer 16) in front of the sampling, which is wrnn_duo.hip's: softmax ->
 //     Categorical (renormalise) -> argmax(p / q) in the reference's operation order, on rnn1's workgroups 4 s .. 4 s + 3 for slot s, one segment per wave; the GRU cells use the library exp / tanh.
