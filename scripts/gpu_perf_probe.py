@@ -70,7 +70,9 @@ for B in [int(x) for x in args.B.split(',')]:
         noise = torch.empty(T, B, 512, device=dev).exponential_(1)
     ref = None
     for v in args.variants.split(','):
-        opts = VARS[v]
+        opts = dict(VARS[v.split('+')[0]])
+        if '+' in v:                                                  # 'd4+0x10AA1000': the variant with this wrnn_options.tuning word
+            opts['tuning'] = int(v.split('+')[1], 0)
         try:
             depth = opts.get('depth', 0)
             if depth > 1 and B <= 64 * (depth - 1) and opts['algo'] in ('loop', 'duo', 'chain'):
