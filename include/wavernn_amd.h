@@ -139,9 +139,11 @@ typedef struct wrnn_options {
                                   at the stage barriers, bit 2 = no fused stages, bit 3 = RAW sampled by role A alone, bit 4 = RAW: one
                                   sampling workgroup per slot, bit 5 / bit 6 = never / always start a stage with the pending back half
                                   (default: up to 2 groups in flight), bit 7 = library exp / tanh in the MoL gate math;
-                                wrnn_duo_kernel: bit 0 = stage order loads-first, bit 1 = publish-first (default: by depth), bit 2 = re-fill the
-                                  exchange ring with the sentinel before EVERY launch, bit 6 = placement read-out through phase_clocks (test
-                                  hook), bit 8 = every layer written through (no XCD-local plain stores);
+                                wrnn_duo_kernel: bit 0 = the ih workgroups load a stage's operand into registers, bit 1 = they fetch it into LDS one
+                                  stage ahead (default: by depth, from 6 groups in flight), bit 2 = re-fill the exchange ring with the sentinel
+                                  before EVERY launch, bit 6 = placement read-out through phase_clocks (test hook), bit 8 = every layer written
+                                  through (no XCD-local plain stores), bit 14 = with phase_clocks: the stage time line of three steps as well
+                                  (phase_clocks then holds [256 * 32 + 512 * 512] words; scripts/gpu_duo_trace.py);
                                 wrnn_sparse_kernel, wrnn_chain_kernel: bits 2, 8 as wrnn_duo_kernel.
                                 When the two-workgroups-per-CU grid of wrnn_duo_kernel is refused the call returns WRNN_ERR_RESIDENCY; the
                                 caller may run it again with WRNN_ALGO_LOOP (another workspace layout: query its size) or _STREAM. */

@@ -1,4 +1,4 @@
-"""A discrete-event MODEL of wrnn_duo_kernel's exchange as it stands after round 4 (csrc/wrnn_duo.hip, header "Ring discipline"): four roles
+"""A discrete-event MODEL of wrnn_duo_kernel's exchange as it stands after round 4 (round 6's MOL stage order: `order6`) (csrc/wrnn_duo.hip, header "Ring discipline"): four roles
 per unit block -- rnn1 / rnn2 x {ih, hh} --, several slots (groups of segments) in flight, a ring of FOUR entries per layer, and three
 different ways a consumer learns that a value is there:
 
@@ -18,12 +18,7 @@ a re-arm never lands on data that is still to be read or that is newer than the 
 progress"), nobody overwrites a gh word that is still to be read, everybody finishes.  `raw=True` adds what 9-bit RAW adds (round 5's form): a
 sixth sentinel layer -- the logit rows every rnn2 hh workgroup publishes for every slot behind its poll of y2, re-armed THREE ahead behind the
 step's last y2 poll and a drain -- and `spp` sampling workgroups per slot (the kernel: four), each polling all logit rows of its slot and
-publishing / re-arming ITS OWN x_t words.  `hh_fc=(mask1, mask2)` is round 6's balance of the two workgroups of a CU: the fc stage of the
-slots in the mask runs on the HH workgroup of the unit block (rnn1: fc1 on x2 -> y1, rnn2: fc2 on y1 -> y2; a sampling workgroup keeps out
-of it: its ih workgroup runs every fc stage) behind its gh stages, and publishes the y words the IH workgroup of the same unit block
-re-arms -- two workgroups store to the same words; what orders the ih workgroup's re-arm (drained at the top of its next step) before the
-hh workgroup's publication two steps later is that the operand of that fc stage depends on what the ih workgroup published after the drain.
-The broken variants at the end show that the model
+publishing / re-arming ITS OWN x_t words.  The broken variants at the end show that the model
 is not vacuous: each of the shortcuts the header argues against is caught for some timing.  A model of the protocol, not of the HIP code
 -- tests/test_gpu_parity.py covers that."""
 import heapq
@@ -35,16 +30,15 @@ SENT = None
 
 class DuoSim:
     def __init__(self, seed, n_wg=3, slots=2, steps=24, ahead_ih=2, ahead_hh=3, cond_ahead=2, cond_drain=True, ih_drain=True,
-                 ih_drain_at_rearm=False, gh_shift=True, raw=False, spp=1, ahead_lg=3, lg_drain=True, hh_fc=(0, 0), sampler_exempt=True):
+                 ih_drain_at_rearm=False, gh_shift=True, raw=False, spp=1, ahead_lg=3, lg_drain=True, order6=False):
         assert spp * slots <= n_wg                          # rnn2's hh workgroup j samples slot j (RAW: slot j // spp, as its sampler j % spp)
         self.raw, self.spp, self.ahead_lg, self.lg_drain = raw, (spp if raw else 1), ahead_lg, lg_drain
         self.rng = random.Random(seed)
         self.n_wg, self.G, self.steps = n_wg, slots, steps
         self.ahead_ih, self.ahead_hh, self.cond_ahead, self.cond_drain = ahead_ih, ahead_hh, cond_ahead, cond_drain
         self.ih_drain, self.ih_drain_at_rearm = ih_drain, ih_drain_at_rearm
-        self.gh_shift = gh_shift and slots >= 2             # hh workgroups: the last slot's gh stage runs at the top of the next step
-        self.hh_fc, self.sampler_exempt = hh_fc, sampler_exempt
-        assert not (hh_fc[0] & 1) and not (hh_fc[1] & 1)    # the ih workgroup always runs the fc stage of slot 0 (its re-arm sits behind that poll at least)
+        self.order6 = order6 and not raw                    # round 6 (MOL): gh(0) .. gh(n - 1) in slot order, the sampler of slot s samples right behind gh(s)
+        self.gh_shift = gh_shift and slots >= 2 and not self.order6     # hh workgroups: the last slot's gh stage runs at the top of the next step
         ring = lambda n: [[[SENT] * n_wg for _ in range(n)] for _ in range(slots)]          # [slot][entry][producer]
         self.mem = {l: ring(RING) for l in ('h1', 'x1', 'y1', 'h2', 'x2', 'y2', 'cI')}
         self.mem['gh1'], self.mem['gh2'] = ring(GHRING), ring(GHRING)
@@ -134,11 +128,6 @@ class DuoSim:
         def publish(layer, i, t):
             self.store(who, layer, i, t % RING, word(layer), t)
 
-        def hh_slots(a):                                     # the slots whose fc stage the HH workgroup of this unit block runs
-            if self.raw or (not a and self.sampler_exempt and j < self.spp * G):
-                return []
-            return [i for i in range(G) if (self.hh_fc[0 if a else 1] >> i) & 1]
-
         def rearm(layers, t, ahead, slots):
             for layer in layers:
                 for i in slots:
@@ -158,10 +147,9 @@ class DuoSim:
                         if a:
                             yield ('poll', ('xt', i, t - 1))
                     publish(mine[1], i, t); publish(mine[0], i, t)
-                own_fc = [i for i in range(G) if i not in hh_slots(a)]
-                for i in own_fc:                             # fc stages (those of the other slots run on the hh workgroup of this unit block)
+                for i in range(G):                           # fc stages
                     yield ('poll', ('x2' if a else 'y1', i, t))
-                    if i == own_fc[-1]:                      # after the last poll of the step: re-arm, all slots (incl. the y words the hh workgroup publishes)
+                    if i == G - 1:                           # after the last poll of the step: re-arm, all slots
                         if self.ih_drain and self.ih_drain_at_rearm:
                             yield ('drain', who)
                         rearm(mine, t, self.ahead_ih, range(G))
@@ -187,10 +175,6 @@ class DuoSim:
                     yield ('poll', ('h1', i, tt)); yield ('work', 1.0)
                     if tt + 1 < self.steps:
                         self.store(who, 'gh1', i, (tt + 1) % GHRING, j, tt + 1)
-                if t < self.steps:
-                    for i in hh_slots(True):                 # fc1 of these slots: y1 words of this unit block (re-armed by its ih workgroup)
-                        yield ('poll', ('x2', i, t)); yield ('work', 0.4)
-                        publish('y1', i, t)
         else:
             def gh_stages(t):
                 if not self.gh_shift:
@@ -201,11 +185,16 @@ class DuoSim:
                     yield ('poll', ('h2', i, tt)); yield ('work', 1.0)
                     if tt + 1 < self.steps:
                         self.store(who, 'gh2', i, (tt + 1) % GHRING, j, tt + 1)
-                if t == self.steps:
-                    break
-                for i in hh_slots(False):                    # fc2 of these slots
-                    yield ('poll', ('y1', i, t)); yield ('work', 0.4)
-                    publish('y2', i, t)
+                    if self.order6 and i == j and j < G:     # round 6: the sampling stage of slot j right behind gh(j)
+                        yield ('poll', ('y2', j, t))
+                        yield ('drain', who)
+                        rearm(('xt',), t, self.ahead_hh, [j])
+                        yield ('work', 0.6)
+                        publish('xt', j, t)
+                if t == self.steps or self.order6:
+                    if t == self.steps:
+                        break
+                    continue
                 if self.raw:
                     for i in range(G):                       # logits stages: this workgroup's rows of fc3 for every slot
                         yield ('poll', ('y2', i, t))
@@ -237,21 +226,21 @@ def test_duo_exchange_is_safe_under_adversarial_timing():
             assert not v, (seed, slots, v[:3])
 
 
+def test_duo_exchange_round6_order_is_safe_under_adversarial_timing():
+    """MOL since round 6 (csrc/wrnn_duo.hip, duo_hh's step loop): no gh stage deferred across the step boundary, sampling behind gh(my_slot)."""
+    for seed in range(40):
+        for slots in (1, 2, 3):
+            v = DuoSim(seed, n_wg=3, slots=slots, steps=24, order6=True).run()
+            assert not v, (seed, slots, v[:3])
+    assert any(DuoSim(seed, steps=30, order6=True, ahead_hh=1).run() for seed in range(60))      # (not vacuous: x_t re-armed one ahead is caught)
+
+
 def test_duo_exchange_raw_form_is_safe_under_adversarial_timing():
     """9-bit RAW: the logits layer and several sampling workgroups per slot (csrc/wrnn_duo.hip: kind-2 and kind-4 stages)."""
     for seed in range(30):
         for n_wg, slots, spp in ((4, 2, 2), (4, 1, 4), (3, 3, 1), (6, 3, 2)):
             v = DuoSim(seed, n_wg=n_wg, slots=slots, steps=24, raw=True, spp=spp).run()
             assert not v, (seed, n_wg, slots, spp, v[:3])
-
-
-def test_duo_exchange_with_fc_stages_on_the_hh_workgroups():
-    """Round 6: the fc stages of some slots run on the hh workgroup of the unit block (wrnn_duo.hip, `fc_on_hh`); the ih workgroup still re-arms."""
-    for seed in range(40):
-        for n_wg, slots, masks in ((3, 2, (2, 2)), (4, 3, (2, 6)), (5, 4, (10, 10)), (5, 4, (14, 10)), (3, 3, (6, 0)), (5, 4, (0, 14))):
-            for kw in (dict(), dict(sampler_exempt=False), dict(gh_shift=False)):
-                v = DuoSim(seed, n_wg=n_wg, slots=slots, steps=24, hh_fc=masks, **kw).run()
-                assert not v, (seed, n_wg, slots, masks, kw, v[:3])
 
 
 def test_other_safe_distances():
@@ -277,9 +266,6 @@ def test_duo_model_detects_the_shortcuts():
     assert broken(cond_drain=False)
     # the sampler's x_t one ahead: its publication of this step can overtake the re-arm
     assert broken(ahead_hh=1)
-    # fc stages on the hh workgroups: the ih workgroup's re-arm of the y words without its drain, or one step ahead only
-    assert broken(n_wg=5, slots=4, hh_fc=(10, 10), ih_drain=False)
-    assert broken(n_wg=5, slots=4, hh_fc=(10, 10), ahead_ih=1)
     # RAW: the same for the logit rows; and their re-arm without the drain in front of it
     # (seen on a workgroup that does not sample: a sampler's own drain, in front of its x_t re-arm, happens to cover the logit rows too)
     assert broken(raw=True, n_wg=6, slots=2, spp=2, ahead_lg=1)

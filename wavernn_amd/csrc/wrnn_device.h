@@ -101,7 +101,6 @@ struct LoopArgs {
     const float *mel_coef;              // [LAST_SCALE][3]: sums of the conv taps that fall on each of the three rows
     int tab_fps, tab_t0;                // wrnn_duo.hip: c2f / c3f / c4f are per-SEGMENT tables of the slab that starts at step tab_t0: row
                                         // (segment index in the call) * tab_fps + frame - (seg_pos + tab_t0) / hop; zero row = Nall * tab_fps
-    int fc_hh1, fc_hh2;                 // wrnn_duo.hip (round 6): bit i = the fc1 / fc2 stage of slot i runs on the HH workgroup of the unit block (launch_duo sets them)
     unsigned *xcc_tab;                  // [MAXCL * 128] zeroed before every launch: XCC id + 1 of every workgroup (placement handshake)
     int kind_tag;                       // 1 wrnn_loop_kernel, 2 wrnn_duo_kernel, 3 wrnn_sparse_kernel: recorded in status[8] by the launch that starts a call at step 0,
                                         // checked by every continuing launch (the two kernels keep different state / ring layouts)

@@ -75,27 +75,12 @@ namespace wrnn {
 #define DUO_XR_FIRST 1                       // 1 = the residual sum (on a slot's chain) is published before h (read a step later)
 #endif
 
-#ifndef DUO_FC_HH1
-#define DUO_FC_HH1 0xAA                       // default slots whose fc1 / fc2 stage runs on the hh workgroup of the unit block (duo_fc_mask; wrnn_options.tuning bit 12 overrides)
-#define DUO_FC_HH2 0xAA
-#endif
-#ifndef DUO_HH_ORDER
-#define DUO_HH_ORDER 1                        // MOL hh workgroups: 1 = the gh stages of a step wait for the LAST slot's h (see the step loop), 0 = round 4's order
-#endif
-#ifndef DUO_HH_DELAY
-#define DUO_HH_DELAY 0
-#endif
-#ifndef DUO_HH_GATE
-#define DUO_HH_GATE 1                         // hh workgroups: a gh stage's MFMA block waits for the next slot's h (see "PHASE GATE")
-#endif
 #ifndef DUO_ABLATE
-#define DUO_ABLATE 0                          // TIMING EXPERIMENTS ONLY (wrong results): bit 0 = fc stages without their MFMAs, bit 1 = gh stages with one tile of three,
-#endif                                        // bit 2 = hh stages load ONE fragment of eight, bit 3 = gate stages with one tile of three, bit 4 = no GRU pointwise math
-#ifndef DUO_LDS_PREFETCH
-#define DUO_LDS_PREFETCH 1                    // ih workgroups: a stage's operand fragments are requested INTO LDS (buffer_load ... lds) one stage ahead
-#endif
-#ifndef DUO_PF_EARLY
-#define DUO_PF_EARLY 0                        // ... at the top of the previous stage (before its back half) instead of in front of its MFMA tiles; >= 2 slots only
+#define DUO_ABLATE 0                          // TIMING EXPERIMENTS ONLY (wrong results): bit 0 = fc stages without their MFMAs, bit 1 = gh stages with one
+#endif                                        // tile of three, bit 2 = hh stages load ONE fragment of eight, bit 3 = gate stages with one tile of three, bit 4 = no GRU
+                                              // pointwise math, bit 5 = ih stages load one fragment of eight (register-load variant)
+#ifndef DUO_LP_DEPTH
+#define DUO_LP_DEPTH 6                        // slots in flight from which the ih workgroups fetch a stage's operand INTO LDS one stage ahead (launch_duo; measured: r06l)
 #endif
 
 constexpr int DNWGC = 4 * LNJ;               // workgroups per cluster (128)
@@ -116,8 +101,7 @@ __host__ __device__ inline DuoLds duo_lds(int G)
     DuoLds l;
     int o = 0;
     l.off_h = o;    o += G * 256;            // h of the owned (unit, segment), per slot (thread-private words)
-    l.off_seg = o;  o += G * 64;             // ints: ih [slot][48]: 16 positions | 16 limits | 16 table-row bases (this slab's per-segment aux tables);
-                                             //       hh [slot][64]: positions | limits | mel offsets (rnn1) | table-row bases
+    l.off_seg = o;  o += G * 48;             // ints: [slot][16 positions | 16 limits | 16 table-row bases (this slab's per-segment aux tables; rnn1's hh workgroups: mel offsets)]
     l.off_xs = o;   o += G * 16;             // A-ih: x_{t0-1} of a continuing launch, x_{t1-1} at its end
     l.off_part = o; o += DPART;
     l.off_log = o;  o += SEG * DLOGS;
@@ -171,27 +155,16 @@ struct DuoGeo {
     u64 nbpack;                              // segment count of slot i in byte i
 };
 
-// Which slots' fc stage (fc1 for rnn1's workgroups, fc2 for rnn2's) runs on the HH workgroup of unit block J instead of the ih workgroup
-// (round 6: the ih workgroup's serial stream -- gates + fc of every slot -- bounded a step while the hh workgroup of the same CU waited half of the
-// time).  Both workgroups of a unit block evaluate this: the same answer.  MOL only (RAW's rnn2 hh workgroups hold their fc3 rows where the fc
-// tile would go); a sampling workgroup (rnn2's hh workgroup J < slots in flight) keeps out of it; slot 0 always stays with the ih workgroup.
-template <int MODE, bool LA>
-__device__ __forceinline__ int duo_fc_mask(const LoopArgs &a, int J, int nact)
-{
-    if (MODE != 1) return 0;
-    if (!LA && J < nact) return 0;
-    return (LA ? a.fc_hh1 : a.fc_hh2) & ((1 << nact) - 1) & ~1;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
 // ih workgroup: LA = rnn1 (W_ih + fc1; its gi has the x_{t-1} term) or rnn2 (W_ih + fc2).  Owns the GRU state of its 16 units (h, the
 // gate pointwise math) and publishes h / the residual sum / relu(fc).
-// PF: a stage starts with the previous stage's back half (its publication leaves earlier: shallow pipelines); else the stage's loads are
-// issued first and fly under that back half (deep pipelines).
+// A stage starts with the previous stage's back half (publish first: faster or equal at every depth, profiles/r04g_probe_*.json).
+// LP: the stage's operand fragments are fetched INTO LDS one stage ahead (buffer_load ... lds, no register) instead of being loaded into
+// registers behind that back half -- round 6; which one a launch runs: launch_duo.
 // PROF (thread 0, shader clocks per segment of a stage, [gates: 0-7, fc: 8-15]): 0 front issue, 1 barrier wait, 2 back half, 3 operand
 // wait / poll, 4 ring hygiene, 5 MFMA tiles + partial writes, 6 stages, 7 stages whose operand was not there at the first look
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int MODE, bool LA, bool PF, bool PROF>
+template <int MODE, bool LA, bool LP, bool PROF>
 __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int cl, const int J, const int ncl, const bool loc_h, const bool loc_y)
 {
     const int G = a.G;
@@ -278,14 +251,6 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
     const unsigned magic = a.hop_magic;
     const int mshift = a.hop_shift;
 
-    // fc stages of the slots in `hmask` run on the HH workgroup of this unit block (duo_fc_mask); this workgroup keeps slot 0 at least,
-    // and goes on re-arming the y words of every slot (header, "fc stages on the hh workgroups")
-    const int hmask = duo_fc_mask<MODE, LA>(a, J, nact);
-    const int last_fc = 31 - __builtin_clz((unsigned)(~hmask & ((1 << nact) - 1)));      // the last fc stage of this workgroup's step
-    auto next_own_fc = [&](int i) -> int {               // the next slot > i whose fc stage runs here (-1: none)
-        const unsigned m = (unsigned)(~hmask & ((1 << nact) - 1)) >> (i + 1);
-        return m ? i + 1 + __builtin_ctz(m) : -1;
-    };
     const int locbits = (loc_h ? 1 : 0) | (loc_y ? 2 : 0);                          // by re-arm lane group: h | y | residual sum (never local)
     bool dead = false;
     int pp = 0;
@@ -371,14 +336,13 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         PHX(cur + 2);
     };
 
-    // LDS prefetch (DUO_LDS_PREFETCH): the operand fragments of the NEXT stage -- (gates, i + 1) ... (gates, n - 1), (fc, 0) ... (fc, n - 1), then
+    // LDS prefetch (LP): the operand fragments of the NEXT stage -- (gates, i + 1) ... (gates, n - 1), (fc, 0) ... (fc, n - 1), then
     // the next step's (gates, 0) -- are requested into this wave's 8 KB of the (here unused) fc3 region while the current stage's MFMA tiles run,
     // and read back with 8 ds_read_b128 at the top of their stage: the L2 / fabric latency of a stage's operand (and the write-through
     // acknowledgements of the stores in front of it: vmcnt retires in order) leaves the workgroup's serial instruction stream, at no register.
     // Protocol-wise the request sits where the next stage's loads used to be issued, minus one MFMA block and one back half in which this
     // workgroup polls nothing another workgroup re-arms: whatever made the entry safe to load there makes it safe here (header; a word
     // that is still the sentinel is polled for as before).
-    constexpr bool LP = DUO_LDS_PREFETCH != 0;
     static_assert(SEG * LDC >= NW * 2048, "the prefetch blocks fit the fc3 region");
     float *const PFW = smem + L.off_f3 + w * 2048;
     auto prefetch_next = [&](auto PHC, int i) {
@@ -386,11 +350,8 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         const int ring = t & (DRING - 1);
         int nso;
         if constexpr (ph == 0) nso = (i + 1 < nact) ? cbase + (i + 1) * (MAXCL * DSLOTB) + ring * XTB + L_P0 * DLAYERB : cbase + ring * XTB + L_P2 * DLAYERB;
-        else {
-            const int nf = next_own_fc(i);
-            nso = nf >= 0 ? cbase + nf * (MAXCL * DSLOTB) + ring * XTB + L_P2 * DLAYERB
-                          : (t + 1 < T1 ? cbase + ((t + 1) & (DRING - 1)) * XTB + L_P0 * DLAYERB : -1);
-        }
+        else nso = (i + 1 < nact) ? cbase + (i + 1) * (MAXCL * DSLOTB) + ring * XTB + L_P2 * DLAYERB
+                                  : (t + 1 < T1 ? cbase + ((t + 1) & (DRING - 1)) * XTB + L_P0 * DLAYERB : -1);
         if (nso >= 0) prefetch8(xrs, PFW, voff_frag, nso);
     };
     if constexpr (LP) {
@@ -417,20 +378,14 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int r = 0; r < 8; ++r) x[r] = *reinterpret_cast<const u32x4 *>(PFW + r * 256 + lane * 4);
-            if (DUO_PF_EARLY && nact >= 2) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                prefetch_next(PHC, i);
-            }
             if (PROF) {                                 // (profiling builds: the time at the top of a stage counts as its "issue" segment)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 cur = ph == 0 ? 0 : 8;
                 PHX(cur + 0);
             }
         }
-        if constexpr (PF || LP) {
-            if constexpr (BK == 1) back_gates(cy);
-            if constexpr (BK == 2) back_relu(cy);
-        }
+        if constexpr (BK == 1) back_gates(cy);
+        if constexpr (BK == 2) back_relu(cy);
         cur = ph == 0 ? 0 : 8;
         tri = i;
         // ---------------- front: this stage's loads ----------------
@@ -462,10 +417,6 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             nc.c0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(frs, (fr * H + prow) * 4, 0, 0));
         }
         PHX(cur + 0);
-        if constexpr (!PF && !LP) {
-            if constexpr (BK == 1) back_gates(cy);
-            if constexpr (BK == 2) back_relu(cy);
-        }
         // ---------------- operands ----------------
         {
             const bool live = fi < nb;
@@ -481,7 +432,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         }
         PHX(cur + 3);
         if (ph == 0 && i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ring hygiene: last step's re-arm stores are out before anything of this step is published
-        if (ph == 2 && i == last_fc) {
+        if (ph == 2 && i == nact - 1) {
             // ring hygiene, once per step, after the last layer this workgroup polls in the step has arrived (see the header): re-arm this
             // wave's own words of entry (t + 2) % 4 in the three layers it publishes, for every slot (drained at the top of the next step)
             const int which = lane >> 4;
@@ -500,10 +451,8 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             }
         }
         if constexpr (LP) {
-            if (!(DUO_PF_EARLY && nact >= 2)) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the fragments are in registers: the wave's LDS block is free)
-                prefetch_next(PHC, i);
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the fragments are in registers: the wave's LDS block is free)
+            prefetch_next(PHC, i);
         }
         PHX(cur + 4);
         float b[32];
@@ -535,7 +484,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         for (int i = 1; i < nact; ++i) stage(I0{}, I1{}, i);
         stage(I2{}, I1{}, 0);
 #pragma unroll 1
-        for (int i = next_own_fc(0); i >= 0; i = next_own_fc(i)) stage(I2{}, I2{}, i);
+        for (int i = 1; i < nact; ++i) stage(I2{}, I2{}, i);
     }
     cur = 8;
     back_relu(cy);
@@ -576,7 +525,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
 // ring layer 4 one step ahead -- nothing of the conditioning is materialised per call.  Keeps no state between launches.
 // PROF: as duo_ih, [gh stages: 0-7, the sampling stage: 8-15]
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int MODE, bool LA, bool PF, bool PROF>
+template <int MODE, bool LA, bool LP, bool PROF>
 __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int cl, const int J, const int ncl, const bool loc_h)
 {
     const int G = a.G;
@@ -609,9 +558,6 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     CondTile ct;
     if constexpr (LA) cond_tile_init(ct, a.I_cT, a.I_b, J, lane);
     constexpr int L_H = LA ? 0 : 1, L_GH = LA ? 8 : 12;
-    constexpr bool FCH = MOL;                           // fc stages of some slots run here (duo_fc_mask)
-    constexpr int L_FCX = LA ? 6 : 2, L_FCY = LA ? 2 : 3;                            // ... polling x2 / y1, publishing y1 / y2
-    const int zrow = a.Nall * a.tab_fps;
 
     float A_hh[3][AF];
 #pragma unroll
@@ -642,12 +588,11 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         const int b0 = (int)(((long)g * NR) / NGR), nb = (int)(((long)(g + 1) * NR) / NGR) - b0;
         if (tid == 0) { GEO[2 * i] = a.rb0 + b0; GEO[2 * i + 1] = nb; }
         nbpack |= (u64)(unsigned)nb << (8 * i);
-        if (tid < SEG) {                                // segment table of the slot (rnn1: the conditioning it forms; both: the aux-table rows of its fc stages)
+        if (LA && tid < SEG) {                          // segment table of the slot (the conditioning it forms)
             const int sc = a.rb0 + b0 + (tid < nb ? tid : nb - 1);
-            SEGT[i * 64 + tid] = a.seg_pos[sc];
-            SEGT[i * 64 + SEG + tid] = a.seg_lim[sc];
-            SEGT[i * 64 + 2 * SEG + tid] = (LA && a.mel_stage) ? a.seg_moff[sc] : 0;
-            SEGT[i * 64 + 3 * SEG + tid] = sc * a.tab_fps - (a.seg_pos[sc] + a.tab_t0) / a.hop;
+            SEGT[i * 48 + tid] = a.seg_pos[sc];
+            SEGT[i * 48 + SEG + tid] = a.seg_lim[sc];
+            SEGT[i * 48 + 2 * SEG + tid] = a.mel_stage ? a.seg_moff[sc] : 0;      // (the ih workgroups keep their table-row bases here)
         }
     }
     __syncthreads();
@@ -661,33 +606,15 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     if (MOL && sampler) {                               // fc3's first tile -> LDS (fragment order as in the pack)
         for (int q = tid; q < XT / 4; q += NT) reinterpret_cast<float4 *>(F3)[q] = reinterpret_cast<const float4 *>(a.fc3f)[q];
     }
-    constexpr bool order1 = MOL && DUO_HH_ORDER == 1;
-    const bool gate_last = (a.tuning & 32768) == 0;                                 // (tuning bit 15: the new stage order without the wait for the last slot's h)
-    const bool gate = (a.tuning & 8192) == 0 && DUO_HH_GATE && !order1;             // (tuning bit 13: no phase gate in the gh stages)
-    const int fcm = FCH ? duo_fc_mask<MODE, LA>(a, J, nact) : 0;                    // slots whose fc stage runs here (never on a sampling workgroup)
-    if (fcm) {
-        // the 16 fc1 / fc2 rows of this unit block as an LDS-resident A tile in fragment order (the hh roles have no 32 registers to spare;
-        // a workgroup that runs fc stages does not sample, so the fc3 region is free): lane = (row fi, k-quad), as load_afrag -- the values
-        // and the MFMA order of mfma1_lds are those of the ih workgroup's register tile: the same bits whoever runs a slot's fc stage
-        float af[AF];
-        load_afrag(af, LA ? a.fc1_w : a.fc2_w, H + AUX, LU * J + fi, true, kbase_lane);
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-            *reinterpret_cast<float4 *>(F3 + frag_off(w, r, lane)) = make_float4(af[4 * r], af[4 * r + 1], af[4 * r + 2], af[4 * r + 3]);
-    }
+    constexpr bool order1 = MOL;                        // MOL: round 6's stage order (see the step loop); RAW: round 4's
     float *const LGT = F3;                              // RAW: the gathered logits of the slot being sampled, [segment][class] rows of stride LDC
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.xbuf, (unsigned)(DXBUF_FLOATS * 4));
-    const __amdgpu_buffer_rsrc_t frs = make_rsrc(LA ? a.c3f : a.c4f, 0x7FFFF000u);                 // per-segment table of fc1 / fc2 (aux columns + bias)
     const int voff_frag = frag_off(w, 0, lane) * 4;
     const int voff_gh = (256 * (J & 7) + tid) * 16;
     const int cbase = cl * DSLOTB;
     auto slot_nb = [&](int i) -> int { return (int)((nbpack >> (8 * i)) & 255u); };
-    auto next_fc = [&](int i) -> int {                  // the next slot > i of fcm (-1: none)
-        const unsigned m = (unsigned)fcm >> (i + 1);
-        return m ? i + 1 + __builtin_ctz(m) : -1;
-    };
 
     bool dead = false;
     int pp = 0;
@@ -710,15 +637,6 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             if (loc_h) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, voff_gh, so, 0);
             else __builtin_amdgcn_raw_buffer_store_b128(q, xrs, voff_gh, so, 16 /* sc1 */);
         }
-        PHX(cur + 2);
-    };
-    // ---------------- back half of an fc stage run here (duo_fc_mask): fc1 / fc2 + relu -> the y1 / y2 words of this unit block (re-armed by its ih workgroup)
-    auto back_fc = [&](const Carry &c) {
-        const float *PB = DPARTOF(c.pp);
-        lds_barrier();
-        PHX(cur + 1);
-        publish4l(xrs, cbase + c.i * (MAXCL * DSLOTB) + L_FCY * DLAYERB + (c.t & (DRING - 1)) * XTB + J * 1024, tid,
-                  fmaxf(get_partial<3>(PB, 0, pu, pj) + c.c0, 0.f), pj < slot_nb(c.i), LA ? false : loc_h);
         PHX(cur + 2);
     };
     // ---------------- RAW: back half of a logits stage: the owned 16 classes x 16 segments of fc3 (:223) -> ring layer 16 (read by the slot's sampler)
@@ -768,12 +686,12 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         if constexpr (LA) {
 #pragma unroll 1
             for (int i = w; i < nact; i += NW) {
-                const int p = SEGT[i * 64 + fi] + tt;
-                const bool valid = fi < slot_nb(i) && p < SEGT[i * 64 + SEG + fi];
+                const int p = SEGT[i * 48 + fi] + tt;
+                const bool valid = fi < slot_nb(i) && p < SEGT[i * 48 + SEG + fi];
                 const int fr = magic ? (int)(__umulhi((unsigned)p, magic) >> mshift) : p / hop;
                 f32x4 v;
                 if (mel_stage) {                        // the last up-sampling stage here too: three rows of its input, this position's tap sums
-                    const int j = p + SEGT[i * 64 + 2 * SEG + fi];
+                    const int j = p + SEGT[i * 48 + 2 * SEG + fi];
                     const int row = j / LAST_SCALE;
                     v = cond_tile_rows(ct, mels_up + (size_t)(row - 1) * MEL, mel_coef + 3 * (j - row * LAST_SCALE), aux_fr + (size_t)fr * (4 * AUX), valid, lane);
                 } else v = cond_tile(ct, mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane);
@@ -802,37 +720,35 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             }
         }
     };
-    enum { BK_NONE = 0, BK_GH = 1, BK_SAMPLE = 2, BK_ANY = 3, BK_LG = 4, BK_FC = 5 };
+    enum { BK_NONE = 0, BK_GH = 1, BK_SAMPLE = 2, BK_ANY = 3, BK_LG = 4 };
     int pend = BK_NONE;                                 // run-time kind of the pending half, read only where two kinds can meet (BK_ANY sites)
     int last_here = nact - 1;                           // the last gh stage in front of a step's other stages (see the step loop)
     bool deferred = false;                              // the running gh stage is the deferred one of the previous step
 
     // kind 1: gh stage of slot i (polls h(t)); kind 3: MOL sampling stage of my_slot (polls y2(t)); RAW: kind 2: logits stage of slot i (polls y2(t)),
-    // kind 4: sampling stage of my_slot (polls the 512 logits); kind 5: fc stage of slot i (duo_fc_mask; polls x2(t) / y1(t))
+    // kind 4: sampling stage of my_slot (polls the 512 logits)
     auto stage = [&](auto KC, auto BKC, int i) {
         constexpr int kind = decltype(KC)::value;
         constexpr int BK = decltype(BKC)::value;
         const int nb = slot_nb(i);
         const int ring = t & (DRING - 1);
         const int sbase = cbase + i * (MAXCL * DSLOTB);
-        const int soff_x = sbase + (kind == 1 ? L_H : (kind == 4 ? 16 : (kind == 5 ? L_FCX : 3))) * DLAYERB + ring * XTB;
+        const int soff_x = sbase + (kind == 1 ? L_H : (kind == 4 ? 16 : 3)) * DLAYERB + ring * XTB;
         Carry nc;
         nc.c0 = nc.c1 = 0.f; nc.i = i; nc.pp = pp; nc.t = t;
         auto run_back = [&] {
             if constexpr (BK == BK_GH) back_gh(cy);
             else if constexpr (BK == BK_SAMPLE) back_sample(cy);
             else if constexpr (BK == BK_LG) back_lg(cy);
-            else if constexpr (BK == BK_FC) back_fc(cy);
             else if constexpr (BK == BK_ANY) {
                 if (pend == BK_GH) back_gh(cy);
-                else if (pend == BK_FC) { if constexpr (FCH) back_fc(cy); }
                 else if (pend == BK_SAMPLE) { if constexpr (!LA && MOL) back_sample(cy); }
                 else if (pend == BK_LG) { if constexpr (!LA && !MOL) back_lg(cy); }
             }
         };
         if (PROF && tid == 0 && plast == 0) plast = __builtin_amdgcn_s_memtime();
         tri = cy.i;
-        if constexpr (PF || kind == 4) run_back();      // (RAW sampling: this workgroup's own logit rows of the slot must be out before it gathers them)
+        run_back();                                     // (publish first: profiles/r04g_probe_*.json)
         cur = kind == 1 ? 0 : 8;
         tri = i;
 
@@ -849,12 +765,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             nc.c0 = nrow[(size_t)(b0 + suc) * 10 + (sm < 10 ? sm : 9)];
             nc.c1 = nrow[(size_t)10 * Nall + b0 + suc];
         }
-        if constexpr (kind == 5) {                      // the aux columns + bias of this thread's (unit, segment): the slab's per-segment table
-            const int fr = table_row(SEGT[i * 64 + pj] + t, SEGT[i * 64 + SEG + pj], SEGT[i * 64 + 3 * SEG + pj], magic, mshift, hop, zrow);
-            nc.c0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(frs, (fr * H + prow) * 4, 0, 0));
-        }
         PHX(cur + 0);
-        if constexpr (!PF && kind != 4) run_back();
         {
             const bool live = fi < nb;
             const bool there = frag_there(x, live);
@@ -898,44 +809,24 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         frag_to_b(x, b);
         {   // the next stage's polled layer, one stage ahead (not across a step boundary: nothing of the next step is published yet)
             xahead = false;
-            if (kind == 1 || kind == 2 || kind == 5) {
+            if (kind == 1 || kind == 2) {
                 int so = -1;
-                const int nf = kind == 5 ? next_fc(i) : (fcm ? __builtin_ctz((unsigned)fcm) : -1);                          // the (next) fc stage of this step
-                if (kind == 1 && order1) {                                                                                  // gh(0 .. my_slot) | sampling | gh(..) | fc stages
+                if (kind == 1 && order1) {                                                                                  // MOL: gh(0 .. my_slot) | sampling | gh(my_slot + 1 ..)
                     if (sampler && i == my_slot) so = cbase + my_slot * (MAXCL * DSLOTB) + 3 * DLAYERB + ring * XTB;
                     else if (i + 1 < nact) so = sbase + MAXCL * DSLOTB + L_H * DLAYERB + ring * XTB;
-                    else if (nf >= 0) so = cbase + nf * (MAXCL * DSLOTB) + L_FCX * DLAYERB + ring * XTB;
                 } else if (kind == 1 && deferred) so = -1;                                                                  // (the next stage belongs to the next step)
-                else if (kind != 5 && i < (kind == 1 ? last_here : nact - 1)) so = sbase + MAXCL * DSLOTB + (kind == 1 ? L_H : 3) * DLAYERB + ring * XTB;
-                else if (kind != 2 && nf >= 0) so = cbase + nf * (MAXCL * DSLOTB) + L_FCX * DLAYERB + ring * XTB;          // the fc stage of slot nf
+                else if (i < (kind == 1 ? last_here : nact - 1)) so = sbase + MAXCL * DSLOTB + (kind == 1 ? L_H : 3) * DLAYERB + ring * XTB;
                 else if (kind == 1 && !LA && !MOL) so = cbase + 3 * DLAYERB + ring * XTB;                                   // RAW: the logits stage of slot 0
                 else if (sampler) so = cbase + my_slot * (MAXCL * DSLOTB) + (MOL ? 3 : 16) * DLAYERB + ring * XTB;      // the sampling stage
                 if (so >= 0) {
                     xahead = true;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) x[r] = ((DUO_ABLATE & 4) && r > 0) ? x[0] : __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, so, 16 /* sc1 */);
-                    if (kind == 1 && gate && !deferred && i < last_here) {
-                        // PHASE GATE: the MFMA block of this gh stage starts when the NEXT slot's h is there.  The ih workgroup of this CU
-                        // publishes h(i + 1) right after the MFMA block of its gates stage i + 1 and then spends a back half + front without the
-                        // matrix pipe: started at once (h(i) arrived while that block was being issued), this block ran alongside the ih
-                        // workgroup's next one -- two waves sharing the pipe, then both in their pointwise halves with the pipe idle.  gh is read a
-                        // step later: the wait costs nothing on any chain, and the next stage finds its operand in the registers.
-                        const bool live2 = fi < slot_nb(i + 1);
-                        unsigned spins = 0;
-                        while (!dead && !frag_there(x, live2) && ++spins < 400u) {
-                            __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, so, 16 /* sc1 */);
-                        }
-                    }
                 }
             }
         }
         PHX(cur + 4);
         float *PW = DPARTOF(pp);
-#if DUO_HH_DELAY
-        if (kind == 1) __builtin_amdgcn_s_sleep(DUO_HH_DELAY);       // (timing experiment: a fixed delay in front of the gh MFMA block)
-#endif
         if constexpr (kind == 1) {
             f32x4 o0, o1, o2;
             if constexpr ((DUO_ABLATE & 2) != 0) { o0 = mfma1(A_hh[0], b); o1 = o0; o2 = o0; }
@@ -944,10 +835,6 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             put_partial<3>(PW, w, 1, lane, o1);
             put_partial<3>(PW, w, 2, lane, o2);
             pend = BK_GH;
-        } else if constexpr (kind == 5) {
-            if constexpr ((DUO_ABLATE & 1) != 0) put_partial<3>(PW, w, 0, lane, f32x4{b[0], b[1], b[2], b[3]});
-            else put_partial<3>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
-            pend = BK_FC;
         } else if constexpr (kind == 2) {
             put_partial<3>(PW, w, 0, lane, mfma1(A_f3, b));
             pend = BK_LG;
@@ -1072,7 +959,6 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     using K2 = std::integral_constant<int, 2>;
     using K3 = std::integral_constant<int, 3>;
     using K4 = std::integral_constant<int, 4>;
-    using K5 = std::integral_constant<int, 5>;
     using BGH = std::integral_constant<int, BK_GH>;
     using BLG = std::integral_constant<int, BK_LG>;
     using BANY = std::integral_constant<int, BK_ANY>;
@@ -1084,41 +970,20 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     // workgroup is free.  So the last slot's gh stage is deferred to the top of the NEXT step (its product, gh(t+1) of that slot, is needed
     // late in that step): gh(n-1)@t-1 | gh(0) .. gh(n-2) | sample ...  -- the same two call sites (every call site of `stage` is a full
     // inlined copy), one more loop iteration at the end of a launch for the last deferred stage.
-    const bool shift = DUO_GH_SHIFT && nact >= 2 && !order1;
+    const bool shift = DUO_GH_SHIFT && nact >= 2 && !order1;                 // (RAW)
     last_here = shift ? nact - 2 : nact - 1;
     if constexpr (order1) {
-        // Round 6 -- WHEN the gh stages run.  The two workgroups of a CU share four SIMDs one wave each, and the matrix pipe serves one
-        // MFMA block at a time: while this workgroup streams the 96 MFMAs of a gh stage the ih workgroup's wave on the same SIMD issues
-        // VALU work at ~0.4 of its rate and no MFMA at all (scripts/micro/mfma_valu_coexec.hip; profiles/r06g_trace_*).  The ih workgroup
-        // is what a step waits for -- every hop of a slot's chain polls ALL ih workgroups -- and its step is a gates phase (128-MFMA-dense:
-        // 3.4 k of 7 k cycles per stage) followed by an fc phase (1.3 k of 5-6 k cycles per stage).  With round 4's order (gh(i) as soon as
-        // h(i) is there) every gh block landed on the ih workgroup's NEXT gates stage.  gh(t + 1) is read a step later: the gh stages of
-        // a step now wait until h of the LAST slot has arrived, i.e. until the ih workgroup of this CU has left its gates phase, and run
-        // under its fc phase.  A sampling workgroup runs its sampling stage behind gh(my_slot): y2 of slot J is published by the J-th fc
-        // stage of rnn2's ih workgroups, about when gh(0 .. J) are through.
-        const u32x4 zero4 = {0u, 0u, 0u, 0u};
+        // Round 6 (MOL).  gh(0) .. gh(n - 1) in slot order, nothing deferred across the step boundary, and a sampling workgroup runs its
+        // sampling stage right behind gh(my_slot): y2 of slot J is published by the J-th fc stage of rnn2's ih workgroups, about when
+        // gh(0 .. J) are through -- round 4's order (the last slot's gh stage deferred to the top of the next step, the sampling stage
+        // behind gh(n - 2)) made the sampler of slot 0 sit through the gh stages of slots whose h2 arrives after its y2.  Measured
+        // (profiles/r06l_*): 16.4 / 19.4 / 22.7 us per step at depth 2 / 3 / 4 against 17.0 / 19.8 / 23.5.  (Also measured, no effect: the
+        // gh stages held back until the LAST slot's h is there, i.e. until the ih workgroup of the CU has left its MFMA-dense gates
+        // phase -- profiles/r06k_*.)
         for (; t < T1; ++t) {
             if constexpr (LA) {
                 if (t + 2 < T1) cond_step(t + 2);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ... and out before anything of this step is published
-            }
-            if (nact >= 2 && gate_last) {
-                // (the pending back half first: it publishes gh(t) of the last slot -- or x_{t-1} -- which the h this wait is for depends on)
-                cur = 0;
-                if (pend == BK_GH) back_gh(cy);
-                else if (pend == BK_FC) { if constexpr (FCH) back_fc(cy); }
-                else if (pend == BK_SAMPLE) { if constexpr (!LA) back_sample(cy); }
-                pend = BK_NONE;
-                const int so = cbase + (nact - 1) * (MAXCL * DSLOTB) + L_H * DLAYERB + (t & (DRING - 1)) * XTB;
-                const bool live = fi < slot_nb(nact - 1);
-                unsigned spins = 0;
-                do {
-                    if (spins) __builtin_amdgcn_s_sleep(4);
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, so, 16 /* sc1 */);
-                } while (!dead && !frag_there(x, live) && ++spins < 4000u);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) x[r] = zero4;
             }
 #pragma unroll 1
             for (int i = 0; i < nact; ++i) {
@@ -1126,10 +991,6 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
                 if constexpr (!LA) {
                     if (sampler && i == my_slot) stage(K3{}, BGH{}, my_slot);
                 }
-            }
-            if constexpr (FCH) {
-#pragma unroll 1
-                for (int i = fcm ? __builtin_ctz((unsigned)fcm) : -1; i >= 0; i = next_fc(i)) stage(K5{}, BANY{}, i);
             }
         }
     } else
@@ -1148,10 +1009,6 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         if (t == T1) break;
 #pragma unroll 1
         for (int i = late ? 0 : 1; i <= last_here; ++i) stage(K1{}, BGH{}, i);
-        if constexpr (FCH) {
-#pragma unroll 1
-            for (int i = fcm ? __builtin_ctz((unsigned)fcm) : -1; i >= 0; i = next_fc(i)) stage(K5{}, BANY{}, i);
-        }
         if constexpr (!LA && MOL) {
             if (sampler) stage(K3{}, BGH{}, my_slot);
         }
@@ -1164,7 +1021,6 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     }
     cur = 0;
     if (pend == BK_GH) back_gh(cy);
-    else if (pend == BK_FC) { if constexpr (FCH) back_fc(cy); }
     else if (pend == BK_SAMPLE) { if constexpr (!LA && MOL) back_sample(cy); }
     else if (pend == BK_LG) { if constexpr (!LA && !MOL) back_lg(cy); }
     cond_leave();
@@ -1179,7 +1035,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
 
 // Grid = clusters x 128 workgroups of 256 threads (two per CU), cooperative launch.  Whole XCDs per cluster (speed only: nothing
 // depends on the placement; what the placement is, is looked at below).
-template <int MODE, bool PF, bool PROF>
+template <int MODE, bool LP, bool PROF>
 __global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1248,11 +1104,11 @@ __global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
 #define DUO_ROLES 15                          // (register-allocation diagnosis: compile with a subset of the four roles, -DDUO_ROLES=<mask>)
 #endif
     if (layer == 0) {
-        if (hh == 0) { if constexpr ((DUO_ROLES & 1) != 0) duo_ih<MODE, true, PF, PROF>(a, smem, cl, J, ncl, loc_a, false); }
-        else { if constexpr ((DUO_ROLES & 2) != 0) duo_hh<MODE, true, PF, PROF>(a, smem, cl, J, ncl, loc_a); }
+        if (hh == 0) { if constexpr ((DUO_ROLES & 1) != 0) duo_ih<MODE, true, LP, PROF>(a, smem, cl, J, ncl, loc_a, false); }
+        else { if constexpr ((DUO_ROLES & 2) != 0) duo_hh<MODE, true, LP, PROF>(a, smem, cl, J, ncl, loc_a); }
     } else {
-        if (hh == 0) { if constexpr ((DUO_ROLES & 4) != 0) duo_ih<MODE, false, PF, PROF>(a, smem, cl, J, ncl, loc_b, loc_b); }
-        else { if constexpr ((DUO_ROLES & 8) != 0) duo_hh<MODE, false, PF, PROF>(a, smem, cl, J, ncl, loc_b); }
+        if (hh == 0) { if constexpr ((DUO_ROLES & 4) != 0) duo_ih<MODE, false, LP, PROF>(a, smem, cl, J, ncl, loc_b, loc_b); }
+        else { if constexpr ((DUO_ROLES & 8) != 0) duo_hh<MODE, false, LP, PROF>(a, smem, cl, J, ncl, loc_b); }
     }
 }
 
@@ -1270,27 +1126,25 @@ int duo_clusters(int n_cus)
     return ncl;
 }
 
-// Stage order, measured on the final kernel (profiles/r04g_probe_{mol,raw}.json): publish first is faster or equal at every depth
-// (12.04 vs 12.48 us per step with one group in flight, 17.2 vs 17.2 with two, 20.9 vs 21.3 with three; RAW 39.3 vs 40.1 at depth 4);
-// loads first stays as an A/B switch.
-constexpr int DUO_PUBFIRST_DEPTH = 1;
+// How the ih workgroups get a stage's operand (round 6, profiles/r06l_*: us per step at 1 / 2 / 3 / 4 / 8 slots in flight -- register loads
+// behind the back half 12.3 / 16.4 / 19.4 / 22.7 / 41.3, LDS prefetch one stage ahead 12.4 / 16.6 / 19.7 / 23.6 / 38.3): the prefetch pays
+// once a step is the workgroups' busy time, not the latency of a slot's chain (its 8 LDS-DMA issues and the read-back cost what the exposed
+// L2 latency costs at 4 slots; at 8 they are 7 % cheaper).
 hipError_t launch_duo(const LoopArgs &args, int ncl, int mode, hipStream_t stream)
 {
     if (ncl < 1 || args.G < 1 || args.G > LMAXG || (mode == 1 && !args.fc3f) || !args.u1 || !args.xcc_tab) return hipErrorInvalidValue;
     const size_t lds = duo_lds_bytes(args.G);
-    // wrnn_options.tuning (A/B switches): bit 0 = loads first, bit 1 = publish first; bit 8 = every layer written through (no XCD-local
-    // plain stores); bit 6 = placement read-out through the phase-clock buffer
-    const bool pf = (args.tuning & 2) ? true : ((args.tuning & 1) ? false : args.G >= DUO_PUBFIRST_DEPTH);
+    // wrnn_options.tuning (A/B switches): bit 0 = operands by register loads, bit 1 = by LDS prefetch (default: by depth); bit 8 = every layer
+    // written through (no XCD-local plain stores); bit 6 = placement read-out through the phase-clock buffer; bit 14 (profiling builds):
+    // the stage time line ("TRACE")
+    const bool lp = (args.tuning & 2) ? true : ((args.tuning & 1) ? false : args.G >= DUO_LP_DEPTH);
     const bool prof = mode == 1 && args.prof && !(args.tuning & 64);              // phase clocks: MOL builds only
-    const void *fn = mode == 1 ? (pf ? (prof ? (const void *)wrnn_duo_kernel<1, true, true> : (const void *)wrnn_duo_kernel<1, true, false>)
+    const void *fn = mode == 1 ? (lp ? (prof ? (const void *)wrnn_duo_kernel<1, true, true> : (const void *)wrnn_duo_kernel<1, true, false>)
                                      : (prof ? (const void *)wrnn_duo_kernel<1, false, true> : (const void *)wrnn_duo_kernel<1, false, false>))
-                               : (pf ? (const void *)wrnn_duo_kernel<0, true, false> : (const void *)wrnn_duo_kernel<0, false, false>);
+                               : (lp ? (const void *)wrnn_duo_kernel<0, true, false> : (const void *)wrnn_duo_kernel<0, false, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     LoopArgs a = args;
-    // fc stages on the hh workgroups (duo_fc_mask): the odd slots by default; tuning bit 12: the masks of bits 16-23 (fc1) / 24-31 (fc2) instead
-    a.fc_hh1 = (args.tuning & 4096) ? (args.tuning >> 16) & 0xFF : DUO_FC_HH1;
-    a.fc_hh2 = (args.tuning & 4096) ? (args.tuning >> 24) & 0xFF : DUO_FC_HH2;
     void *params[] = {(void *)&a};
     return hipLaunchCooperativeKernel(fn, dim3(ncl * DNWGC), dim3(NT), params, (unsigned)lds, stream);
 }
