@@ -10,7 +10,8 @@ with parity noise (per-utterance MT19937 streams), for three forms of the loop:
 
 A run is free-running, so a segment is "exposed" until its first differing sample: flips = segments that part ways, exposure = the
 segment-steps before that; rate = flips / exposure.  The oracle outputs come from tests/_cache (scripts/make_oracle_cache.py) or are
-computed on the spot.  TEST / MEASUREMENT infrastructure (imports oracle/ through tests/helpers.py).
+computed on the spot.  Every flip is recorded with the GPU's class, the oracle's and -- where tests/golden holds the reference's own run of
+that utterance (raw_flip_u*.npz, scripts/make_golden.py) -- the REFERENCE's.  TEST / MEASUREMENT infrastructure (imports oracle/ through tests/helpers.py).
 
     python scripts/gpu_raw_flips.py [--batches 4] [--json gpurun_out/raw_flips.json]
 """
@@ -40,6 +41,7 @@ def main():
     variants = {'duo_mel_in_loop': dict(mel_in_loop=True, loop_algo='auto'), 'duo_mel_full': dict(mel_in_loop=False, loop_algo='auto'),
                 'loop_ref_order': dict(mel_in_loop=False, loop_algo='loop')}
     res = {v: dict(flips=0, exposure=0, segments=0, first=[]) for v in args.variants.split(',')}
+    to_cls = lambda x: int(round((float(x) + 1.0) * 511.0 / 2.0))
     for k in range(args.batches):
         us = list(range(16 * k, 16 * k + 16))
         mels = [torch.from_numpy(random_mel(1234 + u, 641)).unsqueeze(0) for u in us]
@@ -58,7 +60,12 @@ def main():
                     res[v]['exposure'] += int(d[0]) if d.size else plan.T
                     if d.size:
                         res[v]['flips'] += 1
-                        res[v]['first'].append([us[i], s, int(d[0])])
+                        t = int(d[0])
+                        rec = dict(utterance=us[i], segment=s, step=t, gpu_class=to_cls(got[s, t]), oracle_class=to_cls(ref[s, t]), reference_class=None)
+                        fx = os.path.join(ROOT, 'tests', 'golden', f'raw_flip_u{us[i]}.npz')        # the REFERENCE's own run, where one is held
+                        if os.path.exists(fx):
+                            rec['reference_class'] = int(np.load(fx)['cls'][s, t])
+                        res[v]['first'].append(rec)
             print(f'batch {k} {v}: {info["kernel"]} depth {info["depth"]} launches {info["launches"]}, flips so far {res[v]["flips"]} in '
                   f'{res[v]["exposure"]} segment-steps ({time.time() - t0:.1f} s)', flush=True)
     for v in res:

@@ -45,6 +45,12 @@ CASES = [
     # exactly -> B = 19 with NO padded fold.  The mel is stored in the fixture (Tacotron is upstream of the path).
     dict(name='mol_tacotron_800f', mode='MOL', wseed=0, mseed=None, frames=800, batched=True, target=11000, overlap=550, mu_law=True, seed=77,
          tts_seed=3),
+    # Round 6: the two utterances of the 64-utterance RAW flip-rate measurement (scripts/gpu_raw_flips.py: weight seed 0, mel seed 1234 + u,
+    # sample seed 77 + u, 641 frames -> 16 segments x 12,100 steps) in which a kernel's class indices parted ways with the C ORACLE -- u = 34
+    # (segment 2, step 7,399: the oracle itself is the odd one out there) and u = 46 (segment 14, step 3,015).  `compact`: only the
+    # reference's class indices are stored ([B, T] uint16; the float sample is 2 idx / 511 - 1).
+    dict(name='raw_flip_u34', mode='RAW', wseed=0, mseed=1268, frames=641, batched=True, target=11000, overlap=550, mu_law=True, seed=111, compact=True),
+    dict(name='raw_flip_u46', mode='RAW', wseed=0, mseed=1280, frames=641, batched=True, target=11000, overlap=550, mu_law=True, seed=123, compact=True),
 ]
 
 
@@ -108,6 +114,12 @@ def run_case(c):
     finally:
         torch.stack = real_stack
     raw = cap['raw'].transpose(0, 1).contiguous().numpy()       # (B,T) float32, pre-decode (:243)
+    if c.get('compact'):
+        idx = np.rint((raw.astype(np.float64) + 1.0) * 511.0 / 2.0).astype(np.uint16)
+        assert np.array_equal(idx.astype(np.float32) * np.float32(2) / np.float32(511) - np.float32(1), raw)
+        np.savez_compressed(os.path.join(OUT, c['name'] + '.npz'), config=np.array(repr(c)), cls=idx, n_classes=np.int64(512))
+        print(c['name'], 'class indices', idx.shape, 'min', idx.min(), 'max', idx.max())
+        return
     mels_up = cap['mels_up'][0].numpy()
     aux_up = cap['aux_up'][0].numpy()
     # keep fixtures small: conditioning is stored strided (every 97th upsampled sample) + full aux frames

@@ -196,6 +196,26 @@ def test_every_depth_the_planner_can_pick(gpu, mode, clusters, algo):
             assert err <= MOL_TOL, (depth, err)
 
 
+@pytest.mark.parametrize('algo,depth', [('chain', 2), ('duo', 4), ('duo', 8)])
+def test_raw_thousand_steps_at_the_depths_the_planner_picks(gpu, algo, depth):
+    """Round-5 verdict, "What's weak" 8: the depth sweep above value-checks 9-bit RAW over 72 steps only.  Here the depths `auto` really runs
+    RAW at -- two groups per cluster on wrnn_chain_kernel, 4 and 8 on wrnn_duo_kernel (8: the LDS-prefetch form of the ih workgroups) -- run
+    1,000 free-running steps across three conditioning slabs, 4 clusters, the last group ragged, against the C oracle: class indices identical."""
+    from wavernn_amd.engine import LoopEngine
+    from wavernn_amd.synthetic import random_state_dict
+    sd = random_state_dict(0, mode='RAW')
+    eng = LoopEngine(sd, 'RAW', device=gpu)
+    T = 1000
+    n = 16 * (4 * (depth - 1) + 2 - 1) + 5
+    mels_up, aux, seg_pos, seg_lim, noise, ref = _sweep_case(sd, 'RAW', n, T, 3000 + n)
+    out = eng.run_segments(mels_up.to(gpu), aux.to(gpu), seg_pos, seg_lim, T, noise.to(gpu), HOP, algo=algo, clusters=4, depth=depth,
+                           slab_steps=T // 3 + 1).cpu().numpy()
+    info = eng.last_run_info()
+    assert (info['clusters'], info['depth'], info['rounds']) == (4, depth, 1), info
+    bad = np.argwhere(out != ref)
+    assert bad.size == 0, f'{algo} depth {depth}: first divergence at (b,t)={bad[0]} of {out.shape}'
+
+
 def test_corpus_slice_matches_per_utterance_oracle(gpu):
     """The first 16 utterances of BASELINE config 4's corpus (lens from RandomState(2024), mel seeds 1000+u: 245 folded
     segments -> 4 clusters x 4 groups in flight, the split the whole corpus' per-GPU share runs at) through `generate_corpus`
@@ -307,3 +327,53 @@ def test_bench_legs_as_benchmarked_match_oracle(gpu, mode):
             assert bad.size == 0, f'utterance {u}: {len(bad)} samples differ, first at (segment, step) = {bad[0]}'
         else:
             assert np.abs(got - ref).max() <= MOL_TOL, (u, np.abs(got - ref).max())
+
+
+FLIP_UTTERANCES = {'raw_flip_u34': 34, 'raw_flip_u46': 46}
+
+
+@pytest.mark.parametrize('name', list(FLIP_UTTERANCES))
+def test_raw_near_ties_one_utterance_matches_the_reference(gpu, name, tmp_path):
+    """Round 6 (fatchord_version.py:231-237): the shipped RAW path -- `WaveRNN.generate()`, materialised mel, `auto` = wrnn_chain_kernel for the 16
+    segments of one utterance -- reproduces the REFERENCE's class indices at the two utterances where the 12.4 M segment-step measurement saw a
+    kernel and the C oracle part ways (tests/golden/raw_flip_u*.npz = the reference's own run; the oracle differs from it at u34 (2, 7399):
+    tests/test_oracle_golden.py)."""
+    from wavernn_amd.synthetic import random_state_dict
+    from wavernn_amd import fold
+    cfg, g = load_case(name)
+    sd = random_state_dict(cfg['wseed'], mode='RAW')
+    model = _model(sd, 'RAW', gpu)
+    assert model.mel_in_loop is None                  # the RAW default: materialised mel
+    torch.manual_seed(cfg['seed'])
+    out = model.generate(torch.tensor(case_mel(cfg, g)).unsqueeze(0), tmp_path / 'o.wav', True, cfg['target'], cfg['overlap'], True)
+    # the reference's class indices through the reference's post-loop arithmetic (decode_mu_law, xfade_and_unfold, tail fade: bit-exact
+    # restatements, tests/test_oracle_golden.py) -- a sample of `out` differs exactly where a class index of its segment does
+    ref_raw = g['cls'].astype(np.float32) * np.float32(2) / np.float32(511) - np.float32(1)
+    want = fold.xfade_and_unfold(fold.decode_mu_law(ref_raw.astype(np.float64), 512, False), cfg['target'], cfg['overlap'])
+    want = fold.finish_waveform(want, (cfg['frames'] - 1) * HOP, HOP)
+    print(f'{name}: {model.last_loop_kernel} {model.last_loop_ms:.1f} ms')
+    assert model.last_loop_kernel == 'wrnn_chain_kernel'
+    assert out.shape == want.shape and np.array_equal(out, want), f'{np.count_nonzero(out != want)} of {out.size} samples differ'
+
+
+def test_raw_near_ties_in_the_benchmarked_batch_match_the_reference(gpu):
+    """The same two utterances inside the batch they were found in -- utterances 32 .. 47 of the flip-rate corpus = 256 segments x 12,100 steps
+    through `generate_corpus` (parity noise per utterance, materialised mel: the RAW default), `auto` = wrnn_duo_kernel at depth 4, the split
+    the RAW bench leg runs: the class indices of utterances 34 and 46 are IDENTICAL to the reference's own run."""
+    from wavernn_amd.batch import generate_corpus
+    from wavernn_amd.synthetic import random_state_dict, random_mel
+    sd = random_state_dict(0, mode='RAW')
+    model = _model(sd, 'RAW', gpu).eval()
+    us = list(range(32, 48))
+    mels = [torch.from_numpy(random_mel(1234 + u, 641)).unsqueeze(0) for u in us]
+    segs, plan = generate_corpus(model, mels, TARGET, OVERLAP, True, [77 + u for u in us], return_segments=True)
+    info = model._loop_engine().last_run_info()
+    print(f'flip batch: {info["kernel"]} depth {info["depth"]} launches {info["launches"]}')
+    assert info['kernel'] == 'wrnn_duo_kernel' and info['depth'] == 4
+    for name, u in FLIP_UTTERANCES.items():
+        cfg, g = load_case(name)
+        i = us.index(u)
+        got = segs[plan.first[i]:plan.first[i] + plan.folds[i]].astype(np.float32)
+        cls = np.rint((got.astype(np.float64) + 1.0) * 511.0 / 2.0).astype(np.int64)
+        ref = g['cls'].astype(np.int64)
+        assert cls.shape == ref.shape and np.array_equal(cls, ref), (name, np.argwhere(cls != ref)[:4].tolist())

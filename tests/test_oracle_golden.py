@@ -143,3 +143,29 @@ def test_tacotron_mirror_reproduces_the_reference_decoder_fixture():
     mel, lin, attn = TacotronInference(random_tacotron_state_dict(3, shapes)).generate(ids, steps=g['mel'].shape[1])
     assert mel.shape == g['mel'].shape and attn.shape == g['attention'].shape
     assert np.abs(mel - g['mel']).max() <= 1e-6 and np.abs(lin - g['linear']).max() <= 1e-6 and np.abs(attn - g['attention']).max() <= 1e-6
+
+
+FLIP_CASES = {'raw_flip_u34': [(2, 7399, 29, 239)], 'raw_flip_u46': []}      # name -> [(segment, step, reference class, oracle class)]
+
+
+@pytest.mark.parametrize('name', list(FLIP_CASES))
+def test_oracle_vs_reference_at_the_raw_near_ties(name):
+    """Round 6: the REFERENCE's own class indices at the two utterances where a kernel's 9-bit RAW output parted ways with the C oracle in
+    the 12.4 M segment-step measurement (scripts/gpu_raw_flips.py; fatchord_version.py:231-237).  What is recorded here: over these 2 x 193,600
+    segment-steps the oracle is identical to the reference EXCEPT at utterance 34, segment 2, step 7,399 -- class 239 against the reference's 29
+    (the two largest p / q ratios are within ~1e-7 there; with these weights the perturbation dies out: every later sample of the segment is
+    identical again) --, i.e. the oracle is a bit-exact stand-in for the reference on every fixture but not over unbounded lengths, and the GPU
+    tests of these two utterances (tests/test_gpu_fullsize.py) compare with the REFERENCE's arrays.  The oracle side comes from tests/_cache
+    (13 minutes of CPU per utterance otherwise)."""
+    import os
+    from helpers import oracle_utterance, CACHE, _oracle_src_sha
+    cfg, g = load_case(name)
+    key = f"RAW_w0_p0_m{cfg['mseed']}_n{cfg['seed']}_f{cfg['frames']}_t{cfg['target']}_o{cfg['overlap']}_{_oracle_src_sha()}.npz"
+    if not os.path.exists(os.path.join(CACHE, key)):
+        pytest.skip('no cached oracle output for this utterance (scripts/make_oracle_cache.py raw64)')
+    ref_cls = g['cls'].astype(np.int64)
+    assert ref_cls.shape == (16, 12100) and int(g['n_classes']) == 512
+    orc = oracle_utterance('RAW', cfg['wseed'], 0.0, cfg['mseed'], cfg['seed'], cfg['frames'], want_cond=False)['ref']
+    orc_cls = np.rint((orc.astype(np.float64) + 1.0) * 511.0 / 2.0).astype(np.int64)
+    diff = [(int(b), int(t), int(ref_cls[b, t]), int(orc_cls[b, t])) for b, t in np.argwhere(ref_cls != orc_cls)]
+    assert diff == FLIP_CASES[name], diff
