@@ -120,11 +120,8 @@ def source_sha16():
     workload is matched separately: kernel, mode, segments, T): the translation units and headers the vocoder's loop kernels,
     their launcher and the conditioning slabs they read are compiled from -- not the Tacotron / generic / sparse / self-test
     units, which cannot change what those dispatches move."""
-    import hashlib
-    h = hashlib.sha256()
-    for name in ('wrnn_abi.hip', 'wrnn_cond.hip', 'wrnn_device.h', 'wrnn_duo.hip', 'wrnn_loop.hip', 'wrnn_ring.h', 'wrnn_tiles.h'):
-        h.update(open(os.path.join(ROOT, 'wavernn_amd', 'csrc', name), 'rb').read())
-    return h.hexdigest()[:16]
+    from wavernn_amd.batch import kernel_source_sha16
+    return kernel_source_sha16()
 
 
 def self_launch(n):
@@ -280,7 +277,36 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    from wavernn_amd.batch import shard_bounds, choose_ranks
+    from wavernn_amd.batch import shard_bounds, choose_ranks, step_table
+
+    def measure_step_table():
+        """us per step of the loop kernel `auto` picks at 1 .. 8 groups in flight per cluster (64 .. 512 segments on this GPU), MoL, synthetic
+        conditioning, 200 steps each: what `choose_ranks` weighs a split of the fixed corpus with -- measured here, on this device and these
+        sources, so that the planner cannot run on stale numbers (round-5 verdict).  Rank 0 also writes it to gpurun_out/step_us.json (copied
+        to profiles/step_us.json by the builder: `wavernn_amd.batch.step_table` reads it where nothing can be measured, e.g. dry-host runs)."""
+        if dry or eng is None or mode != 'MOL' or args.prune > 0:
+            return None
+        rs = np.random.RandomState(5)
+        T4, stride = 200, 64
+        tab = {}
+        for d in range(1, 9):
+            B4 = 64 * d
+            L4 = (B4 * stride + T4 + hop - 1) // hop * hop
+            mu = torch.from_numpy(rs.uniform(0, 1, (L4, 80)).astype(np.float32)).to(dev)
+            au = torch.from_numpy(rs.uniform(-1, 1, (L4 // hop, 128)).astype(np.float32)).to(dev)
+            nz = torch.empty(T4, 11 * B4, device=dev).uniform_(1e-5, 1 - 1e-5)
+            for _ in range(2):
+                eng.run(mu, au, B4, T4, stride, nz, hop, algo='auto')
+            tab[d] = round(eng.last_loop_ms() * 1e3 / T4, 3)
+        if rank == 0:
+            try:
+                os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+                json.dump({'source_sha16': source_sha16(), 'step_us_by_depth': tab, 'device': torch.cuda.get_device_name(dev),
+                           'what': 'us per step of the loop kernel `auto` picks for 64 * depth segments (MoL, 200 steps, synthetic conditioning); bench.py'},
+                          open(os.path.join(ROOT, 'gpurun_out', 'step_us.json'), 'w'), indent=1)
+            except OSError:
+                pass
+        return tab
 
     def config4_leg():
         """BASELINE config 4 beside the weak-scaling value (round-4 verdict, item 6): the FIXED corpus -- 64 random mels of 300-900 frames =
@@ -291,7 +317,12 @@ def main():
         p4 = plan_utterances([n * hop for n in f4], target, overlap)
         m4 = [torch.from_numpy(random_mel(1000 + u, n)).unsqueeze(0).to(dev) for u, n in enumerate(f4)]
         s4 = [4000 + u for u in range(len(f4))]
-        active = choose_ranks(p4.n_segments, world)
+        table = measure_step_table()
+        if group is not None and table is not None:      # every rank must plan with the SAME table: rank 0's
+            tt = torch.tensor([table[d] for d in range(1, 9)], dtype=torch.float64, device=dev)
+            dist.broadcast(tt, src=0, group=group)
+            table = {d: float(v) for d, v in zip(range(1, 9), tt.tolist())}
+        active = choose_ranks(p4.n_segments, world, table)
         tm = {}
 
         def pass4():
@@ -319,7 +350,11 @@ def main():
         out = {'what': "BASELINE config 4: the fixed corpus sharded over the ranks of this launch (STRONG scaling; `value` above is the weak-scaling batch)",
                'utterances': len(f4), 'segments': p4.n_segments, 'steps_per_segment': p4.T, 'world_seen': world_seen, 'ranks_used': active,
                'segments_per_rank': [h - l for l, h in shard_bounds(p4.n_segments, world, active)],
-               'ms_per_pass': round(d4 * 1e3, 3), 'gather_wait_ms': round(gw, 3), 'unfold_under_gather_ms': round(uu, 3)}
+               'ms_per_pass': round(d4 * 1e3, 3), 'gather_wait_ms': round(gw, 3), 'unfold_under_gather_ms': round(uu, 3),
+               'group_world_size_seen_by_the_collective': int(tm.get('world_seen', 1)),
+               'all_gather_bytes_received_per_rank_per_pass': int(tm.get('gather_bytes', 0) // max(1, reps)),
+               'planner_step_us_by_depth': table if table is not None else step_table()[0],
+               'planner_table_origin': 'measured in this run (bench.py measure_step_table)' if table is not None else step_table()[1]}
         if dry:
             out['dry_host'] = True
         else:

@@ -37,3 +37,34 @@ def test_generate_corpus_through_a_one_rank_rccl_group(tmp_path):
             assert b is not None and np.abs(a - b).max() <= MOL_TOL
     finally:
         dist.destroy_process_group()
+
+
+def test_generate_corpus_over_every_visible_gpu(tmp_path):
+    """The first real multi-GPU run checks itself (round-5 verdict, item 6; SURVEY 8e, gen_wavernn.py:26-35): with more than one GPU visible,
+    min(device_count, 8) ranks -- one process per GPU, RCCL over xGMI -- run a 5-utterance corpus through `generate_corpus`; every rank's
+    waveforms must be BITWISE what one process computes alone, and the collective must have seen all N ranks.  (One-GPU boxes: skipped; the
+    sharding logic itself runs under gloo at world 2 and 3 in tests/test_distributed_gloo.py.)"""
+    import os, socket, subprocess, sys
+    n = min(torch.cuda.device_count(), 8)
+    if n < 2:
+        pytest.skip(f'{torch.cuda.device_count()} GPU visible: the N-rank RCCL run needs at least two')
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import dist_worker as W
+    from wavernn_amd.batch import generate_corpus
+    dev = torch.device('cuda', 0)
+    mels, seeds = W.corpus()
+    alone = generate_corpus(W.model_on(dev), mels, 550, 55, True, seeds)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, W.__file__, str(tmp_path)], env=env))
+    rcs = [p.wait(timeout=600) for p in procs]
+    assert rcs == [0] * n, rcs
+    for r in range(n):
+        z = np.load(tmp_path / f'rank{r}.npz')
+        assert int(z['world_seen']) == n and float(z['reduced']) == float(n)
+        assert int(z['gather_bytes']) > 0
+        for u, a in enumerate(alone):
+            assert np.array_equal(z[f'u{u}'], a), (r, u)

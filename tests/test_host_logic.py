@@ -344,12 +344,32 @@ def test_bench_default_command_carries_the_config4_leg_dry_host(n):
 def test_choose_ranks_fills_the_pipeline_not_the_node():
     """`batch.choose_ranks`: the smallest rank count that reaches the best estimated wall time of a pass over a FIXED corpus (the step time
     depends on the pipeline depth a rank's block fills).  BASELINE config 4 (942 segments): all of 1, 2, 4, 8 GPUs; 15 of 16."""
-    from wavernn_amd.batch import choose_ranks, shard_bounds, estimate_step_us
-    assert [choose_ranks(942, w) for w in (1, 2, 4, 8, 16)] == [1, 2, 4, 8, 15]
-    assert choose_ranks(12, 8) == 1 and choose_ranks(64, 8) == 1 and choose_ranks(65, 8) == 2          # one group per cluster is as fast as it gets
+    from wavernn_amd.batch import choose_ranks, shard_bounds, estimate_step_us, DEFAULT_STEP_US_BY_DEPTH as TAB
+    assert [choose_ranks(942, w, TAB) for w in (1, 2, 4, 8, 16)] == [1, 2, 4, 8, 15]
+    assert choose_ranks(12, 8, TAB) == 1 and choose_ranks(64, 8, TAB) == 1 and choose_ranks(65, 8, TAB) == 2     # one group per cluster is as fast as it gets
     b = shard_bounds(942, 16, 15)
     assert b[15] == (942, 942) and sum(h - l for l, h in b) == 942 and b[0][0] == 0 and b[14][1] == 942
-    assert estimate_step_us(118) < estimate_step_us(135) < estimate_step_us(236)
+    assert estimate_step_us(118, TAB) < estimate_step_us(135, TAB) < estimate_step_us(236, TAB)
+    # a table measured elsewhere changes the plan: were depth 2 as slow as depth 3, five GPUs (189 segments each: depth 3) would do for 942 segments
+    flat = dict(TAB); flat[2] = flat[3]
+    assert choose_ranks(942, 8, flat) == 5
+
+
+def test_step_table_is_keyed_to_the_kernel_sources(tmp_path):
+    """`batch.step_table`: the record bench.py measured is used only for the kernel sources it was measured on (round-5 verdict: the planner's
+    step times were constants in the code that went stale silently); anything else falls back to the built-in numbers and says so."""
+    import json
+    from wavernn_amd.batch import step_table, kernel_source_sha16, DEFAULT_STEP_US_BY_DEPTH
+    f = tmp_path / 'step_us.json'
+    tab = {str(d): 10.0 + d for d in range(1, 9)}
+    json.dump({'source_sha16': kernel_source_sha16(), 'step_us_by_depth': tab}, open(f, 'w'))
+    t, origin = step_table(str(f))
+    assert t == {d: 10.0 + d for d in range(1, 9)} and 'measured on these kernel sources' in origin
+    json.dump({'source_sha16': '0' * 16, 'step_us_by_depth': tab}, open(f, 'w'))
+    t, origin = step_table(str(f))
+    assert t == DEFAULT_STEP_US_BY_DEPTH and 'other kernel sources' in origin
+    t, origin = step_table(str(tmp_path / 'absent.json'))
+    assert t == DEFAULT_STEP_US_BY_DEPTH and 'built-in' in origin
 
 
 def test_bench_eight_ranks_share_config4_dry_host():

@@ -78,28 +78,67 @@ def shard_bounds(n_segments: int, world: int, active: Optional[int] = None):
     return [((r * n_segments) // active, ((r + 1) * n_segments) // active) if r < active else (n_segments, n_segments) for r in range(world)]
 
 
-#: measured step time (us) of the dense loop kernels by groups in flight per cluster (4 clusters x depth x 16 segments per GPU; one MI355X:
-#: wrnn_chain_kernel at depth 1-2, wrnn_duo_kernel from 3 on; profiles/r05i_probe_chain_depths.json, r04p_probe.json): what
-#: `choose_ranks` weighs a split with
-STEP_US_BY_DEPTH = {1: 10.4, 2: 13.8, 3: 19.8, 4: 23.5, 5: 28.0, 6: 32.0, 7: 36.5, 8: 40.5}
+#: LAST-RESORT step times (us) of the dense MoL loop kernels by groups in flight per cluster (4 clusters x depth x 16 segments per GPU, one MI355X,
+#: round 6: wrnn_chain_kernel at depth 1-2, wrnn_duo_kernel from 3 on).  `choose_ranks` plans with a table that is MEASURED: bench.py times the
+#: depths on the device it runs on and hands the table over (and records it in profiles/step_us.json, keyed by a hash of the kernel sources, like
+#: profiles/traffic_latest.json); without one `step_table()` reads that file and falls back to these numbers -- saying so -- only when the file is
+#: missing or was measured on other sources.
+DEFAULT_STEP_US_BY_DEPTH = {1: 10.4, 2: 13.8, 3: 19.4, 4: 22.9, 5: 27.4, 6: 31.3, 7: 35.5, 8: 38.9}
+_STEP_TABLE = None
 
 
-def estimate_step_us(n_segments: int) -> float:
+def kernel_source_sha16() -> str:
+    """Hash of the sources the dense loop kernels are compiled from (what a measured step-time / traffic record belongs to)."""
+    import hashlib
+    import os
+    from . import _lib
+    h = hashlib.sha256()
+    for name in ('wrnn_abi.hip', 'wrnn_cond.hip', 'wrnn_device.h', 'wrnn_duo.hip', 'wrnn_loop.hip', 'wrnn_ring.h', 'wrnn_tiles.h'):
+        h.update(open(os.path.join(_lib.CSRC, name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def step_table(path: Optional[str] = None):
+    """(table {depth: us per step}, origin string).  The record bench.py wrote for THESE kernel sources, else the built-in numbers."""
+    global _STEP_TABLE
+    if _STEP_TABLE is None or path is not None:
+        import json
+        import os
+        from . import _lib
+        f = path or os.path.join(os.path.dirname(os.path.dirname(_lib.CSRC)), 'profiles', 'step_us.json')
+        table, origin = dict(DEFAULT_STEP_US_BY_DEPTH), 'built-in defaults (no profiles/step_us.json)'
+        try:
+            j = json.load(open(f))
+            if j.get('source_sha16') == kernel_source_sha16():
+                table, origin = {int(k): float(v) for k, v in j['step_us_by_depth'].items()}, f'{f} (measured on these kernel sources)'
+            else:
+                origin = f'built-in defaults ({f} was measured on other kernel sources)'
+        except (OSError, ValueError, KeyError):
+            pass
+        if path is not None:
+            return table, origin
+        _STEP_TABLE = (table, origin)
+    return _STEP_TABLE
+
+
+def estimate_step_us(n_segments: int, table: Optional[dict] = None) -> float:
     """Step time of one GPU that advances `n_segments` segments by one sample (rounds of <= 512 segments at the measured depth)."""
     if n_segments <= 0:
         return 0.0
+    table = table or step_table()[0]
     groups = -(-n_segments // 16)
     rounds = -(-groups // 32)
     depth = min(8, max(1, -(-(-(-groups // rounds)) // 4)))
-    return rounds * STEP_US_BY_DEPTH[depth]
+    return rounds * table[depth]
 
 
-def choose_ranks(n_segments: int, world: int) -> int:
+def choose_ranks(n_segments: int, world: int, table: Optional[dict] = None) -> int:
     """How many of `world` GPUs a FIXED corpus of `n_segments` folded segments should be sharded over (strong scaling, BASELINE config 4):
     the wall time of a pass is the step time of the largest block, which depends on the pipeline depth that block fills -- not on the rank
     count as such -- so the smallest rank count that reaches the best estimated wall time is taken (942 segments on 8 GPUs: 118 per GPU =
-    depth 2, and 7 GPUs would need depth 3: all 8; on 16 GPUs: 15 suffice).  The ranks left out still take part in the all-gather."""
-    est = [estimate_step_us(-(-n_segments // r)) for r in range(1, world + 1)]
+    depth 2, and 7 GPUs would need depth 3: all 8; on 16 GPUs: 15 suffice).  The ranks left out still take part in the all-gather.
+    table: {depth: us per step} measured by the caller (bench.py); default: `step_table()`."""
+    est = [estimate_step_us(-(-n_segments // r), table) for r in range(1, world + 1)]
     best = min(est)
     return 1 + next(i for i, e in enumerate(est) if e <= best * 1.01)
 
@@ -320,6 +359,9 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
     if group is not None:
         gathered = [torch.empty_like(out_local) for _ in range(world)]
         work = dist.all_gather(gathered, out_local, group=group, async_op=True)
+        if timings is not None:                         # what this rank receives over the fabric in the ONE collective of the path
+            timings['gather_bytes'] = timings.get('gather_bytes', 0) + (world - 1) * out_local.numel() * out_local.element_size()
+            timings['world_seen'] = dist.get_world_size(group)
 
     def gathered_segments():
         nonlocal work
