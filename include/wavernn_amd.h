@@ -45,7 +45,8 @@ enum { WRNN_MODE_RAW = 0, WRNN_MODE_MOL = 1 };  /* reference: WaveRNN(mode='RAW'
 /* Loop kernel selection. */
 enum {
     WRNN_ALGO_AUTO = 0,     /* shipped dims: WRNN_ALGO_SPARSE when the pack qualifies (wrnn_pack_sparse_blocks() > 0) on a 256-CU device, else
-                               WRNN_ALGO_CHAIN (MOL, <= 64 segments, 256 CUs), else WRNN_ALGO_DUO (MOL, or RAW with 512 classes; >= 128 CUs),
+                               WRNN_ALGO_CHAIN (MOL or RAW with 512 classes, <= 128 segments, 256 CUs, dense pack), else WRNN_ALGO_DUO (MOL, or RAW
+                               with 512 classes; >= 128 CUs),
                                else WRNN_ALGO_STREAM; other dims: wrnn_generic_kernel */
     WRNN_ALGO_STREAM = 1,   /* one workgroup per folded segment, weights streamed from L2/MALL each step: the generic fallback
                                (any class count, any device size) and the on-GPU cross-check */

@@ -298,7 +298,8 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
                 if len(utts) > 1 and mode == 'RAW':       # (MoL: 11 draws per segment-step -- not worth a thread)
                     import os
                     from concurrent.futures import ThreadPoolExecutor
-                    pool = ThreadPoolExecutor(max(1, min(len(utts), (os.cpu_count() or 2) // 2)))
+                    # (the host's cores are shared by the ranks of the node: LOCAL_WORLD_SIZE, as torch.distributed.run and bench.py set it)
+                    pool = ThreadPoolExecutor(max(1, min(len(utts), (os.cpu_count() or 2) // (2 * max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1')))))))
                 from .rng import burn_ctor_draws
                 for u in utts:
                     gens[u] = torch.Generator(device='cpu').manual_seed(int(seeds[u]))

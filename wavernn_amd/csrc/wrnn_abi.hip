@@ -465,9 +465,11 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
         pl->ngr_max = (pl->per_round + SEG - 1) / SEG;
         if (pl->ngr_max > ccl * g) { pl->rounds += 1; pl->per_round = (B + pl->rounds - 1) / pl->rounds; pl->ngr_max = (pl->per_round + SEG - 1) / SEG; }
         int slab = o->slab_steps;
-        if (slab < 1) slab = p->mode == WRNN_MODE_MOL ? (int)((32u << 20) / ((size_t)pl->per_round * 11 * sizeof(float) * pl->rounds)) : 4096;
-        if (slab < 16) slab = 16;
-        if (slab > 4096) slab = 4096;
+        if (slab < 1) {                      // (an explicit slab length is taken as given -- short slabs included: tests -- as the duo branch does)
+            slab = p->mode == WRNN_MODE_MOL ? (int)((32u << 20) / ((size_t)pl->per_round * 11 * sizeof(float) * pl->rounds)) : 4096;
+            if (slab < 16) slab = 16;
+            if (slab > 4096) slab = 4096;
+        }
         if (slab > T) slab = T;
         pl->slab = slab;
         pl->tab_fps = DUO_TAB_FPS;
@@ -489,9 +491,11 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
         pl->ngr_max = (pl->per_round + SEG - 1) / SEG;
         if (pl->ngr_max > scl) { pl->rounds += 1; pl->per_round = (B + pl->rounds - 1) / pl->rounds; pl->ngr_max = (pl->per_round + SEG - 1) / SEG; }
         int slab = o->slab_steps;
-        if (slab < 1) slab = (int)((32u << 20) / ((size_t)pl->per_round * 11 * sizeof(float) * pl->rounds));      // one slab of derived noise
-        if (slab < 16) slab = 16;
-        if (slab > 4096) slab = 4096;
+        if (slab < 1) {
+            slab = (int)((32u << 20) / ((size_t)pl->per_round * 11 * sizeof(float) * pl->rounds));      // one slab of derived noise
+            if (slab < 16) slab = 16;
+            if (slab > 4096) slab = 4096;
+        }
         if (slab > T) slab = T;
         pl->slab = slab;
         pl->tab_fps = DUO_TAB_FPS;
@@ -549,6 +553,12 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
         set_err("a partial step range [%d, %d) needs a persistent loop kernel", pl->t0, pl->t1);
         return WRNN_ERR_ARG;
     }
+    // the kernels that form their conditioning in the loop index the per-segment, per-slab aux tables with 32-bit byte offsets inside one buffer
+    // resource: refused HERE, so that wrnn_plan_segments / wrnn_workspace_bytes_segments report it and nothing has been queued when a call fails
+    if ((pl->kind == K_DUO || pl->kind == K_SPARSE || pl->kind == K_CHAIN) && ((size_t)B * pl->tab_fps + 1) * 3 * H * sizeof(float) >= 0x7FFFF000ull) {
+        set_err("%d segments in one call: the per-slab aux tables exceed a 2 GB buffer resource; split the call (generate_corpus caps a launch at 4096 segments)", B);
+        return WRNN_ERR_ARG;
+    }
     return WRNN_OK;
 }
 
@@ -571,7 +581,8 @@ WsLayout ws_layout(const wrnn_pack *p, const Plan &pl, int B, int T, int n_frame
     l.c4f = o;    o = al(o + tab_rows * H * sizeof(float));
     const bool mol = p->mode == WRNN_MODE_MOL;
     if (pl.kind == K_LOOP || slabbed) {
-        l.xbuf = o;  o = al(o + (slabbed ? duo_xbuf_bytes_max() : XBUF_FLOATS * sizeof(float)));
+        // (the exchange regions a kernel touches: wrnn_chain_kernel G x 4, wrnn_sparse_kernel 16, wrnn_duo_kernel up to 8 x 4 -- its launches may differ in depth)
+        l.xbuf = o;  o = al(o + (pl.kind == K_CHAIN ? chain_xbuf_bytes(pl.G) : pl.kind == K_SPARSE ? sparse_xbuf_bytes() : slabbed ? duo_xbuf_bytes_max() : XBUF_FLOATS * sizeof(float)));
         l.state = o; o = al(o + (size_t)pl.rounds * (pl.kind == K_SPARSE ? sparse_state_floats() : pl.kind == K_CHAIN ? chain_state_floats(pl.G) : loop_state_floats(pl.G)) * sizeof(float));
         l.cIf = o;   if (pl.kind == K_LOOP) o = al(o + (size_t)pl.slab * pl.ngr_max * SEG * H * sizeof(float));      // (the duo kernel forms cI in the loop)
         l.npre = o;  if (mol) o = al(o + (size_t)pl.slab * 11 * B * sizeof(float));      // derived MOL noise of one slab
@@ -765,11 +776,6 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
         // the aux tables are per segment and slab (filled in the slab loop): a slab may not span more than tab_fps - 2 whole hops
         const long eff = (long)(pl.tab_fps - 2) * hop + 1;
         if (pl.slab > eff) pl.slab = (int)eff;
-        // (the kernels index the tables with 32-bit byte offsets inside one buffer resource)
-        if (((size_t)B * pl.tab_fps + 1) * 3 * H * sizeof(float) >= 0x7FFFF000ull) {
-            set_err("%d segments in one call: the per-slab aux tables exceed a 2 GB buffer resource; split the call (generate_corpus caps a launch at 4096 segments)", B);
-            return WRNN_ERR_ARG;
-        }
     } else HIPCHK(launch_cond_frames(c, stream));
 
     LoopArgs a;

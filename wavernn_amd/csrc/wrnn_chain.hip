@@ -1,5 +1,6 @@
-// wrnn_chain.hip -- the persistent WaveRNN loop kernel (MOL and 9-bit RAW, dense weights) for SMALL batches: <= 64 folded segments = one utterance of
-// BASELINE config 2 (N = 481 -> 12 segments; N = 1001 -> 24) or config 3's sentence (19), on MI355X (gfx950 / CDNA4).  Round 5.
+// wrnn_chain.hip -- the persistent WaveRNN loop kernel (MOL and 9-bit RAW, dense weights) for SMALL batches: <= 128 folded segments (what `auto` runs on
+// it: one group per 64-CU cluster up to 64 segments = one utterance of BASELINE config 2 (N = 481 -> 12 segments; N = 1001 -> 24) or config 3's
+// sentence (19); two groups per cluster up to 128), on MI355X (gfx950 / CDNA4).  Round 5.
 //
 // With one group of <= 16 segments per cluster nothing can be pipelined: a step of reference models/fatchord_version.py:201-241 IS the
 // latency of its chain x_{t-1} -> h1 -> h2 -> fc1 -> fc2 -> sample.  wrnn_duo.hip (two workgroups per CU, four roles, built for throughput:

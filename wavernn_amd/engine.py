@@ -23,7 +23,7 @@ FALLBACK_ALGO = {'wrnn_sparse_kernel': 'duo', 'wrnn_chain_kernel': 'duo', 'wrnn_
 
 
 class MelRows:
-    """The conditioning mel handed to the loop ONE up-sampling stage short (`wrnn_options.mel_stage = 1`; wrnn_duo_kernel and wrnn_sparse_kernel): the
+    """The conditioning mel handed to the loop ONE up-sampling stage short (`wrnn_options.mel_stage = 1`; wrnn_duo_kernel, wrnn_chain_kernel and wrnn_sparse_kernel): the
     kernel forms the last Stretch2d + conv stage and the crop (reference models/fatchord_version.py:73-80, :86-88) itself, so the
     [L, feat] up-sampled mel is never written.
 
@@ -91,6 +91,7 @@ class LoopEngine:
         self._last_opts = None
         self._launches = 0
         self._slice_algo = None
+        self._auto_floor = None           # the kernel an `auto` call degraded to after a refused cooperative launch: where later `auto` calls start
         self._progress_keep = []          # ctypes thunks of progress callbacks whose host functions may still be queued on the stream
 
     def __del__(self):
@@ -122,6 +123,8 @@ class LoopEngine:
         return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, **kw)
 
     def options(self, algo='auto', depth=0, clusters=0, slab_steps=0, cond_valu=False, t_range=None, tuning=0):
+        if algo == 'auto' and self._auto_floor is not None:      # (after a refused cooperative launch: see run_segments)
+            algo = self._auto_floor
         o = _lib.Options()
         o.algo = _lib.ALGOS[algo]
         o.depth, o.clusters, o.slab_steps, o.cond_valu = int(depth), int(clusters), int(slab_steps), int(bool(cond_valu))
@@ -231,15 +234,21 @@ class LoopEngine:
                 self._ws = None
                 if progress is not None:
                     self._progress_keep.pop()       # (the retry registers its own thunk)
-                return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo=nxt, force_x=force_x, want_logits=want_logits,
-                                         check=check, slab_steps=slab_steps, cond_valu=cond_valu, t_range=t_range, out=out, logits=logits,
-                                         phase_clocks=phase_clocks, tuning=tuning, progress=progress, _fallback=True)
+                res = self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo=nxt, depth=depth, clusters=clusters, force_x=force_x,
+                                        want_logits=want_logits, check=check, slab_steps=slab_steps, cond_valu=cond_valu, t_range=t_range, out=out,
+                                        logits=logits, phase_clocks=phase_clocks, tuning=tuning, progress=progress, _fallback=True)
+                if algo == 'auto':
+                    self._auto_floor = self._auto_floor or nxt       # later `auto` calls start from the kernel that ran (no refused launch + workspace re-allocation per call)
+                return res
             if t1 == T:
                 warnings.warn('wavernn_amd: cooperative launch refused (' + why + '); using the stream kernel')
                 if progress is not None:
                     self._progress_keep.pop()
+                if algo == 'auto':
+                    self._auto_floor = 'stream'
                 return self.run_segments(mels_up, aux, seg_pos, seg_lim, T, noise, hop, algo='stream', force_x=force_x,
-                                         want_logits=want_logits, check=check, cond_valu=cond_valu, out=out, logits=logits, progress=progress)
+                                         want_logits=want_logits, check=check, slab_steps=slab_steps, cond_valu=cond_valu, out=out, logits=logits,
+                                         phase_clocks=phase_clocks, tuning=tuning, progress=progress)
             # ... the same refusal on the first slice of a step-sliced run (only the loop kernels continue a call): the caller, who owns
             # the slicing and the noise stream, redoes the whole call on the stream kernel
             raise _lib.ResidencyError('cooperative launch refused (' + why + ')')
