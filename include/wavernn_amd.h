@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define WRNN_ABI_VERSION 7   /* v7 (round 5): WRNN_ALGO_CHAIN (wrnn_chain_kernel, what `auto` runs for <= 128 segments of a dense model, MOL or 9-bit RAW); WRNN_ALGO_SPARSE is the rebuilt wrnn_sparse_kernel (slabbed, resumable, takes mel_stage) and what `auto` picks for a qualifying pack; wrnn_options.depth does not apply to it.  v6 (round 4): wrnn_options.mel_stage & co + wrnn_pre_upsample_rows -- the last up-sampling stage formed inside wrnn_duo_kernel.  v5 (round 4): WRNN_ALGO_DUO runs RAW too; `auto` never degrades inside the library (WRNN_ERR_RESIDENCY: the caller re-plans); tuning bits per kernel */
+#define WRNN_ABI_VERSION 8   /* v8 (round 6): WRNN_ALGO_OCTO (wrnn_octo_kernel: one 512-thread workgroup per CU, matrix waves + service waves; dense MOL).  v7 (round 5): WRNN_ALGO_CHAIN (wrnn_chain_kernel, what `auto` runs for <= 128 segments of a dense model, MOL or 9-bit RAW); WRNN_ALGO_SPARSE is the rebuilt wrnn_sparse_kernel (slabbed, resumable, takes mel_stage) and what `auto` picks for a qualifying pack; wrnn_options.depth does not apply to it.  v6 (round 4): wrnn_options.mel_stage & co + wrnn_pre_upsample_rows -- the last up-sampling stage formed inside wrnn_duo_kernel.  v5 (round 4): WRNN_ALGO_DUO runs RAW too; `auto` never degrades inside the library (WRNN_ERR_RESIDENCY: the caller re-plans); tuning bits per kernel */
 
 enum {
     WRNN_OK = 0,
@@ -60,6 +60,10 @@ enum {
     WRNN_ALGO_CHAIN = 7,    /* the single-stream latency kernel (MOL and 9-bit RAW, <= 256 segments, 256 CUs): one workgroup per CU, <= 4 groups of <= 16 segments per
                                64-CU cluster, both halves of a GRU cell's rows in one workgroup (gh never leaves the registers), rnn2 + fc1 + fc2
                                on one XCD (csrc/wrnn_chain.hip).  What `auto` runs for one utterance (<= 128 segments) of a dense model */
+    WRNN_ALGO_OCTO = 8,     /* the WAVE-SPECIALISED form of the dense loop kernel (MOL, 256 CUs; round 6): ONE 512-thread workgroup per CU -- four matrix
+                               waves (W_ih and W_hh of the CU's 16 units in registers, the fc tile in LDS: operand by LDS-DMA, MFMA block, partial tiles)
+                               and four service waves (partial sums, GRU cell, publishes, conditioning, fc3 + sampling) that meet through LDS counters;
+                               gh never leaves the CU.  Same split, workspace, exchange buffer and state layout as WRNN_ALGO_DUO (csrc/wrnn_octo.hip) */
     WRNN_ALGO_SPARSE = 5    /* block-sparse GRU kernel (MOL; BASELINE config 5): needs GRU matrices whose 16x1 block rows keep <= 64 columns
                                (wrnn_pack_sparse_blocks) and a 256-CU device; 16 clusters of 16 CUs, ONE group of <= 16 segments each: a
                                step is the latency of one chain, sixteen chains run side by side (csrc/wrnn_sparse.hip) */

@@ -43,6 +43,7 @@ VARS = {'auto': dict(algo='auto'), 'stream': dict(algo='stream'), 'g1': dict(alg
         # wrnn_duo_kernel (round 4): tuning bit 0 = loads first, bit 1 = publish first (default: by depth), bit 8 = every layer written through
         # (no XCD-local plain stores), bit 2 = ring re-filled before every launch
         'd1': dict(algo='duo', depth=1), 'd2': dict(algo='duo', depth=2), 'd3': dict(algo='duo', depth=3), 'd4': dict(algo='duo', depth=4),
+        **{f'o{d}': dict(algo='octo', depth=d) for d in range(1, 9)}, 'oauto': dict(algo='octo'),       # wrnn_octo_kernel (round 6)
         'd5': dict(algo='duo', depth=5), 'd6': dict(algo='duo', depth=6), 'd8': dict(algo='duo', depth=8), 'dauto': dict(algo='duo'),
         'd2lf': dict(algo='duo', depth=2, tuning=1), 'd3lf': dict(algo='duo', depth=3, tuning=1), 'd4lf': dict(algo='duo', depth=4, tuning=1),
         'd6lf': dict(algo='duo', depth=6, tuning=1), 'd8lf': dict(algo='duo', depth=8, tuning=1),
@@ -75,7 +76,7 @@ for B in [int(x) for x in args.B.split(',')]:
             opts['tuning'] = int(v.split('+')[1], 0)
         try:
             depth = opts.get('depth', 0)
-            if depth > 1 and B <= 64 * (depth - 1) and opts['algo'] in ('loop', 'duo', 'chain'):
+            if depth > 1 and B <= 64 * (depth - 1) and opts['algo'] in ('loop', 'duo', 'chain', 'octo'):
                 continue                                              # the extra slots would stay empty: same run as a shallower depth
             out = eng.run(mels_up, aux, B, T, stride, noise, hop, **opts)
             out = eng.run(mels_up, aux, B, T, stride, noise, hop, **opts)

@@ -95,18 +95,27 @@ VARIANTS = {
     'chain-g2': dict(algo='chain', depth=2),
     'chain-g2-slabs': dict(algo='chain', depth=2, slab_steps=97),
     'chain-g4': dict(algo='chain', depth=4, slab_steps=131),
+    # round 6: the wave-specialised form (MOL): matrix waves + service waves in one 512-thread workgroup per CU; the duo kernel's splits
+    'octo': dict(algo='octo'),
+    'octo-g1': dict(algo='octo', depth=1),
+    'octo-g2-slabs': dict(algo='octo', depth=2, slab_steps=97),
+    'octo-c1-g3': dict(algo='octo', clusters=1, depth=3, slab_steps=160),
+    'octo-c2-g2': dict(algo='octo', clusters=2, depth=2),
+    'octo-g1-wt': dict(algo='octo', depth=1, tuning=256),
 }
-KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'loop': 'wrnn_loop_kernel', 'sparse': 'wrnn_sparse_kernel', 'duo': 'wrnn_duo_kernel', 'chain': 'wrnn_chain_kernel'}
+KERNEL_NAME = {'stream': 'wrnn_stream_kernel', 'loop': 'wrnn_loop_kernel', 'sparse': 'wrnn_sparse_kernel', 'duo': 'wrnn_duo_kernel', 'chain': 'wrnn_chain_kernel',
+               'octo': 'wrnn_octo_kernel'}
 
 
 def _skip_unless_supported(mode, opts):
-    pass            # (every kernel of VARIANTS runs both modes: the duo kernel since round 4, wrnn_chain_kernel since round 5)
+    if opts.get('algo') == 'octo' and mode != 'MOL':      # (every other kernel of VARIANTS runs both modes: the duo kernel since round 4, wrnn_chain_kernel since round 5)
+        pytest.skip('wrnn_octo_kernel is a MOL kernel (RAW runs on wrnn_duo_kernel / wrnn_chain_kernel)')
 
 
 def test_device_selftests(gpu):
     from wavernn_amd import _lib
     L = _lib.lib()
-    assert L.wrnn_abi_version() == 7
+    assert L.wrnn_abi_version() == 8
     assert L.wrnn_device_cus(0) > 0
     _lib.check(L.wrnn_selftest(0, 1), 'mfma selftest')
     print(L.wrnn_last_error().decode())
@@ -150,7 +159,7 @@ def test_exchange_layers_match_oracle(gpu, mode):
         assert np.abs(out.cpu().numpy() - ref).max() <= MOL_TOL
 
 
-@pytest.mark.parametrize('mode,algo', [('MOL', 'loop'), ('RAW', 'loop'), ('MOL', 'duo'), ('RAW', 'duo'), ('MOL', 'chain'), ('RAW', 'chain')])
+@pytest.mark.parametrize('mode,algo', [('MOL', 'loop'), ('RAW', 'loop'), ('MOL', 'duo'), ('RAW', 'duo'), ('MOL', 'chain'), ('RAW', 'chain'), ('MOL', 'octo')])
 def test_step_ranges_continue_bit_exactly(gpu, mode, algo):
     """`wrnn_options.t_begin / t_end`: the loop run as calls over [0, 200), [200, 201), [201, 203), [203, T), each with only its
     own rows of noise, equals the single call bit for bit (the per-group state lives in the workspace between calls; the duo
@@ -161,7 +170,7 @@ def test_step_ranges_continue_bit_exactly(gpu, mode, algo):
     eng = LoopEngine(sd, mode, device=gpu)
     mu, au, nz = torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), torch.from_numpy(flat).to(gpu)
     whole = eng.run(mu, au, B, T, stride, nz, 275, algo=algo, slab_steps=128).cpu().numpy()
-    if algo in ('duo', 'chain'):       # ... and the ring re-filled before every launch (tuning bit 2) changes nothing
+    if algo in ('duo', 'chain', 'octo'):       # ... and the ring re-filled before every launch (tuning bit 2) changes nothing
         again = eng.run(mu, au, B, T, stride, nz, 275, algo=algo, slab_steps=128, tuning=4).cpu().numpy()
         assert np.array_equal(again, whole)
         short = eng.run(mu, au, B, T, stride, nz, 275, algo=algo, slab_steps=3).cpu().numpy()      # slabs shorter than the re-arm distance
@@ -238,7 +247,7 @@ def test_loop_matches_reference_golden(gpu, name, variant):
         assert np.abs(out - ref).max() <= MOL_TOL
 
 
-@pytest.mark.parametrize('variant', ['stream', 'loop', 'loop-g2-slabs', 'duo', 'duo-g2-slabs', 'chain', 'chain-slabs'])
+@pytest.mark.parametrize('variant', ['stream', 'loop', 'loop-g2-slabs', 'duo', 'duo-g2-slabs', 'chain', 'chain-slabs', 'octo', 'octo-g2-slabs'])
 @pytest.mark.parametrize('name', ['raw_batched_60f', 'mol_batched_100f'])
 def test_teacher_forced_logits(gpu, name, variant):
     """Feed the reference's samples back (teacher forcing) and compare every step's fc3 logits with the C
@@ -717,6 +726,9 @@ def test_planner_picks_the_kernel_by_pack_and_batch(gpu):
         pl = dense.plan(n, 12100)
         assert (pl['kernel'], pl['clusters'], pl['depth'], pl['rounds']) == (kernel, 4, depth, 1), (n, pl)
     assert dense.plan(256, 12100, algo='chain')['depth'] == 4 and dense.plan(300, 12100, algo='chain')['rounds'] == 2
+    # wrnn_octo_kernel (round 6, on request only): the duo kernel's split up to FOUR slots per cluster (its LDS carve), rounds beyond; MOL only
+    assert dense.plan(256, 12100, algo='octo') == dict(dense.plan(256, 12100, algo='duo'), kernel='wrnn_octo_kernel')
+    assert (dense.plan(512, 12100, algo='octo')['depth'], dense.plan(512, 12100, algo='octo')['rounds']) == (4, 2)
     with pytest.raises(_lib.WrnnError, match='block-sparse kernel needs'):
         dense.plan(16, 100, algo='sparse')
     raw = LoopEngine(random_state_dict(3, mode='RAW'), 'RAW', device=gpu)
@@ -725,6 +737,8 @@ def test_planner_picks_the_kernel_by_pack_and_batch(gpu):
     assert raw8.plan(12, 100)['kernel'] == 'wrnn_stream_kernel'
     with pytest.raises(_lib.WrnnError, match='wrnn_chain_kernel needs MOL or RAW with 512 classes'):
         raw8.plan(12, 100, algo='chain')
+    with pytest.raises(_lib.WrnnError, match='wrnn_octo_kernel needs MOL'):
+        raw.plan(256, 12100, algo='octo')
     sparse = LoopEngine(block_prune_state_dict(sd, 0.95, (16, 1))[0], 'MOL', device=gpu)
     for n, rounds in ((12, 1), (256, 1), (257, 2), (942, 4)):
         pl = sparse.plan(n, 12100)

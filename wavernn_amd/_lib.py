@@ -14,9 +14,9 @@ SO_PATH = os.path.join(CSRC, 'libwavernn_amd.so')
 WRNN_OK = 0
 ERR_RESIDENCY = -6          # WRNN_ERR_RESIDENCY: the persistent grid cannot be co-resident on this device
 MODE_RAW, MODE_MOL = 0, 1
-ABI_VERSION = 7
-ALGO_AUTO, ALGO_STREAM, ALGO_LOOP, ALGO_SPARSE, ALGO_DUO, ALGO_CHAIN = 0, 1, 2, 5, 6, 7
-ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'loop': ALGO_LOOP, 'sparse': ALGO_SPARSE, 'duo': ALGO_DUO, 'chain': ALGO_CHAIN}
+ABI_VERSION = 8
+ALGO_AUTO, ALGO_STREAM, ALGO_LOOP, ALGO_SPARSE, ALGO_DUO, ALGO_CHAIN, ALGO_OCTO = 0, 1, 2, 5, 6, 7, 8
+ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'loop': ALGO_LOOP, 'sparse': ALGO_SPARSE, 'duo': ALGO_DUO, 'chain': ALGO_CHAIN, 'octo': ALGO_OCTO}
 
 #: every symbol include/wavernn_amd.h declares
 EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_create', 'wrnn_pack_destroy',

@@ -35,6 +35,9 @@ size_t sparse_state_floats();
 size_t sparse_xbuf_bytes();
 hipError_t launch_put_floats(float *dst, const float *src, int n, hipStream_t stream);
 hipError_t launch_chain(const LoopArgs &args, int mode, hipStream_t stream);
+hipError_t launch_octo(const LoopArgs &args, int ncl, int mode, hipStream_t stream);
+int octo_clusters(int n_cus);
+int octo_max_depth();
 int chain_clusters(int n_cus);
 int chain_max_depth();
 size_t chain_state_floats(int G);
@@ -386,6 +389,7 @@ constexpr int DUO_TAB_FPS = 8;       // wrnn_duo_kernel: rows per segment of the
 constexpr bool DUO_AUTO = true;      // `auto` runs MoL on wrnn_duo_kernel at every depth (round 4, profiles/r04a_probe_new.json: 13.5 vs 16.6 us per step
 constexpr int CHAIN_AUTO_GROUPS = 8;   // `auto` runs calls of up to this many groups (128 segments) on wrnn_chain_kernel: one / two groups per cluster, 10.4 / 13.8 us (RAW: 12.8 / 16.3)
                                        // per step against wrnn_duo_kernel's 12.2 / 16.9; from three groups on the duo kernel wins (profiles/r05i_probe_chain_depths.json)
+constexpr bool OCTO_AUTO = false;    // `auto` runs dense MoL batches beyond wrnn_chain_kernel's range on wrnn_octo_kernel (round 6)
 constexpr int DUO_MIN_DEPTH = 1;     // with one group in flight, 17.9 vs 21.7 with two, 26.2 vs 36 with four; round 3's kernel paid off from depth 3 on)
 
 // what a call will run: kernel, split, rounds, slab length
@@ -394,6 +398,8 @@ struct Plan {
     int ncl, G, rounds, per_round, slab, ngr_max;
     int tab_fps;                        // K_DUO: rows per segment of the per-slab aux tables
     int t0, t1;
+    bool octo;                          // K_DUO planned onto wrnn_octo_kernel (one 512-thread workgroup per CU: matrix + service waves; MOL): the same split,
+                                        // workspace, exchange buffer and state layout
 };
 
 struct WsLayout {
@@ -426,7 +432,9 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
     if (pl->t0 == 0 && pl->t1 == 0) pl->t1 = T;
     if (pl->t0 < 0 || pl->t1 > T || pl->t0 >= pl->t1) { set_err("bad step range [%d, %d) of T=%d", pl->t0, pl->t1, T); return WRNN_ERR_ARG; }
     const int algo = o->algo;
-    if (algo != WRNN_ALGO_AUTO && algo != WRNN_ALGO_STREAM && algo != WRNN_ALGO_LOOP && algo != WRNN_ALGO_SPARSE && algo != WRNN_ALGO_DUO && algo != WRNN_ALGO_CHAIN) {
+    pl->octo = false;
+    if (algo != WRNN_ALGO_AUTO && algo != WRNN_ALGO_STREAM && algo != WRNN_ALGO_LOOP && algo != WRNN_ALGO_SPARSE && algo != WRNN_ALGO_DUO && algo != WRNN_ALGO_CHAIN &&
+        algo != WRNN_ALGO_OCTO) {
         set_err("unknown algo %d", algo);
         return WRNN_ERR_ARG;
     }
@@ -499,8 +507,12 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
         if (slab > T) slab = T;
         pl->slab = slab;
         pl->tab_fps = DUO_TAB_FPS;
-    } else if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_LOOP || algo == WRNN_ALGO_DUO) {
+    } else if (algo == WRNN_ALGO_AUTO || algo == WRNN_ALGO_LOOP || algo == WRNN_ALGO_DUO || algo == WRNN_ALGO_OCTO) {
         int ncl = loop_clusters(p->n_cus);
+        if (algo == WRNN_ALGO_OCTO && (p->mode != WRNN_MODE_MOL || octo_clusters(p->n_cus) != MAXCL)) {
+            set_err("wrnn_octo_kernel needs MOL and >= 256 CUs (mode %d, device has %d CUs)", p->mode, p->n_cus);
+            return p->mode != WRNN_MODE_MOL ? WRNN_ERR_ARG : WRNN_ERR_RESIDENCY;
+        }
         if (algo == WRNN_ALGO_DUO && (!shape_ok || duo_clusters(p->n_cus) < 1)) {
             set_err("the two-workgroups-per-CU loop kernel needs MOL or RAW with 512 classes, and >= 64 CUs (C = %d, device has %d CUs)", p->C, p->n_cus);
             return !shape_ok ? WRNN_ERR_ARG : WRNN_ERR_RESIDENCY;
@@ -512,7 +524,7 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
                 // without a group leaves at once), so that a small batch sits on whole XCDs exactly as a large one does
                 int c2 = 1; while (c2 < groups) c2 *= 2; if (c2 < ncl) ncl = c2;
             }
-            const int gmax = loop_max_depth(p->mode);
+            const int gmax = algo == WRNN_ALGO_OCTO ? octo_max_depth() : loop_max_depth(p->mode);      // (wrnn_octo_kernel: what its LDS carve holds)
             int g = o->depth;
             if (g < 1 || g > gmax) {
                 // as deep as the segments fill evenly: rounds = ceil(groups / (ncl * gmax)), then the shallowest depth that
@@ -525,8 +537,9 @@ int make_plan(const wrnn_pack *p, int B, int T, const wrnn_options *o, Plan *pl)
             pl->kind = K_LOOP; pl->ncl = ncl; pl->G = g;
             // the two-workgroups-per-CU form (MOL): on request, or when `auto` has >= DUO_MIN_DEPTH groups in flight per cluster
             // (busy time bounds a step there; with fewer the latency of a slot's chain does, and the duo kernel's chain is one hop longer)
-            if (algo == WRNN_ALGO_DUO || (algo == WRNN_ALGO_AUTO && DUO_AUTO && g >= DUO_MIN_DEPTH && ncl == MAXCL))
+            if (algo == WRNN_ALGO_DUO || algo == WRNN_ALGO_OCTO || (algo == WRNN_ALGO_AUTO && DUO_AUTO && g >= DUO_MIN_DEPTH && ncl == MAXCL))
                 pl->kind = K_DUO;
+            pl->octo = pl->kind == K_DUO && (algo == WRNN_ALGO_OCTO || (algo == WRNN_ALGO_AUTO && OCTO_AUTO && p->mode == WRNN_MODE_MOL && ncl == MAXCL && !o->clusters));
             pl->rounds = (groups + ncl * g - 1) / (ncl * g);
             // balanced rounds of whole segments; every round is cut into <= ncl * g groups of <= 16
             pl->per_round = (B + pl->rounds - 1) / pl->rounds;
@@ -665,7 +678,7 @@ extern "C" int wrnn_plan_segments(const wrnn_pack *p, int32_t n_segments, int32_
     int rc = make_plan(p, n_segments, T, &whole, &pl);
     if (rc != WRNN_OK) return rc;
     memset(out, 0, sizeof *out);
-    out->kernel = pl.kind == K_GENERIC ? "wrnn_generic_kernel" : pl.kind == K_CHAIN ? "wrnn_chain_kernel" : pl.kind == K_DUO ? "wrnn_duo_kernel" : pl.kind == K_LOOP ? "wrnn_loop_kernel" : (pl.kind == K_SPARSE ? "wrnn_sparse_kernel" : "wrnn_stream_kernel");
+    out->kernel = pl.kind == K_GENERIC ? "wrnn_generic_kernel" : pl.kind == K_CHAIN ? "wrnn_chain_kernel" : pl.kind == K_DUO ? (pl.octo ? "wrnn_octo_kernel" : "wrnn_duo_kernel") : pl.kind == K_LOOP ? "wrnn_loop_kernel" : (pl.kind == K_SPARSE ? "wrnn_sparse_kernel" : "wrnn_stream_kernel");
     out->units_per_wg = pl.kind == K_STREAM ? 0 : (pl.kind == K_SPARSE ? 64 : 16);
     out->clusters = pl.ncl; out->depth = pl.G; out->rounds = pl.rounds; out->slab_steps = pl.slab;
     return WRNN_OK;
@@ -806,7 +819,8 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
     if (pl.kind == K_LOOP || slabbed) {
         // ---- persistent loop kernels: for every slab of steps { derived noise; for every round { conditioning slab; loop } } ----
         const bool duo = slabbed, sparse = pl.kind == K_SPARSE, chain = pl.kind == K_CHAIN;      // (duo: the conditioning is formed in the loop)
-        info.kernel = chain ? "wrnn_chain_kernel" : sparse ? "wrnn_sparse_kernel" : (duo ? "wrnn_duo_kernel" : "wrnn_loop_kernel"); info.units_per_wg = sparse ? 64 : 16;
+        const bool octo = pl.kind == K_DUO && pl.octo;
+        info.kernel = chain ? "wrnn_chain_kernel" : sparse ? "wrnn_sparse_kernel" : (duo ? (octo ? "wrnn_octo_kernel" : "wrnn_duo_kernel") : "wrnn_loop_kernel"); info.units_per_wg = sparse ? 64 : 16;
         a.sp_vals = p->sp_vals; a.sp_cols = p->sp_cols;
         const bool mol = p->mode == WRNN_MODE_MOL;
         a.xbuf = (float *)(ws + l.xbuf);
@@ -842,9 +856,9 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
                 if (duo) HIPCHK(hipMemsetAsync(ws + l.xcc, 0, XCC_WORDS * sizeof(unsigned), stream));      // placement handshake of this launch
                 a.state = (float *)(ws + l.state) + (size_t)r * (sparse ? sparse_state_floats() : chain ? chain_state_floats(pl.G) : loop_state_floats(pl.G));
                 a.t0 = s0; a.t1 = s1; a.cI_t0 = s0; a.rb0 = rb0; a.Btot = nr; a.NG = ngr; a.resume = s0 > 0 ? 1 : 0;
-                a.kind_tag = chain ? 4 : sparse ? 3 : (duo ? 2 : 1);
+                a.kind_tag = chain ? 4 : sparse ? 3 : (duo ? (octo ? 5 : 2) : 1);
                 if ((rc = timer_mark(timer, stream)) != WRNN_OK) return rc;
-                hipError_t e = chain ? launch_chain(a, p->mode, stream) : sparse ? launch_sparse(a, p->sp_nbp, stream) : (duo ? launch_duo(a, pl.ncl, p->mode, stream) : launch_loop(a, pl.ncl, p->mode, stream));
+                hipError_t e = chain ? launch_chain(a, p->mode, stream) : sparse ? launch_sparse(a, p->sp_nbp, stream) : (duo ? (octo ? launch_octo(a, pl.ncl, p->mode, stream) : launch_duo(a, pl.ncl, p->mode, stream)) : launch_loop(a, pl.ncl, p->mode, stream));
                 // (two workgroups per CU not co-resident right now: WRNN_ERR_RESIDENCY -- the caller re-plans with WRNN_ALGO_LOOP, whose
                 // workspace layout is another one: wavernn_amd/engine.py does)
                 if (e != hipSuccess) {

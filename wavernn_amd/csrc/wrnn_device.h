@@ -102,7 +102,7 @@ struct LoopArgs {
     int tab_fps, tab_t0;                // wrnn_duo.hip: c2f / c3f / c4f are per-SEGMENT tables of the slab that starts at step tab_t0: row
                                         // (segment index in the call) * tab_fps + frame - (seg_pos + tab_t0) / hop; zero row = Nall * tab_fps
     unsigned *xcc_tab;                  // [MAXCL * 128] zeroed before every launch: XCC id + 1 of every workgroup (placement handshake)
-    int kind_tag;                       // 1 wrnn_loop_kernel, 2 wrnn_duo_kernel, 3 wrnn_sparse_kernel, 4 wrnn_chain_kernel: recorded in status[8] by the launch that starts a call at step 0,
+    int kind_tag;                       // 1 wrnn_loop_kernel, 2 wrnn_duo_kernel, 3 wrnn_sparse_kernel, 4 wrnn_chain_kernel, 5 wrnn_octo_kernel: recorded in status[8] by the launch that starts a call at step 0,
                                         // checked by every continuing launch (the two kernels keep different state / ring layouts)
 };
 

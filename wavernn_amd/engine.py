@@ -19,7 +19,7 @@ RESUMABLE_KERNELS = ('wrnn_loop_kernel', 'wrnn_duo_kernel', 'wrnn_sparse_kernel'
 #: ... and those that form the last up-sampling stage of the mel themselves (wrnn_options.mel_stage: they take `MelRows`)
 MEL_STAGE_KERNELS = ('wrnn_duo_kernel', 'wrnn_sparse_kernel', 'wrnn_chain_kernel')
 #: what `auto` falls back to when a persistent grid is refused (cooperative launch not co-resident): kernel -> next algo
-FALLBACK_ALGO = {'wrnn_sparse_kernel': 'duo', 'wrnn_chain_kernel': 'duo', 'wrnn_duo_kernel': 'loop'}
+FALLBACK_ALGO = {'wrnn_sparse_kernel': 'duo', 'wrnn_chain_kernel': 'duo', 'wrnn_octo_kernel': 'duo', 'wrnn_duo_kernel': 'loop'}
 
 
 class MelRows:
@@ -255,7 +255,7 @@ class LoopEngine:
         _lib.check(rc, 'wrnn_generate_segments')
         self._launches = (self._launches if t0 > 0 else 0) + int(self._info.launches)
         if t0 == 0:
-            self._slice_algo = {'wrnn_loop_kernel': 'loop', 'wrnn_duo_kernel': 'duo', 'wrnn_sparse_kernel': 'sparse', 'wrnn_chain_kernel': 'chain'}.get((self._info.kernel or b'').decode())
+            self._slice_algo = {'wrnn_loop_kernel': 'loop', 'wrnn_duo_kernel': 'duo', 'wrnn_octo_kernel': 'octo', 'wrnn_sparse_kernel': 'sparse', 'wrnn_chain_kernel': 'chain'}.get((self._info.kernel or b'').decode())
         self._last_opts = (B, T, n_frames, self.options(algo, depth, clusters, slab_steps, cond_valu, None))
         if check:
             rc = self.lib.wrnn_status(self._ws.data_ptr(), stream)      # synchronises the stream: every queued progress call has run
