@@ -79,8 +79,8 @@ namespace wrnn {
 #define DUO_ABLATE 0                          // TIMING EXPERIMENTS ONLY (wrong results): bit 0 = fc stages without their MFMAs, bit 1 = gh stages with one
 #endif                                        // tile of three, bit 2 = hh stages load ONE fragment of eight, bit 3 = gate stages with one tile of three, bit 4 = no GRU
                                               // pointwise math, bit 5 = ih stages load one fragment of eight (register-load variant)
-#ifndef DUO_LP_DEPTH
-#define DUO_LP_DEPTH 6                        // slots in flight from which the ih workgroups fetch a stage's operand INTO LDS one stage ahead (launch_duo; measured: r06l)
+#ifndef DUO_EI_DEPTH
+#define DUO_EI_DEPTH 4                        // slots in flight from which the ih workgroups ISSUE a stage's operand loads in front of the pending back half (launch_duo; measured: r06v)
 #endif
 
 constexpr int DNWGC = 4 * LNJ;               // workgroups per cluster (128)
@@ -161,10 +161,12 @@ struct DuoGeo {
 // A stage starts with the previous stage's back half (publish first: faster or equal at every depth, profiles/r04g_probe_*.json).
 // LP: the stage's operand fragments are fetched INTO LDS one stage ahead (buffer_load ... lds, no register) instead of being loaded into
 // registers behind that back half -- round 6; which one a launch runs: launch_duo.
+// EI (register-load form only): the loads are ISSUED in front of the pending back half -- i.e. in front of its publish stores: vmcnt retires in order, a
+// load issued behind a write-through store waits ~1 us for that store's acknowledgement -- and looked at behind it, as before (round 6).
 // PROF (thread 0, shader clocks per segment of a stage, [gates: 0-7, fc: 8-15]): 0 front issue, 1 barrier wait, 2 back half, 3 operand
 // wait / poll, 4 ring hygiene, 5 MFMA tiles + partial writes, 6 stages, 7 stages whose operand was not there at the first look
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int MODE, bool LA, bool LP, bool PROF>
+template <int MODE, bool LA, bool LP, bool EI, bool PROF>
 __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int cl, const int J, const int ncl, const bool loc_h, const bool loc_y)
 {
     const int G = a.G;
@@ -332,7 +334,8 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         const int sb = cbase + c.i * (MAXCL * DSLOTB) + (c.t & (DRING - 1)) * XTB;
         lds_barrier();
         PHX(cur + 1);
-        publish4l(xrs, sb + L_Y * DLAYERB + J * 1024, tid, fmaxf(get_partial<3>(PB, 0, pu, pj) + c.c0, 0.f), pj < slot_nb(c.i), loc_y);
+        const float yv = fmaxf(get_partial<3>(PB, 0, pu, pj) + c.c0, 0.f);
+        publish4l(xrs, sb + L_Y * DLAYERB + J * 1024, tid, yv, pj < slot_nb(c.i), loc_y);
         PHX(cur + 2);
     };
 
@@ -384,6 +387,11 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
                 PHX(cur + 0);
             }
         }
+        if constexpr (!LP && EI) {
+            const int so0 = sb + (ph == 0 ? L_P0 : L_P2) * DLAYERB;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, so0, 16 /* sc1 */);
+        }
         if constexpr (BK == 1) back_gates(cy);
         if constexpr (BK == 2) back_relu(cy);
         cur = ph == 0 ? 0 : 8;
@@ -392,7 +400,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
         int soff_x;                                     // where the operand fragments come from (for the re-load of a poll)
         if constexpr (ph == 0) {
             soff_x = sb + L_P0 * DLAYERB;
-            if constexpr (!LP) {
+            if constexpr (!LP && !EI) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) x[r] = ((DUO_ABLATE & 32) && r > 0) ? x[0] : __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
             }
@@ -409,7 +417,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
             if (t > T0) nc.gw = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_gh, sbase + (L_GH + (J >> 3)) * DLAYERB + (t & (DGHRING - 1)) * XTB, 16 /* sc1 */);
         } else {
             soff_x = sb + L_P2 * DLAYERB;
-            if constexpr (!LP) {
+            if constexpr (!LP && !EI) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) x[r] = ((DUO_ABLATE & 32) && r > 0) ? x[0] : __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
             }
@@ -1035,7 +1043,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
 
 // Grid = clusters x 128 workgroups of 256 threads (two per CU), cooperative launch.  Whole XCDs per cluster (speed only: nothing
 // depends on the placement; what the placement is, is looked at below).
-template <int MODE, bool LP, bool PROF>
+template <int MODE, bool LP, bool EI, bool PROF>
 __global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1104,10 +1112,10 @@ __global__ __launch_bounds__(NT, 2) void wrnn_duo_kernel(const LoopArgs a)
 #define DUO_ROLES 15                          // (register-allocation diagnosis: compile with a subset of the four roles, -DDUO_ROLES=<mask>)
 #endif
     if (layer == 0) {
-        if (hh == 0) { if constexpr ((DUO_ROLES & 1) != 0) duo_ih<MODE, true, LP, PROF>(a, smem, cl, J, ncl, loc_a, false); }
+        if (hh == 0) { if constexpr ((DUO_ROLES & 1) != 0) duo_ih<MODE, true, LP, EI, PROF>(a, smem, cl, J, ncl, loc_a, false); }
         else { if constexpr ((DUO_ROLES & 2) != 0) duo_hh<MODE, true, LP, PROF>(a, smem, cl, J, ncl, loc_a); }
     } else {
-        if (hh == 0) { if constexpr ((DUO_ROLES & 4) != 0) duo_ih<MODE, false, LP, PROF>(a, smem, cl, J, ncl, loc_b, loc_b); }
+        if (hh == 0) { if constexpr ((DUO_ROLES & 4) != 0) duo_ih<MODE, false, LP, EI, PROF>(a, smem, cl, J, ncl, loc_b, loc_b); }
         else { if constexpr ((DUO_ROLES & 8) != 0) duo_hh<MODE, false, LP, PROF>(a, smem, cl, J, ncl, loc_b); }
     }
 }
@@ -1134,14 +1142,19 @@ hipError_t launch_duo(const LoopArgs &args, int ncl, int mode, hipStream_t strea
 {
     if (ncl < 1 || args.G < 1 || args.G > LMAXG || (mode == 1 && !args.fc3f) || !args.u1 || !args.xcc_tab) return hipErrorInvalidValue;
     const size_t lds = duo_lds_bytes(args.G);
-    // wrnn_options.tuning (A/B switches): bit 0 = operands by register loads, bit 1 = by LDS prefetch (default: by depth); bit 8 = every layer
+    // wrnn_options.tuning (A/B switches): bit 0 = operands by LATE register loads (behind the back half), bit 1 = by LDS prefetch one stage ahead (on request only
+    // since r06v: early register loads beat it at 8 slots); bit 8 = every layer
     // written through (no XCD-local plain stores); bit 6 = placement read-out through the phase-clock buffer; bit 14 (profiling builds):
     // the stage time line ("TRACE")
-    const bool lp = (args.tuning & 2) ? true : ((args.tuning & 1) ? false : args.G >= DUO_LP_DEPTH);
+    // ... bit 9 = register loads issued in front of the pending back half (EI; default from DUO_EI_DEPTH slots in flight on: r06v -- 22.7 vs 22.9 us per
+    // step at 4 slots, 37.4 at 8 against 38.8 with the LDS prefetch and 41.9 with late register loads; 0.1-0.2 us slower below 4)
+    const bool lp = (args.tuning & 2) != 0;
+    const bool ei = !lp && ((args.tuning & 512) ? true : ((args.tuning & 1) ? false : args.G >= DUO_EI_DEPTH));
     const bool prof = mode == 1 && args.prof && !(args.tuning & 64);              // phase clocks: MOL builds only
-    const void *fn = mode == 1 ? (lp ? (prof ? (const void *)wrnn_duo_kernel<1, true, true> : (const void *)wrnn_duo_kernel<1, true, false>)
-                                     : (prof ? (const void *)wrnn_duo_kernel<1, false, true> : (const void *)wrnn_duo_kernel<1, false, false>))
-                               : (lp ? (const void *)wrnn_duo_kernel<0, true, false> : (const void *)wrnn_duo_kernel<0, false, false>);
+    const void *fn = mode == 1 ? (lp ? (prof ? (const void *)wrnn_duo_kernel<1, true, false, true> : (const void *)wrnn_duo_kernel<1, true, false, false>)
+                                : ei ? (prof ? (const void *)wrnn_duo_kernel<1, false, true, true> : (const void *)wrnn_duo_kernel<1, false, true, false>)
+                                     : (prof ? (const void *)wrnn_duo_kernel<1, false, false, true> : (const void *)wrnn_duo_kernel<1, false, false, false>))
+                               : (lp ? (const void *)wrnn_duo_kernel<0, true, false, false> : ei ? (const void *)wrnn_duo_kernel<0, false, true, false> : (const void *)wrnn_duo_kernel<0, false, false, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     LoopArgs a = args;
