@@ -254,6 +254,12 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
     const int mshift = a.hop_shift;
 
     const int locbits = (loc_h ? 1 : 0) | (loc_y ? 2 : 0);                          // by re-arm lane group: h | y | residual sum (never local)
+    // Round 6 (profiles/r06y_sweep.log, r06aa_reprobe.log; A/B: wrnn_options.tuning bit 7 / bit 3 switch them OFF): the residual input word of the owned
+    // unit is requested BEHIND the operand check (beside the operand loads it was the sentinel whenever the layer had not arrived yet, and the back half
+    // then paid a whole round trip for it: 15.4 vs 16.4 us per step at 2 slots), and rnn1 asks for x_{t-1} AGAIN at the top of the stage that runs the
+    // pending back half (22.5 vs 22.8 us at 4 slots).  Also measured, no effect: a static wave priority for the ih workgroups (s_setprio 1 .. 3), the
+    // back halves at priority 3; the hh workgroups at a higher priority cost 4.5 %.
+    const bool late_xo = (a.tuning & 128) == 0, reprobe = (a.tuning & 8) == 0;
     bool dead = false;
     int pp = 0;
     int t = T0;
@@ -268,6 +274,9 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
     };
     Carry cy;
     cy.c0 = cy.c1 = cy.c2 = 0.f; cy.gw = u32x4{0u, 0u, 0u, 0u}; cy.xo = cy.xt = 0u; cy.i = 0; cy.pp = 0; cy.t = T0;
+    // (Round 6, measured and dropped -- profiles/r06ab_defer.log: rnn1's gates back half DEFERRED behind the next gate stage's front when its x_{t-1} was
+    // not there -- wave 0 deciding for the workgroup through a word in LDS -- instead of waited for: 15.5 vs 16.4 us per step at 2 slots, but 23.8 vs
+    // 23.5 at 4 and 42.7 vs 41.4 at 8, and the code alone cost 0.7 us at 4 slots and 3 us at 8 against the kernel without it.)
 
     auto slot_nb = [&](int i) -> int { return (int)((nbpack >> (8 * i)) & 255u); };
 
@@ -387,6 +396,12 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
                 PHX(cur + 0);
             }
         }
+        if constexpr (LA && BK == 1) {
+            // the pending gates back half needs x_{t-1} of its slot: the word requested in ITS front is ~one MFMA block old -- ask again now, under the
+            // barrier and the partial sums, instead of finding the stale sentinel behind them and paying a whole round trip there
+            if (reprobe && cy.t > T0)
+                cy.xt = __builtin_amdgcn_raw_buffer_load_b32(xrs, pj * 4, cbase + cy.i * (MAXCL * DSLOTB) + 7 * DLAYERB + ((cy.t - 1) & (DRING - 1)) * XTB, 16 /* sc1 */);
+        }
         if constexpr (!LP && EI) {
             const int so0 = sb + (ph == 0 ? L_P0 : L_P2) * DLAYERB;
 #pragma unroll
@@ -404,7 +419,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
 #pragma unroll
                 for (int r = 0; r < 8; ++r) x[r] = ((DUO_ABLATE & 32) && r > 0) ? x[0] : __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
             }
-            nc.xo = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, soff_x, 16 /* sc1 */);
+            if (!late_xo) nc.xo = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, soff_x, 16 /* sc1 */);
             if constexpr (LA) {
                 if (t > T0) nc.xt = __builtin_amdgcn_raw_buffer_load_b32(xrs, pj * 4, sbase + 7 * DLAYERB + ((t - 1) & (DRING - 1)) * XTB, 16 /* sc1 */);
             } else {
@@ -439,6 +454,7 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
                          status, dead, 0x500u | (LA ? 0u : 8u) | (unsigned)ph, t);
         }
         PHX(cur + 3);
+        if (ph == 0 && late_xo) nc.xo = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, soff_x, 16 /* sc1 */);      // (this wave's quarter is there: the other waves' usually too)
         if (ph == 0 && i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ring hygiene: last step's re-arm stores are out before anything of this step is published
         if (ph == 2 && i == nact - 1) {
             // ring hygiene, once per step, after the last layer this workgroup polls in the step has arrived (see the header): re-arm this
@@ -485,6 +501,9 @@ __device__ __forceinline__ void duo_ih(const LoopArgs &a, float *smem, const int
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
+    // (Round 6, measured and dropped -- profiles/r06z_lag.log: the fc stage of slot k interleaved `lag` gate stages behind its gate stage, g0 g1 f0 g2 f1 ..:
+    // 25.4 us per step at 4 slots with lag 2, 23.6 with lag 3 against 23.8 for this order in the same build; that build took the kind of the pending
+    // back half as a run-time value -- two call sites instead of five -- which alone cost 1.1 us per step at 4 slots and 4 us at 8.)
     for (; t < T1; ++t) {
         if (t == T0) stage(I0{}, I0{}, 0);
         else stage(I0{}, I2{}, 0);
@@ -624,6 +643,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     const int cbase = cl * DSLOTB;
     auto slot_nb = [&](int i) -> int { return (int)((nbpack >> (8 * i)) & 255u); };
 
+    const bool prio_smp = (a.tuning & 32) == 0;          // the sampling stage (on its slot's chain) runs at wave priority 3 (round 6: 16.1 vs 16.4 us per step at 2 slots, 22.56 vs 22.72 at 4; A/B: tuning bit 5 = off)
     bool dead = false;
     int pp = 0;
     int t = T0;
@@ -687,6 +707,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xv), xrs, su * 4, cbase + bi * (MAXCL * DSLOTB) + 7 * DLAYERB + (bt & (DRING - 1)) * XTB, 16 /* sc1 */);
             }
         }
+        if (prio_smp) __builtin_amdgcn_s_setprio(0);
         PHX(cur + 2);
     };
     // ---------------- rnn1: cI(tt) of the owned 16 rows, slots w, w + 4 by wave w (no barrier: a wave forms, publishes and later re-arms its own slots)
@@ -759,6 +780,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         run_back();                                     // (publish first: profiles/r04g_probe_*.json)
         cur = kind == 1 ? 0 : 8;
         tri = i;
+        if (kind == 3 && prio_smp) __builtin_amdgcn_s_setprio(3);
 
         if (!xahead) {
 #pragma unroll
