@@ -176,6 +176,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
 
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.xbuf, (unsigned)(DXBUF_FLOATS * 4));
     const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.c2f, 0x7FFFF000u);
+    const __amdgpu_buffer_rsrc_t nrs = make_rsrc(noise_pre, 0x7FFFF000u);
     const __amdgpu_buffer_rsrc_t f1rs = make_rsrc(a.c3f, 0x7FFFF000u), f2rs = make_rsrc(a.c4f, 0x7FFFF000u);
     const int voff_frag = frag_off(w, 0, lane) * 4;      // this lane's first fragment of a layer (bytes)
     const int voff_own = (((J * 64) + 16 * w + pj) * 4 + (tid & 3)) * 4;      // the layer word of (unit 16 J + pu, segment pj) = its publish position
@@ -190,9 +191,10 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
 
     // one stage: the layer at byte offset `so` -> three (NTL = 3) or one tile(s) of this workgroup x the slot's 16 segments; the sums of the
     // thread's (unit, segment) come back in s0..s2, `ownw` = the thread's own word of that layer (the residual input of the gate stages)
-    auto stage = [&](auto NTC, const float (&A0)[AF], const float (&A1)[AF], const float (&A2)[AF], int so, int nb, unsigned code, int ts, int px_wait,
+    auto stage = [&](auto NTC, auto AGC, const float (&A0)[AF], const float (&A1)[AF], const float (&A2)[AF], int so, int nb, unsigned code, int ts, int px_wait,
                      float &s0, float &s1, float &s2, unsigned &ownw, bool want_own) {
         constexpr int NTL = decltype(NTC)::value;
+        constexpr bool AG = decltype(AGC)::value != 0;  // the tiles live in AGPRs (wrnn_ring.h: mfma3s_ag)
         const bool live = fi < nb, plive = pj < nb;
         u32x4 x[8];
 #pragma unroll
@@ -203,6 +205,10 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
                      [&] {
 #pragma unroll
                          for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, so, 16 /* sc1 */);
+                         // (the own word with every re-load: asked for once, beside the FIRST look, it is the sentinel whenever the layer is waited for, and the
+                         // poll below then cost a whole round trip behind the arrival: 10.5 -> 9.75 us per step for one utterance, profiles/r06af_chain_ab.log.
+                         // Measured with it, no gain: TWO requests in flight half a round trip apart -- 9.76 vs 9.74; 15.7 vs 14.3 with two slots.)
+                         if (want_own) ownw = __builtin_amdgcn_raw_buffer_load_b32(xrs, voff_own, so, 16 /* sc1 */);
                      },
                      status, dead, code, ts);
         if (want_own && __builtin_expect(__any(plive && ownw == SENT), 0))
@@ -214,11 +220,13 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
         float *PW = PART + pp * (NW * 3 * 256);
         if constexpr (NTL == 3) {
             f32x4 o0, o1, o2;
-            mfma3s(A0, A1, A2, b, o0, o1, o2);
+            if constexpr (AG) mfma3s_ag(A0, A1, A2, b, o0, o1, o2);
+            else mfma3s(A0, A1, A2, b, o0, o1, o2);
             put_partial<3>(PW, w, 0, lane, o0);
             put_partial<3>(PW, w, 1, lane, o1);
             put_partial<3>(PW, w, 2, lane, o2);
-        } else put_partial<3>(PW, w, 0, lane, mfma1(A0, b));
+        } else if constexpr (AG) put_partial<3>(PW, w, 0, lane, mfma1_ag(A0, b));
+        else put_partial<3>(PW, w, 0, lane, mfma1(A0, b));
         lds_barrier();
         s0 = get_partial<3>(PW, 0, pu, pj);
         if constexpr (NTL == 3) { s1 = get_partial<3>(PW, 1, pu, pj); s2 = get_partial<3>(PW, 2, pu, pj); }
@@ -226,6 +234,8 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
     };
     using N1 = std::integral_constant<int, 1>;
     using N3 = std::integral_constant<int, 3>;
+    using VG = std::integral_constant<int, 0>;          // weight tiles in VGPRs: W_ih, fc1 (128 registers) | in AGPRs: W_hh, fc2 / RAW's fc3 rows (128)
+    using AGR = std::integral_constant<int, 1>;
     // re-arm this wave's quarter of the workgroup's 1 KB block of `layer` of slot i in entry (t + 2) % 4 (lanes 16 q .. 16 q + 15)
     auto rearm1 = [&](int i, int layer, int q, bool local) {
         if (kq == q) {
@@ -243,7 +253,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             const float cv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(f1rs, (fr * H + prow) * 4, 0, 0));
             float s0, s1, s2;
             unsigned dummy = 0u;
-            stage(N1{}, A_fc1, A_fc1, A_fc1, sb + 6 * DLAYERB, nb, 0x801u, t, 2, s0, s1, s2, dummy, false);
+            stage(N1{}, VG{}, A_fc1, A_fc1, A_fc1, sb + 6 * DLAYERB, nb, 0x801u, t, 2, s0, s1, s2, dummy, false);
             publish4l(xrs, sb + 2 * DLAYERB + J * 1024, tid, fmaxf(s0 + cv, 0.f), pj < nb, loc_y1);
             CHX(3);
         }
@@ -252,7 +262,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
     auto gh_stage = [&](int i) {
         float s0, s1, s2;
         unsigned dummy = 0u;
-        stage(N3{}, A_hh[0], A_hh[1], A_hh[2], cbase_of(i) + (LA ? 0 : 1) * DLAYERB + (t & (DRING - 1)) * XTB, nb_of(i), 0x840u | (LA ? 0u : 8u), t, LA ? 2 : 6, s0, s1, s2,
+        stage(N3{}, AGR{}, A_hh[0], A_hh[1], A_hh[2], cbase_of(i) + (LA ? 0 : 1) * DLAYERB + (t & (DRING - 1)) * XTB, nb_of(i), 0x840u | (LA ? 0u : 8u), t, LA ? 2 : 6, s0, s1, s2,
               dummy, false);
         ST[(i * 8 + 1) * NT + tid] = s0 + bh_r; ST[(i * 8 + 2) * NT + tid] = s1 + bh_z; ST[(i * 8 + 3) * NT + tid] = s2 + bh_n;
         CHX(LA ? 3 : 7);
@@ -282,7 +292,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
         auto front = [&](int i, int ts) {               // W_ih1 . cI(ts) of slot i + the thread's own cI word (xi - w0 x)
             unsigned ow = 0u;
             float s0, s1, s2;
-            stage(N3{}, A_ih[0], A_ih[1], A_ih[2], cbase_of(i) + 4 * DLAYERB + (ts & (DRING - 1)) * XTB, nb_of(i), 0x820u, ts, 4, s0, s1, s2, ow, true);
+            stage(N3{}, VG{}, A_ih[0], A_ih[1], A_ih[2], cbase_of(i) + 4 * DLAYERB + (ts & (DRING - 1)) * XTB, nb_of(i), 0x820u, ts, 4, s0, s1, s2, ow, true);
             ST[(i * 8 + 4) * NT + tid] = s0; ST[(i * 8 + 5) * NT + tid] = s1; ST[(i * 8 + 6) * NT + tid] = s2; ST[(i * 8 + 7) * NT + tid] = __uint_as_float(ow);
             CHX(5);
         };
@@ -320,14 +330,16 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             const int nb = nb_of(i), b0g = GEO[2 * i], cb = cbase_of(i);
             const bool live = fi < nb, plive = pj < nb;
             const int sb = cb + (t & (DRING - 1)) * XTB;
+            // (the step's noise FIRST -- in front of the y2 requests and of every re-load of the poll: behind them the two words came back from L2 / HBM
+            // on the slot's chain -- round 6)
+            const int su = tid >> 4, sm = tid & 15;     // sampling role: 16-lane row = segment su, lane sm = mixture
+            const int suc = su < nb ? su : nb - 1;
+            const int nvo = (int)(((size_t)(t - noise_t0) * 11 * Nall) * 4);
+            const float nz0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(nrs, ((b0g + suc) * 10 + (sm < 10 ? sm : 9)) * 4, nvo, 0));
+            const float nz1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(nrs, (10 * Nall + b0g + suc) * 4, nvo, 0));
             u32x4 x[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 3 * DLAYERB, 16 /* sc1 */);
-            const int su = tid >> 4, sm = tid & 15;     // sampling role: 16-lane row = segment su, lane sm = mixture
-            const float *nrow = noise_pre + (size_t)(t - noise_t0) * 11 * Nall;
-            const int suc = su < nb ? su : nb - 1;
-            const float nz0 = nrow[(size_t)(b0g + suc) * 10 + (sm < 10 ? sm : 9)];
-            const float nz1 = nrow[(size_t)10 * Nall + b0g + suc];
             if (__builtin_expect(!frag_there(x, live), 0))
                 wait_for([&] { return frag_there(x, live); },
                          [&] {
@@ -371,7 +383,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             const int nb = nb_of(i), sb = cbase_of(i) + (t & (DRING - 1)) * XTB;
             float s0, s1, s2;
             unsigned dummy = 0u;
-            stage(N1{}, A_f3, A_f3, A_f3, sb + 3 * DLAYERB, nb, 0x851u, t, 7, s0, s1, s2, dummy, false);
+            stage(N1{}, AGR{}, A_f3, A_f3, A_f3, sb + 3 * DLAYERB, nb, 0x851u, t, 7, s0, s1, s2, dummy, false);
             publish4l(xrs, sb + 16 * DLAYERB + J * 1024, tid, s0 + b3, pj < nb, loc_a);
             CHX(8);
         };
@@ -538,7 +550,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             const float c2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, vo, 2 * H * 4, 0));
             unsigned ow = 0u;
             float s0, s1, s2;
-            stage(N3{}, A_ih[0], A_ih[1], A_ih[2], sb + 5 * DLAYERB, nb, 0x828u, t, 0, s0, s1, s2, ow, true);
+            stage(N3{}, VG{}, A_ih[0], A_ih[1], A_ih[2], sb + 5 * DLAYERB, nb, 0x828u, t, 0, s0, s1, s2, ow, true);
             const float h = MOL ? gru_update_fast(s0 + c0, s1 + c1, s2 + c2, ST[(i * 8 + 1) * NT + tid], ST[(i * 8 + 2) * NT + tid], ST[(i * 8 + 3) * NT + tid], ST[(i * 8 + 0) * NT + tid])
                                 : gru_update(s0 + c0, s1 + c1, s2 + c2, ST[(i * 8 + 1) * NT + tid], ST[(i * 8 + 2) * NT + tid], ST[(i * 8 + 3) * NT + tid], ST[(i * 8 + 0) * NT + tid]);
             ST[(i * 8 + 0) * NT + tid] = h;
@@ -552,7 +564,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             const float cv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(f2rs, (fr * H + prow) * 4, 0, 0));
             float s0, s1, s2;
             unsigned dummy = 0u;
-            stage(N1{}, A_fc2, A_fc2, A_fc2, sb + 2 * DLAYERB, nb, 0x802u, t, 4, s0, s1, s2, dummy, false);
+            stage(N1{}, AGR{}, A_fc2, A_fc2, A_fc2, sb + 2 * DLAYERB, nb, 0x802u, t, 4, s0, s1, s2, dummy, false);
             publish4l(xrs, sb + 3 * DLAYERB + J * 1024, tid, fmaxf(s0 + cv, 0.f), pj < nb, false);
             // ring hygiene: behind the last poll of the slot's step (y1(t): everybody is past the readers of step t - 2) and behind the publication
             rearm1(i, 1, 0, loc_b);

@@ -436,4 +436,49 @@ __device__ __forceinline__ void mfma3s(const float (&a0)[AF], const float (&a1)[
     o0 = c0; o1 = c1; o2 = c2;
 }
 
+// ---- the same tiles with the WEIGHT operand read from the accumulation registers (round 6) -----------------------------------------------
+// A one-workgroup-per-CU kernel (wrnn_chain.hip, wrnn_sparse.hip: 512 registers per lane) holds more weight registers than the 256 architectural
+// VGPRs.  Left to itself the allocator keeps the surplus in AGPRs AS SPILL SLOTS: every stage began with ~230 v_accvgpr_read / _write copies of the
+// tiles it was about to multiply -- on the slot's chain (2,000 such copies in either kernel).  gfx950's MFMA reads srcA from either half of the
+// register file, so the tiles named here are CONSTRAINED to AGPRs ("a") and used in place; same products, same order: bit-identical results.
+// The hazard recogniser does not see through inline assembly: a block ends with 24 wait states before its accumulators are read (an 8-pass
+// XDL write needs <= 19); consecutive MFMAs on one accumulator are >= 2 issue slots apart as in the builtin forms.
+__device__ __forceinline__ void mfma_ag(f32x4 &c, float a, float b) { asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "a"(a), "v"(b)); }
+// (the first product of a chain takes the constant 0 as srcC, as the builtin form does: a zeroed register read by the very next instruction is a
+// VALU-write -> MFMA-read the hazard recogniser cannot pad inside inline assembly)
+__device__ __forceinline__ f32x4 mfma_ag0(float a, float b)
+{
+    f32x4 c;
+    asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(c) : "a"(a), "v"(b));
+    return c;
+}
+__device__ __forceinline__ void mfma3s_ag(const float (&a0)[AF], const float (&a1)[AF], const float (&a2)[AF], const float (&b)[32], f32x4 &o0, f32x4 &o1, f32x4 &o2)
+{
+    f32x4 c0 = mfma_ag0(a0[0], b[0]), c1 = mfma_ag0(a1[0], b[0]), c2 = mfma_ag0(a2[0], b[0]);
+#pragma unroll
+    for (int k = 1; k < 32; ++k) {
+        mfma_ag(c0, a0[k], b[k]);
+        mfma_ag(c1, a1[k], b[k]);
+        mfma_ag(c2, a2[k], b[k]);
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c0), "+v"(c1), "+v"(c2));
+    o0 = c0; o1 = c1; o2 = c2;
+}
+__device__ __forceinline__ f32x4 mfma1_ag(const float (&a)[AF], const float (&b)[32])
+{
+    f32x4 c0 = mfma_ag0(a[0], b[0]), c1 = mfma_ag0(a[4], b[4]);
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (r + e > 0) {
+                mfma_ag(c0, a[4 * r + e], b[4 * r + e]);
+                mfma_ag(c1, a[4 * r + 4 + e], b[4 * r + 4 + e]);
+            }
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c0), "+v"(c1));
+    return c0 + c1;
+}
+
 }  // namespace wrnn
