@@ -112,16 +112,19 @@ __device__ __forceinline__ bool gather_there(const unsigned (&v)[3][MPW], unsign
         for (int i = 0; i < MPW; ++i) m = max(m, v[g][i]);
     return __all(m != SENT || !live);
 }
+// (round 6: the tile values are CONSTRAINED to AGPRs and read in place -- wrnn_ring.h, mfma_ag: the allocator used the AGPRs as spill slots and copied the
+// tiles of every stage into VGPRs first, 2,045 v_accvgpr moves in this kernel, most of them on the cluster's chain; same products, same order)
 template <int MPW>
 __device__ __forceinline__ void gate_mfma(const GateTiles<MPW> &gt, const unsigned (&v)[3][MPW], f32x4 &o0, f32x4 &o1, f32x4 &o2)
 {
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
+    f32x4 c0 = mfma_ag0(gt.a[0][0], __uint_as_float(v[0][0])), c1 = mfma_ag0(gt.a[1][0], __uint_as_float(v[1][0])), c2 = mfma_ag0(gt.a[2][0], __uint_as_float(v[2][0]));
 #pragma unroll
-    for (int i = 0; i < MPW; ++i) {                          // three independent chains interleaved (96 cycles between dependent MFMAs)
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gt.a[0][i], __uint_as_float(v[0][i]), c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gt.a[1][i], __uint_as_float(v[1][i]), c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gt.a[2][i], __uint_as_float(v[2][i]), c2, 0, 0, 0);
+    for (int i = 1; i < MPW; ++i) {                          // three independent chains interleaved (96 cycles between dependent MFMAs)
+        mfma_ag(c0, gt.a[0][i], __uint_as_float(v[0][i]));
+        mfma_ag(c1, gt.a[1][i], __uint_as_float(v[1][i]));
+        mfma_ag(c2, gt.a[2][i], __uint_as_float(v[2][i]));
     }
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c0), "+v"(c1), "+v"(c2));
     o0 = c0; o1 = c1; o2 = c2;
 }
 
@@ -139,17 +142,20 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // two fc row tiles that share the activation operand (B fragments in registers); per tile mfma1's order (two chains by k-block parity)
 __device__ __forceinline__ void mfma2(const float (&a0)[AF], const float (&a1)[AF], const float (&b)[32], f32x4 &o0, f32x4 &o1)
 {
-    f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
+    f32x4 c00 = mfma_ag0(a0[0], b[0]), c10 = mfma_ag0(a1[0], b[0]), c01 = mfma_ag0(a0[4], b[4]), c11 = mfma_ag0(a1[4], b[4]);
 #pragma unroll
     for (int r = 0; r < 8; r += 2) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + e], b[4 * r + e], c00, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + e], b[4 * r + e], c10, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * r + 4 + e], b[4 * r + 4 + e], c01, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * r + 4 + e], b[4 * r + 4 + e], c11, 0, 0, 0);
+            if (r + e > 0) {
+                mfma_ag(c00, a0[4 * r + e], b[4 * r + e]);
+                mfma_ag(c10, a1[4 * r + e], b[4 * r + e]);
+                mfma_ag(c01, a0[4 * r + 4 + e], b[4 * r + 4 + e]);
+                mfma_ag(c11, a1[4 * r + 4 + e], b[4 * r + 4 + e]);
+            }
         }
     }
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c00), "+v"(c10), "+v"(c01), "+v"(c11));
     o0 = c00 + c01;
     o1 = c10 + c11;
 }
