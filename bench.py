@@ -168,6 +168,7 @@ def main():
     ap.add_argument('--no-single', action='store_true', help="skip the single-utterance generate() entries (BASELINE config 2's N=481 / N=1001)")
     ap.add_argument('--prune', type=float, default=0.0,
                     help='BASELINE config 5: block-prune the GRU matrices (16x1 blocks) to this sparsity, e.g. 0.95')
+    ap.add_argument('--prune-linear', action='store_true', help='... and fc1 / fc2 with them, as the reference\'s pruning notebook prunes its Linear layer (the gathered fc stages of wrnn_sparse_kernel)')
     ap.add_argument('--parity-noise', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -222,7 +223,7 @@ def main():
     sd = random_state_dict(0, mode=mode)
     if args.prune > 0:
         from wavernn_amd.prune import block_prune_state_dict
-        sd, _ = block_prune_state_dict(sd, args.prune, (16, 1))
+        sd, _ = block_prune_state_dict(sd, args.prune, (16, 1), linear=args.prune_linear)
     model = WaveRNN(**SHIPPED, mode=mode)
     model.num_params = lambda *a, **k: 0
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
@@ -636,11 +637,18 @@ def main():
             except Exception as e:
                 res['config']['raw']['single_utterance'] = {'error': repr(e)}
             from wavernn_amd.prune import block_prune_state_dict
-            res['config']['config5'] = side_config(block_prune_state_dict(random_state_dict(0, mode='MOL'), 0.95, (16, 1))[0], 'MOL',
-                                                   'BASELINE config 5: GRU matrices 95 % block-sparse (16x1 blocks) on the same batch, `auto` kernel '
-                                                   '(wrnn_sparse_kernel: 16 clusters of 16 CUs, one group of 16 segments each)')
+            # BASELINE config 5 = "the Pruning notebook config": the notebook prunes `[self.rnn, self.fc]` (Pruning - Scratchpad.ipynb :199-204) -- GRU matrices
+            # AND Linear layers; `config5_gru_only` is rounds 1-5's pack (fc1 / fc2 dense)
+            res['config']['config5'] = side_config(block_prune_state_dict(random_state_dict(0, mode='MOL'), 0.95, (16, 1), linear=True)[0], 'MOL',
+                                                   'BASELINE config 5: GRU matrices AND fc1 / fc2 95 % block-sparse (16x1 blocks; the pruning notebook prunes the Linear '
+                                                   'layers with the GRUs) on the same batch, `auto` kernel (wrnn_sparse_kernel: 16 clusters of 16 CUs, one group of 16 '
+                                                   'segments each, gathered gate AND fc stages)')
             if 'samples_per_s' in res['config']['config5']:
                 res['config']['config5']['vs_dense_value'] = round(res['config']['config5']['samples_per_s'] / value, 3)
+            res['config']['config5_gru_only'] = side_config(block_prune_state_dict(random_state_dict(0, mode='MOL'), 0.95, (16, 1))[0], 'MOL',
+                                                            'config 5 with ONLY the GRU matrices pruned (rounds 1-5): dense fc1 / fc2 stages on the cluster\'s chain')
+            if 'samples_per_s' in res['config']['config5_gru_only']:
+                res['config']['config5_gru_only']['vs_dense_value'] = round(res['config']['config5_gru_only']['samples_per_s'] / value, 3)
             res['config']['config5_dense_kernel'] = side_config(block_prune_state_dict(random_state_dict(0, mode='MOL'), 0.95, (16, 1))[0], 'MOL',
                                                                 'BASELINE config 5 on the DENSE wrnn_duo_kernel (algo = duo: the pruned weights as masked dense matrices)', algo2='duo')
         if not args.no_cpu_baseline and world == 1:

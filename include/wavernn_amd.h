@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define WRNN_ABI_VERSION 8   /* v8 (round 6): WRNN_ALGO_OCTO (wrnn_octo_kernel: one 512-thread workgroup per CU, matrix waves + service waves; dense MOL).  v7 (round 5): WRNN_ALGO_CHAIN (wrnn_chain_kernel, what `auto` runs for <= 128 segments of a dense model, MOL or 9-bit RAW); WRNN_ALGO_SPARSE is the rebuilt wrnn_sparse_kernel (slabbed, resumable, takes mel_stage) and what `auto` picks for a qualifying pack; wrnn_options.depth does not apply to it.  v6 (round 4): wrnn_options.mel_stage & co + wrnn_pre_upsample_rows -- the last up-sampling stage formed inside wrnn_duo_kernel.  v5 (round 4): WRNN_ALGO_DUO runs RAW too; `auto` never degrades inside the library (WRNN_ERR_RESIDENCY: the caller re-plans); tuning bits per kernel */
+#define WRNN_ABI_VERSION 9   /* v9 (round 6): wrnn_pack_sparse_fc_blocks -- block-sparse Linear layers in wrnn_sparse_kernel.  v8 (round 6): WRNN_ALGO_OCTO (wrnn_octo_kernel: one 512-thread workgroup per CU, matrix waves + service waves; dense MOL).  v7 (round 5): WRNN_ALGO_CHAIN (wrnn_chain_kernel, what `auto` runs for <= 128 segments of a dense model, MOL or 9-bit RAW); WRNN_ALGO_SPARSE is the rebuilt wrnn_sparse_kernel (slabbed, resumable, takes mel_stage) and what `auto` picks for a qualifying pack; wrnn_options.depth does not apply to it.  v6 (round 4): wrnn_options.mel_stage & co + wrnn_pre_upsample_rows -- the last up-sampling stage formed inside wrnn_duo_kernel.  v5 (round 4): WRNN_ALGO_DUO runs RAW too; `auto` never degrades inside the library (WRNN_ERR_RESIDENCY: the caller re-plans); tuning bits per kernel */
 
 enum {
     WRNN_OK = 0,
@@ -196,6 +196,10 @@ size_t wrnn_pack_weight_bytes(const wrnn_pack *p);
 /* block sparsity of the pack's GRU matrices: the largest number of non-zero 16x1 blocks in any (matrix, gate, 16-row) block
  * row -- positive when WRNN_ALGO_SPARSE can run this pack (<= 64, MOL), negated when it cannot */
 int wrnn_pack_sparse_blocks(const wrnn_pack *p);
+/* (v9) the same figure for fc1 / fc2 (their first H columns; 32 block rows of 16 each): positive when the Linear layers are block-sparse
+ * too -- the reference's pruning recipe prunes them with the GRUs, notebooks/"Pruning - Scratchpad.ipynb":199-204 -- and
+ * wrnn_sparse_kernel runs its GATHERED fc stages (no dense fc1 / fc2 MFMA blocks on the chain); negated: dense fc stages */
+int wrnn_pack_sparse_fc_blocks(const wrnn_pack *p);
 
 /* Workspace (device bytes) wrnn_generate needs for this geometry under these options (NULL = defaults).  With the loop
  * kernel it does not grow with T: conditioning is produced in slabs (942 segments x 12,100 steps: < 1 GB). */

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--T', type=int, default=1500)
 ap.add_argument('--mode', default='MOL')
 ap.add_argument('--prune', type=float, default=0.0, help='block-prune the GRU matrices to this sparsity (config 5)')
+ap.add_argument('--prune-linear', action='store_true', help='... and fc1 / fc2 (the notebook prunes the Linear layers too): the gathered fc stages')
 ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'probe.json'))
 ap.add_argument('--B', default='12,24,64,128,192,256,512')
 ap.add_argument('--variants', default='auto,g1,g2,g4,g8')
@@ -30,7 +31,7 @@ mode, T, hop = args.mode, args.T, 275
 sd = random_state_dict(0, mode=mode)
 if args.prune > 0:
     from wavernn_amd.prune import block_prune_state_dict
-    sd, _ = block_prune_state_dict(sd, args.prune, (16, 1))
+    sd, _ = block_prune_state_dict(sd, args.prune, (16, 1), linear=args.prune_linear)
 eng = LoopEngine(sd, mode, device=dev)
 rs = np.random.RandomState(3)
 #: name -> wrnn_options (LoopEngine.run keyword arguments)

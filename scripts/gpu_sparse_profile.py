@@ -11,10 +11,10 @@ from wavernn_amd.prune import block_prune_state_dict
 from wavernn_amd.synthetic import random_state_dict
 ap = argparse.ArgumentParser()
 ap.add_argument('--B', type=int, default=256); ap.add_argument('--T', type=int, default=1200); ap.add_argument('--tuning', type=int, default=0)
-ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'sparse_phase_clocks.json'))
+ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'sparse_phase_clocks.json')); ap.add_argument('--linear', action='store_true')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
-sd, _ = block_prune_state_dict(random_state_dict(0, mode='MOL'), 0.95, (16, 1))
+sd, _ = block_prune_state_dict(random_state_dict(0, mode='MOL'), 0.95, (16, 1), linear=a.linear)
 eng = LoopEngine(sd, 'MOL', device=dev)
 rs = np.random.RandomState(3)
 hop, stride = 275, 64

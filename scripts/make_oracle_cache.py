@@ -19,6 +19,7 @@ SETS = {
     'raw64': [dict(mode='RAW', wseed=0, prune=0.0, mel_seed=1234 + u, noise_seed=77 + u, frames=641) for u in range(64)],
     'mol16': [dict(mode='MOL', wseed=0, prune=0.0, mel_seed=1234 + u, noise_seed=77 + u, frames=641) for u in range(16)],
     'sparse16': [dict(mode='MOL', wseed=0, prune=0.95, mel_seed=1234 + u, noise_seed=77 + u, frames=641) for u in range(16)],
+    'sparse16L': [dict(mode='MOL', wseed=0, prune=0.95, linear=True, mel_seed=1234 + u, noise_seed=77 + u, frames=641) for u in range(16)],
 }
 
 if __name__ == '__main__':

@@ -124,25 +124,25 @@ def _oracle_src_sha():
     return h.hexdigest()[:12]
 
 
-def pruned_state_dict(mode, wseed, prune):
+def pruned_state_dict(mode, wseed, prune, linear=False):
     from wavernn_amd.synthetic import random_state_dict
     sd = random_state_dict(wseed, mode=mode)
     if prune > 0:
         from wavernn_amd.prune import block_prune_state_dict
-        sd, _ = block_prune_state_dict(sd, prune, (16, 1))
+        sd, _ = block_prune_state_dict(sd, prune, (16, 1), linear=linear)
     return sd
 
 
-def oracle_utterance(mode, wseed, prune, mel_seed, noise_seed, frames, target=11000, overlap=550, nthreads=8, want_cond=True, sd=None):
+def oracle_utterance(mode, wseed, prune, mel_seed, noise_seed, frames, target=11000, overlap=550, nthreads=8, want_cond=True, sd=None, linear=False):
     """The C oracle's loop output for ONE utterance generated the reference's way (random mel `mel_seed` of `frames` frames, weights
     `random_state_dict(wseed)` block-pruned to `prune`, batched fold, `torch.manual_seed(noise_seed)` noise stream): dict(ref = [B, T]
     float32 -- RAW: 2 idx / (C - 1) - 1 --, and with want_cond the oracle-side conditioning: mels_up [L, 80], aux [frames, 128], noise in
     the launch layout).  `ref` comes from tests/_cache when an entry made by the same oracle sources exists."""
     from oracle import c_oracle as C, wavernn_oracle as O
     from wavernn_amd.synthetic import random_mel
-    key = f'{mode}_w{wseed}_p{int(round(prune * 1000))}_m{mel_seed}_n{noise_seed}_f{frames}_t{target}_o{overlap}_{_oracle_src_sha()}'
+    key = f'{mode}_w{wseed}_p{int(round(prune * 1000))}{"L" if linear else ""}_m{mel_seed}_n{noise_seed}_f{frames}_t{target}_o{overlap}_{_oracle_src_sha()}'
     path = os.path.join(CACHE, key + '.npz')
-    sd = pruned_state_dict(mode, wseed, prune) if sd is None else sd
+    sd = pruned_state_dict(mode, wseed, prune, linear) if sd is None else sd
     mel = random_mel(mel_seed, frames)
     res = {}
     ref = None

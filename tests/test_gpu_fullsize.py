@@ -265,8 +265,10 @@ def test_block_sparse_kernel_full_length_matches_oracle(gpu):
             assert np.abs(got - ref).max() <= MOL_TOL, (algo, u, np.abs(got - ref).max())
 
 
-def test_config5_256_segments_matches_oracle(gpu):
-    """BASELINE config 5 AS BENCHMARKED (`bench.py` `config.config5`): the GRU matrices 95 % block-sparse (16x1 blocks), 16 x 641-frame
+@pytest.mark.parametrize('linear', [True, False], ids=['gru+linear', 'gru'])
+def test_config5_256_segments_matches_oracle(gpu, linear):
+    """(`linear`: fc1 / fc2 pruned with the GRUs, the notebook's recipe = `config.config5` since round 6 -- the gathered fc stages; else `config5_gru_only`.)
+    BASELINE config 5 AS BENCHMARKED (`bench.py` `config.config5`): the GRU matrices 95 % block-sparse (16x1 blocks), 16 x 641-frame
     utterances = 256 segments x 12,100 steps through `generate_corpus` -- HIP pre-loop kernels, the last up-sampling stage formed inside
     the loop (wrnn_options.mel_stage = 1), `algo = auto` -> wrnn_sparse_kernel: all 16 clusters, one group each, one round --, parity
     noise, against the C oracle on the masked dense weights per utterance (round-4 verdict: 256 segments, was 32).  The loop's
@@ -274,7 +276,7 @@ def test_config5_256_segments_matches_oracle(gpu):
     from helpers import oracle_utterance, pruned_state_dict
     from wavernn_amd.batch import generate_corpus
     from wavernn_amd.synthetic import random_mel
-    sd = pruned_state_dict('MOL', 0, 0.95)
+    sd = pruned_state_dict('MOL', 0, 0.95, linear)
     model = _model(sd, 'MOL', gpu)
     NU = 16
     mels = [torch.from_numpy(random_mel(1234 + u, 641)).unsqueeze(0) for u in range(NU)]
@@ -284,10 +286,11 @@ def test_config5_256_segments_matches_oracle(gpu):
     print(f'config 5: {info} {eng.last_loop_ms():.1f} ms')
     assert plan.n_segments == 256 and plan.T == 12100
     assert info['kernel'] == 'wrnn_sparse_kernel' and (info['clusters'], info['depth'], info['rounds']) == (16, 1, 1)
+    assert (eng.sparse_fc_blocks > 0) == linear
     assert model.mel_rows_ok(eng, 256, plan.T)
     ws = [eng.workspace_bytes(256, T, 16 * 641) for T in (12100, 121000)]
     assert ws[0] == ws[1] and ws[0] < 300e6, ws
-    refs = _pool_map(lambda u: oracle_utterance('MOL', 0, 0.95, 1234 + u, 77 + u, 641, want_cond=False, sd=sd)['ref'], list(range(NU)))
+    refs = _pool_map(lambda u: oracle_utterance('MOL', 0, 0.95, 1234 + u, 77 + u, 641, want_cond=False, sd=sd, linear=linear)['ref'], list(range(NU)))
     for u, ref in enumerate(refs):
         got = segs[plan.first[u]:plan.first[u] + plan.folds[u]].astype(np.float32)
         assert np.abs(got - ref).max() <= MOL_TOL, (u, np.abs(got - ref).max())

@@ -115,7 +115,7 @@ def _skip_unless_supported(mode, opts):
 def test_device_selftests(gpu):
     from wavernn_amd import _lib
     L = _lib.lib()
-    assert L.wrnn_abi_version() == 8
+    assert L.wrnn_abi_version() == 9
     assert L.wrnn_device_cus(0) > 0
     _lib.check(L.wrnn_selftest(0, 1), 'mfma selftest')
     print(L.wrnn_last_error().decode())
@@ -647,29 +647,32 @@ def test_block_sparse_gru_weights(gpu, mode, variant):
         assert np.abs(out - ref).max() <= MOL_TOL, np.abs(out - ref).max()
 
 
-def _sparse_case(frames, target, overlap, wseed=35):
-    """Inputs + the C oracle's free run / teacher-forced logits on 95 %-block-pruned GRU weights (memoised)."""
+def _sparse_case(frames, target, overlap, wseed=35, linear=False):
+    """Inputs + the C oracle's free run / teacher-forced logits on 95 %-block-pruned GRU weights (memoised); `linear`: fc1 / fc2 pruned too, as
+    the reference's pruning notebook prunes its Linear layer."""
     from oracle import c_oracle as C, wavernn_oracle as O
     from wavernn_amd.prune import block_prune_state_dict
-    key = ('sparse', frames, target, overlap, wseed)
+    key = ('sparse', frames, target, overlap, wseed, linear)
     if key not in _MEMO:
         cfg = dict(mode='MOL', wseed=wseed, mseed=135, frames=frames, batched=True, target=target, overlap=overlap, seed=95)
         sd0, mel, mels_up, aux, (B, T, stride), noise, flat = _inputs(cfg)
-        sd, _ = block_prune_state_dict(sd0, 0.95, (16, 1))
+        sd, _ = block_prune_state_dict(sd0, 0.95, (16, 1), linear=linear)
         mels_f, aux_f, _ = O.conditioning(sd, mel, True, target, overlap)
         ref, ref_logits = C.loop(sd, 'MOL', mels_f, aux_f, noise, want_logits=True)
         _MEMO[key] = (sd0, sd, mels_up, aux, (B, T, stride), flat, ref, ref_logits)
     return _MEMO[key]
 
 
-def test_block_sparse_kernel_teacher_forced_logits(gpu):
+@pytest.mark.parametrize('linear', [False, True], ids=['gru', 'gru+linear'])
+def test_block_sparse_kernel_teacher_forced_logits(gpu, linear):
     """Stage-level check of wrnn_sparse_kernel: the oracle's own samples fed back (teacher forcing), every step's fc3 logits against the C
     oracle on the same pruned weights as masked dense matrices -- isolates the kernel's arithmetic and exchange from chaotic divergence.
     46 segments = 3 groups on 3 clusters (the last one ragged: 14 segments), several conditioning slabs."""
     from wavernn_amd.engine import LoopEngine
-    sd0, sd, mels_up, aux, (B, T, stride), flat, ref, ref_logits = _sparse_case(100, 550, 55)
+    sd0, sd, mels_up, aux, (B, T, stride), flat, ref, ref_logits = _sparse_case(100, 550, 55, linear=linear)
     eng = LoopEngine(sd, 'MOL', device=gpu)
     assert 0 < eng.sparse_blocks <= 48
+    assert (0 < eng.sparse_fc_blocks <= 48) if linear else eng.sparse_fc_blocks == -512      # gathered fc stages (round 6) / the dense ones
     for slab in (0, 97):
         out, logits = eng.run(torch.from_numpy(mels_up).to(gpu), torch.from_numpy(aux).to(gpu), B, T, stride, torch.from_numpy(flat).to(gpu), 275,
                               algo='sparse', force_x=torch.from_numpy(ref), want_logits=True, slab_steps=slab)
@@ -680,16 +683,19 @@ def test_block_sparse_kernel_teacher_forced_logits(gpu):
         assert np.abs(out.cpu().numpy() - ref).max() <= MOL_TOL
 
 
+@pytest.mark.parametrize('linear', [False, True], ids=['gru', 'gru+linear'])
 @pytest.mark.parametrize('frames,target,overlap,opts', [(100, 550, 55, {}), (100, 220, 22, dict(slab_steps=97)), (300, 220, 22, {}),
-                                                        (300, 220, 22, dict(slab_steps=61, tuning=256)), (100, 550, 55, 'slices')])
-def test_block_sparse_kernel_matches_oracle(gpu, frames, target, overlap, opts):
+                                                        (300, 220, 22, dict(slab_steps=61, tuning=256)), (100, 550, 55, 'slices'),
+                                                        (100, 550, 55, dict(tuning=2048))])
+def test_block_sparse_kernel_matches_oracle(gpu, frames, target, overlap, opts, linear):
     """`WRNN_ALGO_SPARSE` (round 5: 16 clusters of 16 CUs, one group each; packed 16x1 blocks, gathered B fragments) on 95 %-pruned GRU
     weights vs the C oracle running the same weights as masked dense matrices: 46 / 114 / 341 segments (one and two rounds; ragged last
     groups), several conditioning slabs (state saved / restored), every layer written through (tuning bit 8), a run continued in step
     slices.  `auto` picks the kernel for such a pack; a dense pack is refused.  MoL tolerance (the surviving terms are summed in a
-    different order)."""
+    different order).  `linear` (round 6): fc1 / fc2 block-pruned as well -- the gathered fc stages, cI three steps ahead, the step barrier; tuning bit
+    11 runs such a pack through the DENSE fc stages."""
     from wavernn_amd.engine import LoopEngine
-    sd0, sd, mels_up, aux, (B, T, stride), flat, ref, _ = _sparse_case(frames, target, overlap)
+    sd0, sd, mels_up, aux, (B, T, stride), flat, ref, _ = _sparse_case(frames, target, overlap, linear=linear)
     eng = LoopEngine(sd, 'MOL', device=gpu)
     assert 0 < eng.sparse_blocks <= 64
     dense = LoopEngine(sd0, 'MOL', device=gpu)

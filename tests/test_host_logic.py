@@ -23,7 +23,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.wrnn_abi_version() == 8
+    assert L.wrnn_abi_version() == 9
     # no GPU here: compute entry points must fail loudly, never fall back to the host
     if not torch.cuda.is_available():
         assert L.wrnn_device_cus(0) < 0

@@ -14,13 +14,13 @@ SO_PATH = os.path.join(CSRC, 'libwavernn_amd.so')
 WRNN_OK = 0
 ERR_RESIDENCY = -6          # WRNN_ERR_RESIDENCY: the persistent grid cannot be co-resident on this device
 MODE_RAW, MODE_MOL = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 ALGO_AUTO, ALGO_STREAM, ALGO_LOOP, ALGO_SPARSE, ALGO_DUO, ALGO_CHAIN, ALGO_OCTO = 0, 1, 2, 5, 6, 7, 8
 ALGOS = {'auto': ALGO_AUTO, 'stream': ALGO_STREAM, 'loop': ALGO_LOOP, 'sparse': ALGO_SPARSE, 'duo': ALGO_DUO, 'chain': ALGO_CHAIN, 'octo': ALGO_OCTO}
 
 #: every symbol include/wavernn_amd.h declares
 EXPORTS = ['wrnn_last_error', 'wrnn_abi_version', 'wrnn_device_cus', 'wrnn_pack_create', 'wrnn_pack_destroy',
-           'wrnn_pack_weight_bytes', 'wrnn_pack_sparse_blocks', 'wrnn_workspace_bytes', 'wrnn_workspace_bytes_segments', 'wrnn_generate',
+           'wrnn_pack_weight_bytes', 'wrnn_pack_sparse_blocks', 'wrnn_pack_sparse_fc_blocks', 'wrnn_workspace_bytes', 'wrnn_workspace_bytes_segments', 'wrnn_generate',
            'wrnn_generate_segments', 'wrnn_plan_segments', 'wrnn_status', 'wrnn_timer_create', 'wrnn_timer_destroy', 'wrnn_timer_ms',
            'wrnn_timer_launches', 'wrnn_debug_read_exchange', 'wrnn_selftest', 'wrnn_selftest_metric', 'wrnn_pre_create',
            'wrnn_pre_destroy', 'wrnn_pre_hop', 'wrnn_pre_workspace_bytes', 'wrnn_pre_upsample', 'wrnn_pre_upsample_rows', 'wrnn_pre_last_error',
@@ -140,6 +140,7 @@ def lib():
     L.wrnn_pack_weight_bytes.argtypes = [ctypes.c_void_p]
     L.wrnn_pack_weight_bytes.restype = ctypes.c_size_t
     L.wrnn_pack_sparse_blocks.argtypes = [ctypes.c_void_p]
+    L.wrnn_pack_sparse_fc_blocks.argtypes = [ctypes.c_void_p]
     L.wrnn_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.POINTER(Geometry), ctypes.POINTER(Options)]
     L.wrnn_workspace_bytes.restype = ctypes.c_size_t
     L.wrnn_generate.argtypes = [ctypes.c_void_p, ctypes.POINTER(Geometry), ctypes.c_void_p, ctypes.c_void_p,

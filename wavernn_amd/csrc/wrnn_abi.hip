@@ -86,6 +86,9 @@ struct wrnn_pack {
     int sp_max_blocks;
     const float *sp_vals;
     const int *sp_cols;
+    int sp_fc_max_blocks;      // fc1 / fc2 (columns [0, H): the aux columns live in the per-frame tables): largest block row
+    const float *sp_fc_vals;   // non-null: the Linear layers are block-sparse too (the notebook prunes them as well) -> wrnn_sparse_kernel's gathered fc stages
+    const int *sp_fc_cols;
 };
 
 extern "C" const char *wrnn_last_error(void) { return g_err; }
@@ -226,8 +229,9 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     }
     // ---- block-sparse view of the GRU matrices (16x1 blocks: 16 consecutive rows of one gate x 1 column) -----------
     // usable by wrnn_sparse_kernel when every block row keeps <= 64 columns (~5 % density keeps ~26 +- 5)
-    int sp_nbp = 0, sp_max = 0;
-    size_t o_spv = 0, o_spc = 0;
+    int sp_nbp = 0, sp_max = 0, sp_fc_max = 0;
+    bool sp_fc_ok = false;
+    size_t o_spv = 0, o_spc = 0, o_sfv = 0, o_sfc = 0;
     {
         const float *mats[4] = {w->w_ih1, w->w_hh1, w->w_ih2, w->w_hh2};
         const int lds_[4] = {H, H, K2, H};
@@ -244,8 +248,41 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
                     }
                     if ((int)cv.size() > sp_max) sp_max = (int)cv.size();
                 }
+        // fc1 / fc2 (round 6; "Pruning - Scratchpad.ipynb" :199-204 prunes the Linear layers too): their first H columns, 32 block rows each
+        const float *fmats[2] = {w->fc1_w, w->fc2_w};
+        std::vector<std::vector<int>> fcols((size_t)2 * 32);
+        for (int m = 0; m < 2; ++m)
+            for (int wg = 0; wg < 32; ++wg) {
+                std::vector<int> &cv = fcols[(size_t)m * 32 + wg];
+                const float *base = fmats[m] + (size_t)(16 * wg) * K2;
+                for (int c = 0; c < H; ++c) {
+                    bool nz = false;
+                    for (int r = 0; r < 16 && !nz; ++r) nz = base[(size_t)r * K2 + c] != 0.0f;
+                    if (nz) cv.push_back(c);
+                }
+                if ((int)cv.size() > sp_fc_max) sp_fc_max = (int)cv.size();
+            }
         if (sp_max <= 64 && w->mode == WRNN_MODE_MOL) {
             sp_nbp = sp_max <= 48 ? 48 : 64;
+            if (sp_fc_max <= 64) {                        // one NBP for the gate and the fc tiles of a launch
+                if (sp_fc_max > 48) sp_nbp = 64;
+                o_sfv = b.add(nullptr, (size_t)2 * 32 * sp_nbp * 16);
+                o_sfc = b.add(nullptr, (size_t)2 * 32 * sp_nbp);
+                for (size_t q = 0; q < (size_t)2 * 32 * sp_nbp * 16; ++q) b.host[o_sfv + q] = 0.f;
+                int *fi_ = reinterpret_cast<int *>(b.host.data() + o_sfc);
+                for (size_t q = 0; q < (size_t)2 * 32 * sp_nbp; ++q) fi_[q] = 0;
+                for (int m = 0; m < 2; ++m)
+                    for (int wg = 0; wg < 32; ++wg) {
+                        const size_t br = (size_t)m * 32 + wg;
+                        const std::vector<int> &cv = fcols[br];
+                        const float *base = fmats[m] + (size_t)(16 * wg) * K2;
+                        for (size_t k = 0; k < cv.size(); ++k) {
+                            reinterpret_cast<int *>(b.host.data() + o_sfc)[br * sp_nbp + k] = cv[k];
+                            for (int r = 0; r < 16; ++r) b.host[o_sfv + (br * sp_nbp + k) * 16 + r] = base[(size_t)r * K2 + cv[k]];
+                        }
+                    }
+                sp_fc_ok = true;
+            }
             o_spv = b.add(nullptr, (size_t)4 * 32 * 3 * sp_nbp * 16);
             o_spc = b.add(nullptr, (size_t)4 * 32 * 3 * sp_nbp);        // ints stored in the float builder (same width)
             for (size_t q = 0; q < (size_t)4 * 32 * 3 * sp_nbp * 16; ++q) b.host[o_spv + q] = 0.f;
@@ -290,6 +327,9 @@ extern "C" int wrnn_pack_create(const wrnn_weights *w, int device, wrnn_pack **o
     p->sp_nbp = sp_nbp; p->sp_max_blocks = sp_max;
     p->sp_vals = sp_nbp ? base + o_spv : nullptr;
     p->sp_cols = sp_nbp ? reinterpret_cast<const int *>(base + o_spc) : nullptr;
+    p->sp_fc_max_blocks = sp_fc_max;
+    p->sp_fc_vals = sp_fc_ok ? base + o_sfv : nullptr;
+    p->sp_fc_cols = sp_fc_ok ? reinterpret_cast<const int *>(base + o_sfc) : nullptr;
     *out = p;
     return WRNN_OK;
 }
@@ -304,6 +344,7 @@ extern "C" void wrnn_pack_destroy(wrnn_pack *p)
 extern "C" size_t wrnn_pack_weight_bytes(const wrnn_pack *p) { return p ? p->weight_bytes : 0; }
 
 extern "C" int wrnn_pack_sparse_blocks(const wrnn_pack *p) { return p ? (p->sp_nbp ? p->sp_max_blocks : -p->sp_max_blocks) : 0; }
+extern "C" int wrnn_pack_sparse_fc_blocks(const wrnn_pack *p) { return p ? (p->sp_fc_vals ? p->sp_fc_max_blocks : -p->sp_fc_max_blocks) : 0; }
 
 struct wrnn_timer {
     int device;
@@ -822,6 +863,7 @@ extern "C" int wrnn_generate_segments(const wrnn_pack *p, int32_t B, int32_t T, 
         const bool octo = pl.kind == K_DUO && pl.octo;
         info.kernel = chain ? "wrnn_chain_kernel" : sparse ? "wrnn_sparse_kernel" : (duo ? (octo ? "wrnn_octo_kernel" : "wrnn_duo_kernel") : "wrnn_loop_kernel"); info.units_per_wg = sparse ? 64 : 16;
         a.sp_vals = p->sp_vals; a.sp_cols = p->sp_cols;
+        a.sp_fc_vals = (o->tuning & 2048) ? nullptr : p->sp_fc_vals; a.sp_fc_cols = p->sp_fc_cols;      // (tuning bit 11: dense fc stages on a pack whose Linear layers are sparse too -- A/B)
         const bool mol = p->mode == WRNN_MODE_MOL;
         a.xbuf = (float *)(ws + l.xbuf);
         a.cIf = (const float *)(ws + l.cIf);

@@ -66,6 +66,8 @@ struct LoopArgs {
     // block-sparse GRU pack (wrnn_sparse.hip): matrix m in {ih1,hh1,ih2,hh2}, block row (16-row block rb, gate g), NBP padded blocks
     const float *sp_vals;               // [4][32][3][NBP][16]  block values (16 rows of one column)
     const int *sp_cols;                 // [4][32][3][NBP]      their column indices (padding: column 0, zero values)
+    const float *sp_fc_vals;            // [2][32][NBP][16]     fc1 / fc2 (their x2 / y1 columns) packed the same way, or null: dense fc stages (round 6)
+    const int *sp_fc_cols;              // [2][32][NBP]
     const float *force_x;               // optional [Btot][T]
     float *out;                         // [Btot][T]
     float *dbg_logits;                  // optional [T][Btot][C]

@@ -128,6 +128,27 @@ __device__ __forceinline__ void gate_mfma(const GateTiles<MPW> &gt, const unsign
     o0 = c0; o1 = c1; o2 = c2;
 }
 
+// Round 6 -- BLOCK-SPARSE fc1 / fc2 (FCS; the reference's pruning recipe prunes the Linear layers with the GRUs: "Pruning - Scratchpad.ipynb" :199-204).
+// ONE 16-row block of fc1 (waves 0-1 of a workgroup) or of fc2 (waves 2-3) per wave over the compacted K, packed and gathered exactly like a gate
+// tile (the pack's sp_fc_vals / sp_fc_cols): MPW MFMAs, the accumulators ARE rows 4 kq .. 4 kq + 3 of the block for segment fi -- no K split, no
+// partial tiles, no LDS, no barrier, and 2 x (12 + 12) registers per lane instead of the 128 of the four dense tiles.
+template <int MPW>
+struct FcTile {
+    float a[MPW];
+    int off[MPW];
+};
+template <int MPW>
+__device__ __forceinline__ void fc_tile_init(FcTile<MPW> &ft, const float *vals, const int *cols, int m, int rb, int lane)
+{
+    const int fi = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        const size_t r = ((size_t)m * 32 + rb) * (4 * MPW) + 4 * i + kq;
+        ft.a[i] = vals[r * 16 + fi];
+        ft.off[i] = cols[r] * 64 + fi * 4;                  // k-major layer: element (column, segment fi)
+    }
+}
+
 __device__ __forceinline__ unsigned max4(const u32x4 &q) { return max(max(q.x, q.y), max(q.z, q.w)); }
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define SPX(k)                                                                 \
@@ -168,7 +189,7 @@ __device__ __forceinline__ void mfma2(const float (&a0)[AF], const float (&a1)[A
 // x_{t-1}, 1 cell + publish, 2 wait for h1(t), 3 gh tiles, 4 wait x2, 5 fc1, 6 wait y1, 7 fc2, 8 wait cI(t+1), 9 W_ih . cI tiles;
 // rnn2: 0 drain + wait for x1(t), 1 gate tiles + cell + publish, 2 wait x2, 3 fc1, 6 wait y1, 7 fc2, 8 wait y2, 9 fc3 + sampling, 4 wait h2 (there), 5 gh
 // tiles, 10 cI(t+2) formed; 15 = steps
-template <int NBP, bool LA, bool PROF>
+template <int NBP, bool FCS, bool LA, bool PROF>
 __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const int rg, const int gid, const int ub, const int wgi, const bool loc)
 {
     constexpr int MPW = NBP / 4;
@@ -206,10 +227,14 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
     gate_tiles_init(gi, a.sp_vals, a.sp_cols, LA ? 0 : 2, rb, lane);
     gate_tiles_init(gh, a.sp_vals, a.sp_cols, LA ? 1 : 3, rb, lane);
     float A_fc1[2][AF], A_fc2[2][AF];
+    FcTile<MPW> ft;                                     // FCS: this wave's fc tile -- waves 0-1: row block 2 wgi + w of fc1, waves 2-3: row block 2 wgi + w - 2 of fc2
+    if constexpr (FCS) fc_tile_init(ft, a.sp_fc_vals, a.sp_fc_cols, w >> 1, 2 * wgi + (w & 1), lane);
+    else {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        load_afrag(A_fc1[q], a.fc1_w, H + AUX, 2 * LU * wgi + LU * q + fi, true, kbase_lane);
-        load_afrag(A_fc2[q], a.fc2_w, H + AUX, 2 * LU * wgi + LU * q + fi, true, kbase_lane);
+        for (int q = 0; q < 2; ++q) {
+            load_afrag(A_fc1[q], a.fc1_w, H + AUX, 2 * LU * wgi + LU * q + fi, true, kbase_lane);
+            load_afrag(A_fc2[q], a.fc2_w, H + AUX, 2 * LU * wgi + LU * q + fi, true, kbase_lane);
+        }
     }
     for (int q = tid; q < L.off_f3; q += NT) smem[q] = 0.f;
     if (sampler) {                                      // fc3 -> LDS (fragment order as in the pack)
@@ -316,7 +341,8 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
     auto rearm = [&]() {
         const int so = cbase + ((t + DAHEAD_IH) & (DRING - 1)) * XTB;
         const u32x4 q = {SENT, SENT, SENT, SENT};
-        store16(q, (kq < 2 ? 2 : 3) * DLAYERB + (2 * wgi + (kq & 1)) * 1024 + w * 256 + fi * 16, so);
+        if constexpr (FCS) store16(q, (w < 2 ? 2 : 3) * DLAYERB + (2 * wgi + (w & 1)) * 1024 + lane * 16, so);      // the wave's OWN 1 KB block of y1 (k-major) / y2
+        else store16(q, (kq < 2 ? 2 : 3) * DLAYERB + (2 * wgi + (kq & 1)) * 1024 + w * 256 + fi * 16, so);
         store16(q, L_H * DLAYERB + voff_blk, so);
         store16(q, L_XR * DLAYERB + voff_blk, so);
     };
@@ -326,6 +352,54 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         constexpr int which = decltype(WC)::value;
         constexpr int LI = which == 1 ? 6 : 2, LO = which == 1 ? 2 : 3;
         const int sb = cbase + (t & (DRING - 1)) * XTB;
+        if constexpr (FCS) {
+            // the gathered form: only the waves that own a tile of this layer run it (wave-uniform); its input layer (x2 / y1) is k-major
+            if ((w < 2) == (which == 1)) {
+                unsigned v[MPW];
+#pragma unroll
+                for (int i = 0; i < MPW; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b32(xrs, ft.off[i], sb + LI * DLAYERB, 16 /* sc1 */);
+                const int fr = table_row(SEGT[fi] + t, SEGT[SEG + fi], SEGT[2 * SEG + fi], magic, mshift, hop, zrow);
+                const int r0 = 2 * LU * wgi + LU * (w & 1) + 4 * kq;                   // the lane's rows r0 .. r0 + 3 (of segment fi)
+                const u32x4 cv = __builtin_amdgcn_raw_buffer_load_b128(which == 1 ? f1rs : f2rs, (fr * H + r0) * 4, 0, 0);
+                auto there = [&] {
+                    unsigned m = 0u;
+#pragma unroll
+                    for (int i = 0; i < MPW; ++i) m = max(m, v[i]);
+                    return __all(m != SENT || !live);
+                };
+                if (__builtin_expect(!there(), 0))
+                    wait_for(there,
+                             [&] {
+#pragma unroll
+                                 for (int i = 0; i < MPW; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b32(xrs, ft.off[i], sb + LI * DLAYERB, 16 /* sc1 */);
+                             },
+                             status, dead, 0x700u | (unsigned)which, t);
+                SPX(LA ? (which == 1 ? 4 : 6) : (which == 1 ? 2 : 6));
+                f32x4 c0 = mfma_ag0(ft.a[0], __uint_as_float(v[0])), c1 = mfma_ag0(ft.a[1], __uint_as_float(v[1])), c2 = mfma_ag0(ft.a[2], __uint_as_float(v[2]));
+#pragma unroll
+                for (int i = 3; i < MPW; ++i) {              // three chains by i % 3, added at the end
+                    if (i % 3 == 0) mfma_ag(c0, ft.a[i], __uint_as_float(v[i]));
+                    else if (i % 3 == 1) mfma_ag(c1, ft.a[i], __uint_as_float(v[i]));
+                    else mfma_ag(c2, ft.a[i], __uint_as_float(v[i]));
+                }
+                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c0), "+v"(c1), "+v"(c2));
+                const f32x4 acc = c0 + c1 + c2;
+                u32x4 q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] = __float_as_uint(fmaxf(acc[e] + __uint_as_float(cv[e]), 0.f));      // relu(fc([x, a]) + b): the aux columns and the bias sit in the per-frame table
+                if (live) {
+                    if constexpr (which == 1) {             // y1: gathered by the fc2 tiles -> k-major
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (loc) __builtin_amdgcn_raw_buffer_store_b32(q[e], xrs, LO * DLAYERB + (r0 + e) * 64 + fi * 4, sb, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b32(q[e], xrs, LO * DLAYERB + (r0 + e) * 64 + fi * 4, sb, 16 /* sc1 */);
+                        }
+                    } else store16(q, LO * DLAYERB + (2 * wgi + (w & 1)) * 1024 + lane * 16, sb);      // y2: read by the dense fc3 of the sampling workgroup -> fragment order
+                }
+                rearm();                                // (behind this wave's last sentinel poll of the step; tests/test_sparse_exchange_model.py, SparseFcSim)
+            }
+            SPX(LA ? (which == 1 ? 5 : 7) : (which == 1 ? 3 : 7));
+        } else {
         u32x4 x[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + LI * DLAYERB, 16 /* sc1 */);
@@ -355,6 +429,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         if constexpr (which == 2) rearm();              // (behind the last poll of the step -- y1(t) above -- and behind the publication: off the chain)
         pp ^= 1;
         SPX(LA ? (which == 1 ? 5 : 7) : (which == 1 ? 3 : 7));
+        }
     };
 
     // ---------------- gate stages ----------------
@@ -370,7 +445,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         }
         if (live) {
             const int sb = cbase + (t & (DRING - 1)) * XTB;
-            if constexpr (LA) store4(qx, L_XR * DLAYERB, sb);               // x1: gathered by rnn2's gate stage (k-major)
+            if constexpr (LA || FCS) store4(qx, L_XR * DLAYERB, sb);        // x1: gathered by rnn2's gate stage (k-major); FCS: x2 is gathered too (fc1 tiles)
             else store16(qx, L_XR * DLAYERB + voff_blk, sb);               // x2: read by the fc1 stages (fragment order: units u0 .. u0 + 3 of segment fi = one word)
             store4(qh, L_H * DLAYERB, sb);
         }
@@ -421,12 +496,21 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
         unsigned v[3][MPW];
         gather_issue(xrs, so, gi, v);
         own = load_own(so);
+        // FCS: every wave also waits for the tagged word x_{t-1} (it exists long before x1(t) does: nothing on the chain) -- a wave whose gathers are
+        // empty (a fully pruned block row) would otherwise run free of the ring; the skew argument: tests/test_sparse_exchange_model.py, SparseFcSim
+        u32x2 xq = {0u, (unsigned)t};
+        if (FCS && t > T0) xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, fi * 8, cbase + 7 * DLAYERB + ((t - 1) & 1) * XTB, 16 /* sc1 */);
         const int fr = table_row(SEGT[fi] + t, SEGT[SEG + fi], SEGT[2 * SEG + fi], magic, mshift, hop, zrow);
         u32x4 c2[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) c2[q] = __builtin_amdgcn_raw_buffer_load_b128(crs, (fr * 3 * H + q * H + u0) * 4, 0, 0);
         if (__builtin_expect(!gather_there(v, max4(own), live), 0))
             wait_for([&] { return gather_there(v, max4(own), live); }, [&] { gather_issue(xrs, so, gi, v); own = load_own(so); }, status, dead, 0x728u, t);
+        if constexpr (FCS) {
+            if (__builtin_expect(__any(live && xq.y != (unsigned)t), 0))
+                wait_for([&] { return !__any(live && xq.y != (unsigned)t); },
+                         [&] { xq = __builtin_amdgcn_raw_buffer_load_b64(xrs, fi * 8, cbase + 7 * DLAYERB + ((t - 1) & 1) * XTB, 16 /* sc1 */); }, status, dead, 0x729u, t);
+        }
         SPX(0);
         f32x4 o0, o1, o2;
         gate_mfma(gi, v, o0, o1, o2);
@@ -546,14 +630,19 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
     if constexpr (LA) {
         front_issue(T0);
         front_finish(T0);
-    } else if (cond_wg) {                               // the two steps a launch starts with; every later cI is formed during the step before its use
+    } else if (cond_wg) {                               // the two (FCS: three) steps a launch starts with; every later cI is formed CLEAD steps ahead
         cond_step(T0);
         if (T0 + 1 < T1) cond_step(T0 + 1);
+        if (FCS && T0 + 2 < T1) cond_step(T0 + 2);
     }
+    // FCS: cI THREE steps ahead -- its readers (end of step t + 2) have seen x_{t+1}, i.e. every wave of the cluster has passed the top of step t + 1 =
+    // the forming wave's drain; two ahead leaned on "y1(t + 1) needed every x2(t + 1)", which a gathered fc stage does not give (SparseFcSim)
+    constexpr int CLEAD = FCS ? 3 : 2;
     for (; t < T1; ++t) {
         if (PROF && tid == 0) PROFL[15] += 1;
         // ring hygiene: last step's re-arm stores (and, rnn1, the cI formed at its end) are out before anything of this step is published
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (FCS) lds_barrier();               // the four waves of a workgroup start a step together (they no longer meet in a dense fc stage): SparseFcSim
         if constexpr (LA) {
             // Off the chain, placed where this workgroup waits anyway (profiles/r05b .. r05d_sparse_phase_clocks.json): gh(t + 1) while x1 -> rnn2
             // -> x2 is under way, W_ih . cI(t + 1) under the sampling of step t.
@@ -573,7 +662,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
             fc(I2{});
             if (sampler) sample();
             gh_stage();
-            if (cond_wg && t + 2 < T1) cond_step(t + 2);
+            if (cond_wg && t + CLEAD < T1) cond_step(t + CLEAD);
         }
     }
     if (PROF && tid == 0 && a.prof) {
@@ -595,7 +684,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
     if (cond_wg) {                                      // (a block of a k-major layer is 1 KB: one 16-byte store per lane)
         const u32x4 q = {SENT, SENT, SENT, SENT};
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < CLEAD; ++e) {
             store16(q, cblk0 * 1024 + lane * 16, cbase + 4 * DLAYERB + ((T1 + e) & (DRING - 1)) * XTB);
             if (cond2) store16(q, cblk1 * 1024 + lane * 16, cbase + 4 * DLAYERB + ((T1 + e) & (DRING - 1)) * XTB);
         }
@@ -606,7 +695,7 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
 // b is observed to run on XCD b % 8 and the blocks of an XCD to be dealt round-robin over its 32 CUs.  XCD x hosts clusters x (its CUs
 // 0-15) and 8 + x (CUs 16-31); CU c of a cluster: c / 8 = rnn1 | rnn2, unit block c % 8.  Group g of a round runs on cluster g: the first
 // eight groups take one cluster on every XCD.
-template <int NBP, bool PROF>
+template <int NBP, bool FCS, bool PROF>
 __global__ __launch_bounds__(NT, 1) void wrnn_sparse_kernel(const LoopArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -646,8 +735,8 @@ __global__ __launch_bounds__(NT, 1) void wrnn_sparse_kernel(const LoopArgs a)
         if (a.tuning & 256) loc = false;                // A/B: everything written through
         __syncthreads();
     }
-    if (cu < 8) sp_role<NBP, true, PROF>(a, smem, cl, cl, cu, cu, loc);
-    else sp_role<NBP, false, PROF>(a, smem, cl, cl, cu - 8, cu, loc);
+    if (cu < 8) sp_role<NBP, FCS, true, PROF>(a, smem, cl, cl, cu, cu, loc);
+    else sp_role<NBP, FCS, false, PROF>(a, smem, cl, cl, cu - 8, cu, loc);
 }
 
 // clusters of 16 CUs: the kernel's block -> role map is written for the whole 256-CU chip
@@ -661,8 +750,11 @@ hipError_t launch_sparse(const LoopArgs &args, int nbp, hipStream_t stream)
     if ((nbp != 48 && nbp != 64) || !args.fc3f || !args.u1 || !args.xcc_tab || !args.sp_vals || args.NG < 1 || args.NG > SPCLUSTERS) return hipErrorInvalidValue;
     const size_t lds = sparse_lds_bytes();
     const bool prof = args.prof && !(args.tuning & 64);              // phase clocks (wrnn_options.phase_clocks)
-    const void *fn = nbp == 48 ? (prof ? (const void *)wrnn_sparse_kernel<48, true> : (const void *)wrnn_sparse_kernel<48, false>)
-                               : (prof ? (const void *)wrnn_sparse_kernel<64, true> : (const void *)wrnn_sparse_kernel<64, false>);
+    const bool fcs = args.sp_fc_vals != nullptr;                     // the pack's Linear layers are block-sparse too: gathered fc stages
+    const void *fn = fcs ? (nbp == 48 ? (prof ? (const void *)wrnn_sparse_kernel<48, true, true> : (const void *)wrnn_sparse_kernel<48, true, false>)
+                                      : (prof ? (const void *)wrnn_sparse_kernel<64, true, true> : (const void *)wrnn_sparse_kernel<64, true, false>))
+                         : (nbp == 48 ? (prof ? (const void *)wrnn_sparse_kernel<48, false, true> : (const void *)wrnn_sparse_kernel<48, false, false>)
+                                      : (prof ? (const void *)wrnn_sparse_kernel<64, false, true> : (const void *)wrnn_sparse_kernel<64, false, false>));
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     LoopArgs a = args;

@@ -111,6 +111,11 @@ class LoopEngine:
         return int(self.lib.wrnn_pack_sparse_blocks(self._pack))
 
     @property
+    def sparse_fc_blocks(self):
+        """> 0: fc1 / fc2 are block-sparse too (the notebook's recipe prunes the Linear layers) -> the sparse kernel's gathered fc stages."""
+        return int(self.lib.wrnn_pack_sparse_fc_blocks(self._pack))
+
+    @property
     def weight_bytes(self):
         return int(self.lib.wrnn_pack_weight_bytes(self._pack))
 

@@ -13,6 +13,7 @@ kernel is the follow-up that turns the 95 % zeros into speed (the pruned GRU wei
 import numpy as np
 
 GRU_KEYS = ('rnn1.weight_ih_l0', 'rnn1.weight_hh_l0', 'rnn2.weight_ih_l0', 'rnn2.weight_hh_l0')
+LINEAR_KEYS = ('fc1.weight', 'fc2.weight')       # the notebook prunes `[self.rnn, self.fc]` ("Pruning - Scratchpad.ipynb" :199-204; 'Linear': 1 mask, :54)
 
 
 def block_mask(W, sparsity, block=(16, 1), gates=3):
@@ -37,15 +38,16 @@ def block_mask(W, sparsity, block=(16, 1), gates=3):
     return mask
 
 
-def block_prune_state_dict(sd, sparsity=0.95, block=(16, 1), keys=GRU_KEYS):
-    """Copy of `sd` (numpy arrays) with the GRU matrices block-pruned; returns (pruned_sd, {key: density})."""
+def block_prune_state_dict(sd, sparsity=0.95, block=(16, 1), keys=GRU_KEYS, linear=False):
+    """Copy of `sd` (numpy arrays) with the GRU matrices block-pruned -- and, `linear=True`, fc1 / fc2 as the reference's pruning notebook prunes its
+    Linear layer (one mask over the whole matrix) --; returns (pruned_sd, {key: density})."""
     out = dict(sd)
     density = {}
-    for k in keys:
+    for k in tuple(keys) + (LINEAR_KEYS if linear else ()):
         W = np.asarray(sd[k], dtype=np.float32)
         if W.shape[1] % block[1]:
             raise ValueError(f'{k}: {W.shape} does not tile by {block}')
-        M = block_mask(W, sparsity, block)
+        M = block_mask(W, sparsity, block, gates=1 if k in LINEAR_KEYS else 3)
         out[k] = (W * M).astype(np.float32)
         density[k] = float(M.mean())
     return out, density
