@@ -126,6 +126,23 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
     if constexpr (HAS_FC1) load_afrag(A_fc1, a.fc1_w, H + AUX, LU * J + fi, true, kbase_lane);
     if constexpr (!LA) load_afrag(A_fc2, a.fc2_w, H + AUX, LU * J + fi, true, kbase_lane);
     float A_f3[AF];                                     // RAW, rnn1: fc3 rows (classes) [16 J, 16 J + 16)
+    float A_f3m[2][AF];                                 // MOL, rnn1: both 16-row tiles of fc3 (30 x 512), this wave's quarter of K -- AGPRs (round 6; they were read from LDS MFMA by MFMA)
+    if constexpr (LA && MOL) {
+        if (a.tuning & 32) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < AF; ++k) A_f3m[q][k] = 0.f;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float4 v = *reinterpret_cast<const float4 *>(a.fc3f + q * XT + frag_off(w, 0, lane) + 256 * r);
+                    A_f3m[q][4 * r + 0] = v.x; A_f3m[q][4 * r + 1] = v.y; A_f3m[q][4 * r + 2] = v.z; A_f3m[q][4 * r + 3] = v.w;
+                }
+        }
+    }
     float b3 = 0.f;
     if constexpr (LA && !MOL) {
         load_afrag(A_f3, a.fc3_w, H, LU * J + fi, true, kbase_lane);
@@ -167,6 +184,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
     // MOL: rnn1's workgroup i runs fc3 + the sampling of slot i.  RAW: FOUR workgroups per slot -- workgroup J samples segments 4 (J & 3) .. + 3 of slot
     // J >> 2, one segment per wave (the 512-class softmax of 16 segments on one workgroup took ~8 us of the chain: profiles/r05k_probe_raw_chain.json)
     const bool sampler = LA && J < (MOL ? nact : 4 * nact);
+    const bool f3_lds = (a.tuning & 32) != 0;           // A/B: fc3's tiles read from LDS, as round 5
     if (MOL && sampler) {                               // fc3 -> LDS (fragment order as in the pack)
         for (int q = tid; q < 2 * XT / 4; q += NT) reinterpret_cast<float4 *>(F3)[q] = reinterpret_cast<const float4 *>(a.fc3f)[q];
         if (tid < 32) fc3b[tid] = tid < 30 ? a.fc3_b[tid] : 0.f;
@@ -351,8 +369,13 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             float b[32];
             frag_to_b(x, b);
             float *PW = PART + pp * (NW * 3 * 256);
-            put_partial<3>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
-            put_partial<3>(PW, w, 1, lane, mfma1_lds(F3 + XT + frag_off(w, 0, lane), b));
+            if (f3_lds) {
+                put_partial<3>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
+                put_partial<3>(PW, w, 1, lane, mfma1_lds(F3 + XT + frag_off(w, 0, lane), b));
+            } else {
+                put_partial<3>(PW, w, 0, lane, mfma1_ag(A_f3m[0], b));
+                put_partial<3>(PW, w, 1, lane, mfma1_ag(A_f3m[1], b));
+            }
             lds_barrier();
             if (dbgl && plive) {                        // test hook: the 30 logits of every segment
                 dbgl[((size_t)t * Nall + b0g + pj) * C + pu] = get_partial<3>(PW, 0, pu, pj) + fc3b[pu];

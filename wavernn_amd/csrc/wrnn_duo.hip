@@ -643,6 +643,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     const int cbase = cl * DSLOTB;
     auto slot_nb = [&](int i) -> int { return (int)((nbpack >> (8 * i)) & 255u); };
 
+    const bool fresh_y2 = (a.tuning & 16) != 0;
     const bool prio_smp = (a.tuning & 32) == 0;          // the sampling stage (on its slot's chain) runs at wave priority 3 (round 6: 16.1 vs 16.4 us per step at 2 slots, 22.56 vs 22.72 at 4; A/B: tuning bit 5 = off)
     bool dead = false;
     int pp = 0;
@@ -777,6 +778,13 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         };
         if (PROF && tid == 0 && plast == 0) plast = __builtin_amdgcn_s_memtime();
         tri = cy.i;
+        if (kind == 3 && fresh_y2) {
+            // the sampling stage is on its slot's chain and its look-ahead request went out in FRONT of the gh stage's MFMA block: ask again now -- the pending
+            // back half covers most of the L2 round trip -- instead of finding the old sentinel behind it and polling from there (round 6)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, soff_x, 16 /* sc1 */);
+            xahead = true;
+        }
         run_back();                                     // (publish first: profiles/r04g_probe_*.json)
         cur = kind == 1 ? 0 : 8;
         tri = i;
