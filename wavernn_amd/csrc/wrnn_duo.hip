@@ -644,6 +644,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
     auto slot_nb = [&](int i) -> int { return (int)((nbpack >> (8 * i)) & 255u); };
 
     const bool fresh_y2 = (a.tuning & 16) != 0;
+
     const bool prio_smp = (a.tuning & 32) == 0;          // the sampling stage (on its slot's chain) runs at wave priority 3 (round 6: 16.1 vs 16.4 us per step at 2 slots, 22.56 vs 22.72 at 4; A/B: tuning bit 5 = off)
     bool dead = false;
     int pp = 0;
@@ -750,6 +751,12 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             }
         }
     };
+    // Round 6: the gh block (96 back-to-back MFMAs, off every chain) is held back by a few 512-cycle units where that was measured to pay: it starts ~one hop
+    // behind the ih workgroup's h publication and ran into that workgroup's NEXT back half -- f32 MFMA and VALU do not overlap on a SIMD, a VALU
+    // instruction beside an MFMA stream waits for the MFMA in flight (profiles/r06x_trace_d4.txt: back halves of 1.3 k cycles stretched to 3-5 k;
+    // scripts/micro/mfma_valu_coexec.hip).  profiles/r06at_gh_delay.log, us per step without / with: 4 slots 22.07 / 21.73 (3 units), 5: 25.58 /
+    // 25.00 (2), 6: 29.26 / 28.80 (2); 2, 3 and 8 slots: slower.  wrnn_options.tuning bits 16-19: units + 1 (A/B).
+    const int gh_delay = ((a.tuning >> 16) & 15) ? ((a.tuning >> 16) & 15) - 1 : (MOL ? (nact == 4 ? 3 : (nact == 5 || nact == 6) ? 2 : 0) : 0);
     enum { BK_NONE = 0, BK_GH = 1, BK_SAMPLE = 2, BK_ANY = 3, BK_LG = 4 };
     int pend = BK_NONE;                                 // run-time kind of the pending half, read only where two kinds can meet (BK_ANY sites)
     int last_here = nact - 1;                           // the last gh stage in front of a step's other stages (see the step loop)
@@ -866,6 +873,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         PHX(cur + 4);
         float *PW = DPARTOF(pp);
         if constexpr (kind == 1) {
+            for (int q = 0; q < gh_delay; ++q) __builtin_amdgcn_s_sleep(8);       // (see gh_delay at the step loop)
             f32x4 o0, o1, o2;
             if constexpr ((DUO_ABLATE & 2) != 0) { o0 = mfma1(A_hh[0], b); o1 = o0; o2 = o0; }
             else mfma3s(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
