@@ -751,12 +751,16 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
             }
         }
     };
-    // Round 6: the gh block (96 back-to-back MFMAs, off every chain) is held back by a few 512-cycle units where that was measured to pay: it starts ~one hop
-    // behind the ih workgroup's h publication and ran into that workgroup's NEXT back half -- f32 MFMA and VALU do not overlap on a SIMD, a VALU
-    // instruction beside an MFMA stream waits for the MFMA in flight (profiles/r06x_trace_d4.txt: back halves of 1.3 k cycles stretched to 3-5 k;
-    // scripts/micro/mfma_valu_coexec.hip).  profiles/r06at_gh_delay.log, us per step without / with: 4 slots 22.07 / 21.73 (3 units), 5: 25.58 /
-    // 25.00 (2), 6: 29.26 / 28.80 (2); 2, 3 and 8 slots: slower.  wrnn_options.tuning bits 16-19: units + 1 (A/B).
-    const int gh_delay = ((a.tuning >> 16) & 15) ? ((a.tuning >> 16) & 15) - 1 : (MOL ? (nact == 4 ? 3 : (nact == 5 || nact == 6) ? 2 : 0) : 0);
+    // Round 6: the gh block -- 96 back-to-back MFMAs, off every chain -- is BROKEN UP: a compare + scalar branch behind every three MFMAs and a 64-cycle
+    // yield (s_sleep 1) behind every twelve.  f32 MFMA and VALU do not overlap on a SIMD (scripts/micro/mfma_valu_coexec.hip: the times ADD), and an
+    // instruction of the ih wave beside an MFMA stream of this wave waits for the MFMA in flight: the block starts ~one hop behind the ih workgroup's
+    // h publication and ran into that workgroup's NEXT back half, which is on its slot's chain (profiles/r06x_trace_d4.txt: back halves of 1.3 k cycles
+    // stretched to 3-5 k).  Measured on one box (profiles/r06bb_gh_branchy.log, us per step at 2 / 4 / 8 slots): 14.4 / 20.6 / 36.0 against 15.2 / 22.3 /
+    // 38.1 for the unbroken block.  Also measured: the yields pinned at compile time without the branches (no gain: r06ay), the branches without the yields
+    // (21.8 / 37.5), 16-64 idle cycles (s_nop) behind every three MFMAs instead (21.4 at 4 slots, slower at 8: r06ba), the whole block held back by 1-1.5 k
+    // cycles (-1.6 % at 4 slots only: r06at), static wave priorities (nothing).  wrnn_options.tuning bit 20: the unbroken block; bits 21-25: yield length / spacing (A/B).
+    const bool gh_yield = (a.tuning & 0x100000) == 0 && nact >= 2;      // (one slot: 11.9 vs 11.6 us per step -- nothing of the ih workgroup to let through)
+    const int gh_chunk = ((a.tuning >> 21) & 3) == 3 ? 0 : 1 + ((a.tuning >> 21) & 3), gh_gran = 3 ^ ((a.tuning >> 23) & 7);
     enum { BK_NONE = 0, BK_GH = 1, BK_SAMPLE = 2, BK_ANY = 3, BK_LG = 4 };
     int pend = BK_NONE;                                 // run-time kind of the pending half, read only where two kinds can meet (BK_ANY sites)
     int last_here = nact - 1;                           // the last gh stage in front of a step's other stages (see the step loop)
@@ -873,10 +877,21 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
         PHX(cur + 4);
         float *PW = DPARTOF(pp);
         if constexpr (kind == 1) {
-            for (int q = 0; q < gh_delay; ++q) __builtin_amdgcn_s_sleep(8);       // (see gh_delay at the step loop)
             f32x4 o0, o1, o2;
             if constexpr ((DUO_ABLATE & 2) != 0) { o0 = mfma1(A_hh[0], b); o1 = o0; o2 = o0; }
-            else mfma3s(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
+            else if (gh_yield) {
+                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_hh[0][k], b[k], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_hh[1][k], b[k], c1, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_hh[2][k], b[k], c2, 0, 0, 0);
+                    // (gh_gran / gh_chunk are RUN-TIME values on purpose: the test below compiles to a compare + a taken scalar branch behind every k -- behind every
+                    // three MFMAs -- and it is THAT broken-up stream, more than the three yields, that lets the ih wave's instructions through; see gh_yield)
+                    if ((k & gh_gran) == gh_gran && k < 31) { for (int q = 0; q < gh_chunk; ++q) __builtin_amdgcn_s_sleep(1); }
+                }
+                o0 = c0; o1 = c1; o2 = c2;
+            } else mfma3s(A_hh[0], A_hh[1], A_hh[2], b, o0, o1, o2);
             put_partial<3>(PW, w, 0, lane, o0);
             put_partial<3>(PW, w, 1, lane, o1);
             put_partial<3>(PW, w, 2, lane, o2);
