@@ -65,7 +65,7 @@ enum {
                                and four service waves (partial sums, GRU cell, publishes, conditioning, fc3 + sampling) that meet through LDS counters;
                                gh never leaves the CU.  Same split, workspace, exchange buffer and state layout as WRNN_ALGO_DUO (csrc/wrnn_octo.hip) */
     WRNN_ALGO_SPARSE = 5    /* block-sparse GRU kernel (MOL; BASELINE config 5): needs GRU matrices whose 16x1 block rows keep <= 64 columns
-                               (wrnn_pack_sparse_blocks) and a 256-CU device; 16 clusters of 16 CUs, ONE group of <= 16 segments each: a
+                               (wrnn_pack_sparse_blocks) and a 256-CU device; fc1 / fc2 are gathered too when they are block-sparse (wrnn_pack_sparse_fc_blocks); 16 clusters of 16 CUs, ONE group of <= 16 segments each: a
                                step is the latency of one chain, sixteen chains run side by side (csrc/wrnn_sparse.hip) */
 };
 
@@ -144,12 +144,16 @@ typedef struct wrnn_options {
                                   at the stage barriers, bit 2 = no fused stages, bit 3 = RAW sampled by role A alone, bit 4 = RAW: one
                                   sampling workgroup per slot, bit 5 / bit 6 = never / always start a stage with the pending back half
                                   (default: up to 2 groups in flight), bit 7 = library exp / tanh in the MoL gate math;
-                                wrnn_duo_kernel: bit 0 = the ih workgroups load a stage's operand into registers, bit 1 = they fetch it into LDS one
-                                  stage ahead (default: by depth, from 6 groups in flight), bit 2 = re-fill the exchange ring with the sentinel
-                                  before EVERY launch, bit 6 = placement read-out through phase_clocks (test hook), bit 8 = every layer written
+                                wrnn_duo_kernel: bit 0 = the ih workgroups load a stage's operand into registers BEHIND the pending back half, bit 9 = in front
+                                  of it (default: from 4 groups in flight), bit 1 = they fetch it into LDS one stage ahead (on request only), bit 2 = re-fill
+                                  the exchange ring with the sentinel before EVERY launch, bit 3 = no second request for x_{t-1}, bit 4 = a fresh y2 request
+                                  at the top of the sampling stage, bit 5 = sampling stage at wave priority 0, bit 7 = the residual input word requested beside
+                                  the operand loads (round 5), bit 20 = the hh workgroups' gh block as ONE unbroken MFMA stream (bits 21-25: yield length /
+                                  spacing of the broken one), bit 6 = placement read-out through phase_clocks (test hook), bit 8 = every layer written
                                   through (no XCD-local plain stores), bit 14 = with phase_clocks: the stage time line of three steps as well
                                   (phase_clocks then holds [256 * 32 + 512 * 512] words; scripts/gpu_duo_trace.py);
-                                wrnn_sparse_kernel, wrnn_chain_kernel: bits 2, 8 as wrnn_duo_kernel.
+                                wrnn_sparse_kernel, wrnn_chain_kernel: bits 2, 8 as wrnn_duo_kernel; wrnn_sparse_kernel: bit 11 = the DENSE fc stages on a pack whose
+                                  Linear layers are block-sparse too; wrnn_chain_kernel: bit 5 = MoL's fc3 tiles read from LDS (round 5).
                                 When the two-workgroups-per-CU grid of wrnn_duo_kernel is refused the call returns WRNN_ERR_RESIDENCY; the
                                 caller may run it again with WRNN_ALGO_LOOP (another workspace layout: query its size) or _STREAM. */
     const float *force_x;    /* test hook, device [n,T]: value fed back as x_t instead of the sample (teacher forcing) */

@@ -184,9 +184,9 @@ def wavernn_pruner(model, start_prune, prune_steps, target_sparsity=0.95, prune_
     """`Pruner` over a WaveRNN's recurrent layers (both weight matrices of rnn1 and rnn2; with `prune_fc` also fc1 / fc2, the
     notebook's `splits['Linear']` case) in the 16x1 block structure the block-sparse loop kernel packs.  Returns
     (pruner, layers): call `pruner.prune(layers, step)` after every optimiser step, then `model.generate()` -- the device weight
-    pack is rebuilt after every pruning step (`Pruner.on_change` -> `WaveRNN.invalidate_engines`); `model.loop_algo = 'sparse'` runs
-    `wrnn_sparse_kernel` once every block row is sparse enough (`LoopEngine.sparse_blocks`; `auto` stays on the dense duo kernel, which is
-    the faster of the two since round 4)."""
+    pack is rebuilt after every pruning step (`Pruner.on_change` -> `WaveRNN.invalidate_engines`); `auto` runs `wrnn_sparse_kernel` once
+    every block row is sparse enough (`LoopEngine.sparse_blocks`), and its gathered fc stages when `prune_fc` has made fc1 / fc2 block-sparse
+    too (`LoopEngine.sparse_fc_blocks`; round 6)."""
     layers = [model.rnn1, model.rnn2] + ([model.fc1, model.fc2] if prune_fc else [])
     if prune_fc and block is not None and (model.fc1.weight.size(1) % block[1] or model.fc1.weight.size(0) % block[0]):
         raise ValueError('fc weights do not tile by the block')
