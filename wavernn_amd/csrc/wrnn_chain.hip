@@ -51,7 +51,7 @@ static_assert(CHCL * CHMAXG <= LMAXG * MAXCL, "one exchange-buffer region per (s
 static_assert(SEG * LDC <= 2 * XT, "RAW logits fit the fc3 region");
 
 struct ChLds {
-    int off_seg, off_geo, off_st, off_part, off_misc, off_prof, off_b3, off_f3, total;
+    int off_seg, off_geo, off_st, off_part, off_misc, off_prof, off_b3, off_y2t, off_f3, total;
 };
 __host__ __device__ inline ChLds ch_lds(int G)
 {
@@ -64,6 +64,7 @@ __host__ __device__ inline ChLds ch_lds(int G)
     l.off_misc = o; o += 64;                 // placement table of the cluster (ints)
     l.off_prof = o; o += 64;                 // [32] u64 phase clocks (profiling builds)
     l.off_b3 = o;   o += 32;                 // sampling workgroups: fc3.bias
+    l.off_y2t = o;  o += 256;                // rnn2 (MOL, fc3 folded into the fc2 stage): the workgroup's y2 tile [row][segment]
     o = (o + 3) & ~3;
     l.off_f3 = o;   o += 2 * XT;             // ... MOL: fc3 (30 x 512 = two 16-row tiles) in A-fragment order; RAW: the gathered logits [segment][class], stride LDC
     l.total = o;
@@ -92,7 +93,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
 {
     const int G = a.G;
     const ChLds L = ch_lds(G);
-    float *PART = smem + L.off_part, *fc3b = smem + L.off_b3, *F3 = smem + L.off_f3, *ST = smem + L.off_st;
+    float *PART = smem + L.off_part, *fc3b = smem + L.off_b3, *F3 = smem + L.off_f3, *ST = smem + L.off_st, *Y2T = smem + L.off_y2t;
     int *SEGT = reinterpret_cast<int *>(smem + L.off_seg), *GEO = reinterpret_cast<int *>(smem + L.off_geo);
     u64 *PROFL = reinterpret_cast<u64 *>(smem + L.off_prof);
     u64 plast = 0;
@@ -143,6 +144,17 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
                 }
         }
     }
+    // MOL, rnn2 (round 6): fc3 FOLDED into the fc2 stage -- this workgroup multiplies ITS 16 rows of y2 through fc3's columns [16 J, 16 J + 16) (two 16-row
+    // tiles x 4 MFMAs, wave 0) and publishes the two partial logit tiles instead of y2; the sampling workgroup adds the 32 workgroups' tiles instead of running
+    // 64 MFMAs per wave on its slot's chain.  A3[q][i]: row 16 q + fi of fc3, column 16 J + 4 i + kq (K-slot kq of MFMA i <-> y2 row 4 i + kq).
+    bool fold3 = false;                                 // (set below: one slot only -- with two the rnn2 workgroups are the busy side: 13.84 vs 13.57 us per step; A/B: tuning bit 4 = off)
+    float A3[2][4];
+    if constexpr (!LA && MOL) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A3[q][i] = (16 * q + fi < C) ? a.fc3_w[(size_t)(16 * q + fi) * H + LU * J + 4 * i + kq] : 0.f;
+    }
     float b3 = 0.f;
     if constexpr (LA && !MOL) {
         load_afrag(A_f3, a.fc3_w, H, LU * J + fi, true, kbase_lane);
@@ -181,6 +193,7 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
         if (resume) sv = *reinterpret_cast<const float4 *>(state_wg + (size_t)i * CHSTATE_SLOT + tid * 4);
         ST[(i * 8 + 0) * NT + tid] = sv.x; ST[(i * 8 + 1) * NT + tid] = sv.y; ST[(i * 8 + 2) * NT + tid] = sv.z; ST[(i * 8 + 3) * NT + tid] = sv.w;
     }
+    fold3 = MOL && nact == 1 && (a.tuning & 16) == 0;
     // MOL: rnn1's workgroup i runs fc3 + the sampling of slot i.  RAW: FOUR workgroups per slot -- workgroup J samples segments 4 (J & 3) .. + 3 of slot
     // J >> 2, one segment per wave (the 512-class softmax of 16 segments on one workgroup took ~8 us of the chain: profiles/r05k_probe_raw_chain.json)
     const bool sampler = LA && J < (MOL ? nact : 4 * nact);
@@ -355,21 +368,39 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             const int nvo = (int)(((size_t)(t - noise_t0) * 11 * Nall) * 4);
             const float nz0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(nrs, ((b0g + suc) * 10 + (sm < 10 ? sm : 9)) * 4, nvo, 0));
             const float nz1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(nrs, (10 * Nall + b0g + suc) * 4, nvo, 0));
-            u32x4 x[8];
+            // x[r] = this wave's fragments of y2 -- or, fc3 folded into the fc2 stage (fold3): the tile-0 partial logits of workgroups 8 w + r (rows 4 kq + e of
+            // segment fi: the accumulators' layout; the same addresses), x1[r] = their tile-1 partial logits (layer 16)
+            u32x4 x[8], x1[8];
+            auto ask = [&] {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 3 * DLAYERB, 16 /* sc1 */);
-            if (__builtin_expect(!frag_there(x, live), 0))
-                wait_for([&] { return frag_there(x, live); },
-                         [&] {
+                for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 3 * DLAYERB, 16 /* sc1 */);
+                if (fold3) {
 #pragma unroll
-                             for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 3 * DLAYERB, 16 /* sc1 */);
-                         },
-                         status, dead, 0x850u, t);
+                    for (int r = 0; r < 8; ++r) x1[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 16 * DLAYERB, 16 /* sc1 */);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) x1[r] = u32x4{0u, 0u, 0u, 0u};
+                }
+            };
+            ask();
+            if (__builtin_expect(!(frag_there(x, live) && frag_there(x1, live)), 0))
+                wait_for([&] { return frag_there(x, live) && frag_there(x1, live); }, ask, status, dead, 0x850u, t);
             CHX(7);
+            float *PW = PART + pp * (NW * 3 * 256);
+            if (fold3) {
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    s0 += f32x4{__uint_as_float(x[r].x), __uint_as_float(x[r].y), __uint_as_float(x[r].z), __uint_as_float(x[r].w)};
+                    s1 += f32x4{__uint_as_float(x1[r].x), __uint_as_float(x1[r].y), __uint_as_float(x1[r].z), __uint_as_float(x1[r].w)};
+                }
+                put_partial<3>(PW, w, 0, lane, s0);
+                put_partial<3>(PW, w, 1, lane, s1);
+            }
             float b[32];
             frag_to_b(x, b);
-            float *PW = PART + pp * (NW * 3 * 256);
-            if (f3_lds) {
+            if (fold3) {
+            } else if (f3_lds) {
                 put_partial<3>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
                 put_partial<3>(PW, w, 1, lane, mfma1_lds(F3 + XT + frag_off(w, 0, lane), b));
             } else {
@@ -588,12 +619,33 @@ __device__ __forceinline__ void ch_role(const LoopArgs &a, float *smem, const in
             float s0, s1, s2;
             unsigned dummy = 0u;
             stage(N1{}, AGR{}, A_fc2, A_fc2, A_fc2, sb + 2 * DLAYERB, nb, 0x802u, t, 4, s0, s1, s2, dummy, false);
-            publish4l(xrs, sb + 3 * DLAYERB + J * 1024, tid, fmaxf(s0 + cv, 0.f), pj < nb, false);
+            const float y2v = fmaxf(s0 + cv, 0.f);
+            if (fold3) {
+                Y2T[pu * 16 + pj] = y2v;                // (the next workgroup barrier -- the gh stage's -- lies between wave 0's reads below and the next writes)
+                lds_barrier();
+                if (w == 0) {
+                    float yb[4];
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) yb[k4] = Y2T[(4 * k4 + kq) * 16 + fi];
+                    const u32x4 sv = {SENT, SENT, SENT, SENT};
+                    const int so2 = cbase_of(i) + ((t + DAHEAD_IH) & (DRING - 1)) * XTB;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4) c = __builtin_amdgcn_mfma_f32_16x16x4f32(A3[q][k4], yb[k4], c, 0, 0, 0);
+                        const u32x4 qv = {__float_as_uint(c[0]), __float_as_uint(c[1]), __float_as_uint(c[2]), __float_as_uint(c[3])};
+                        // partial logits, rows 16 q + 4 kq + e of segment fi: layer 3 (tile 0) / 16 (tile 1), block J, to the sampling workgroup's XCD
+                        if (fi < nb) __builtin_amdgcn_raw_buffer_store_b128(qv, xrs, (q == 0 ? 3 : 16) * DLAYERB + J * 1024 + lane * 16, sb, 16 /* sc1 */);
+                        __builtin_amdgcn_raw_buffer_store_b128(sv, xrs, (q == 0 ? 3 : 16) * DLAYERB + J * 1024 + lane * 16, so2, 16 /* sc1 */);      // ring hygiene (as rearm1)
+                    }
+                }
+            } else publish4l(xrs, sb + 3 * DLAYERB + J * 1024, tid, y2v, pj < nb, false);
             // ring hygiene: behind the last poll of the slot's step (y1(t): everybody is past the readers of step t - 2) and behind the publication
             rearm1(i, 1, 0, loc_b);
             rearm1(i, 6, 1, loc_x2);
             rearm1(i, 2, 2, loc_y1);
-            rearm1(i, 3, 3, false);
+            if (!fold3) rearm1(i, 3, 3, false);
             CHX(5);
         };
         for (; t < T1; ++t) {
