@@ -236,6 +236,17 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
             load_afrag(A_fc2[q], a.fc2_w, H + AUX, 2 * LU * wgi + LU * q + fi, true, kbase_lane);
         }
     }
+    // FCS: fc3 FOLDED into the fc2 tiles (as wrnn_chain.hip, round 6): a wave that owns an fc2 row block multiplies ITS 16 rows of y2 through fc3's columns of
+    // those rows -- two 16-row tiles x 4 MFMAs; K-slot kq of MFMA e <-> row 4 kq + e, i.e. the B operand IS the lane's accumulator element e: no data moves --
+    // and publishes two partial logit tiles (layers 3 and 16) instead of y2; the sampling workgroup adds the 32 waves' tiles instead of running 64 MFMAs per wave.
+    const bool fold3 = FCS && (a.tuning & 16) == 0;     // (A/B: tuning bit 4 = y2 published, dense fc3 on the sampling workgroup)
+    float A3[2][4];
+    if constexpr (FCS) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) A3[q][e] = (16 * q + fi < C) ? a.fc3_w[(size_t)(16 * q + fi) * H + LU * (2 * wgi + (w & 1)) + 4 * kq + e] : 0.f;
+    }
     for (int q = tid; q < L.off_f3; q += NT) smem[q] = 0.f;
     if (sampler) {                                      // fc3 -> LDS (fragment order as in the pack)
         for (int q = tid; q < 2 * XT / 4; q += NT) reinterpret_cast<float4 *>(F3)[q] = reinterpret_cast<const float4 *>(a.fc3f)[q];
@@ -341,7 +352,10 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
     auto rearm = [&]() {
         const int so = cbase + ((t + DAHEAD_IH) & (DRING - 1)) * XTB;
         const u32x4 q = {SENT, SENT, SENT, SENT};
-        if constexpr (FCS) store16(q, (w < 2 ? 2 : 3) * DLAYERB + (2 * wgi + (w & 1)) * 1024 + lane * 16, so);      // the wave's OWN 1 KB block of y1 (k-major) / y2
+        if constexpr (FCS) {
+            store16(q, (w < 2 ? 2 : 3) * DLAYERB + (2 * wgi + (w & 1)) * 1024 + lane * 16, so);      // the wave's OWN 1 KB block of y1 (k-major) / y2 (fold3: tile-0 partial logits)
+            if (fold3 && w >= 2) store16(q, 16 * DLAYERB + (2 * wgi + (w & 1)) * 1024 + lane * 16, so);       // ... and the tile-1 partial logits
+        }
         else store16(q, (kq < 2 ? 2 : 3) * DLAYERB + (2 * wgi + (kq & 1)) * 1024 + w * 256 + fi * 16, so);
         store16(q, L_H * DLAYERB + voff_blk, so);
         store16(q, L_XR * DLAYERB + voff_blk, so);
@@ -387,6 +401,18 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
                 u32x4 q;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) q[e] = __float_as_uint(fmaxf(acc[e] + __uint_as_float(cv[e]), 0.f));      // relu(fc([x, a]) + b): the aux columns and the bias sit in the per-frame table
+                u32x4 pl[2] = {q, q};
+                if constexpr (which == 2) {
+                    if (fold3) {                            // (whole-wave MFMAs: outside the per-lane `live` branch; a column of an absent segment is never stored)
+#pragma unroll
+                        for (int tl = 0; tl < 2; ++tl) {
+                            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(A3[tl][e], __uint_as_float(q[e]), c, 0, 0, 0);
+                            pl[tl] = u32x4{__float_as_uint(c[0]), __float_as_uint(c[1]), __float_as_uint(c[2]), __float_as_uint(c[3])};
+                        }
+                    }
+                }
                 if (live) {
                     if constexpr (which == 1) {             // y1: gathered by the fc2 tiles -> k-major
 #pragma unroll
@@ -394,6 +420,9 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
                             if (loc) __builtin_amdgcn_raw_buffer_store_b32(q[e], xrs, LO * DLAYERB + (r0 + e) * 64 + fi * 4, sb, 0);
                             else __builtin_amdgcn_raw_buffer_store_b32(q[e], xrs, LO * DLAYERB + (r0 + e) * 64 + fi * 4, sb, 16 /* sc1 */);
                         }
+                    } else if (fold3) {                     // partial logits of this wave's 16 y2 rows: tile 0 -> layer 3, tile 1 -> layer 16 (block = the fc2 row block)
+                        store16(pl[0], 3 * DLAYERB + (2 * wgi + (w & 1)) * 1024 + lane * 16, sb);
+                        store16(pl[1], 16 * DLAYERB + (2 * wgi + (w & 1)) * 1024 + lane * 16, sb);
                     } else store16(q, LO * DLAYERB + (2 * wgi + (w & 1)) * 1024 + lane * 16, sb);      // y2: read by the dense fc3 of the sampling workgroup -> fragment order
                 }
                 rearm();                                // (behind this wave's last sentinel poll of the step; tests/test_sparse_exchange_model.py, SparseFcSim)
@@ -579,27 +608,45 @@ __device__ __forceinline__ void sp_role(const LoopArgs &a, float *smem, const in
     // rnn2's workgroup 0: fc3 (30 x 512: two 16-row tiles in A-fragment order, in LDS) + the mixture-of-logistics sampling of step t
     auto sample = [&]() {
         const int sb = cbase + (t & (DRING - 1)) * XTB;
-        u32x4 x[8];
+        // x[r] = this wave's fragments of y2 -- or (fold3) the tile-0 partial logits of the fc2 row blocks 8 w + r (rows 4 kq + e of segment fi: the
+        // accumulators' layout, the same addresses); x1[r]: their tile-1 partial logits (layer 16)
+        u32x4 x[8], x1[8];
+        auto ask = [&] {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 3 * DLAYERB, 16 /* sc1 */);
+            for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 3 * DLAYERB, 16 /* sc1 */);
+            if (fold3) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) x1[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 16 * DLAYERB, 16 /* sc1 */);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) x1[r] = u32x4{0u, 0u, 0u, 0u};
+            }
+        };
+        ask();
         const int su = tid >> 4, sm = tid & 15;         // sampling role: 16-lane row = segment su, lane sm = mixture
         const float *nrow = noise_pre + (size_t)(t - noise_t0) * 11 * Nall;
         const int suc = su < nb ? su : nb - 1;
         const float nz0 = nrow[(size_t)(b0g + suc) * 10 + (sm < 10 ? sm : 9)];
         const float nz1 = nrow[(size_t)10 * Nall + b0g + suc];
-        if (__builtin_expect(!frag_there(x, live), 0))
-            wait_for([&] { return frag_there(x, live); },
-                     [&] {
-#pragma unroll
-                         for (int r = 0; r < 8; ++r) x[r] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff_frag + r * 1024, sb + 3 * DLAYERB, 16 /* sc1 */);
-                     },
-                     status, dead, 0x750u, t);
+        if (__builtin_expect(!(frag_there(x, live) && frag_there(x1, live)), 0))
+            wait_for([&] { return frag_there(x, live) && frag_there(x1, live); }, ask, status, dead, 0x750u, t);
         SPX(8);
-        float b[32];
-        frag_to_b(x, b);
         float *PW = PART + pp * (NW * 2 * 256);
-        put_partial<2>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
-        put_partial<2>(PW, w, 1, lane, mfma1_lds(F3 + XT + frag_off(w, 0, lane), b));
+        if (fold3) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                s0 += f32x4{__uint_as_float(x[r].x), __uint_as_float(x[r].y), __uint_as_float(x[r].z), __uint_as_float(x[r].w)};
+                s1 += f32x4{__uint_as_float(x1[r].x), __uint_as_float(x1[r].y), __uint_as_float(x1[r].z), __uint_as_float(x1[r].w)};
+            }
+            put_partial<2>(PW, w, 0, lane, s0);
+            put_partial<2>(PW, w, 1, lane, s1);
+        } else {
+            float b[32];
+            frag_to_b(x, b);
+            put_partial<2>(PW, w, 0, lane, mfma1_lds(F3 + frag_off(w, 0, lane), b));
+            put_partial<2>(PW, w, 1, lane, mfma1_lds(F3 + XT + frag_off(w, 0, lane), b));
+        }
         lds_barrier();
         if (dbgl && pj < nb) {                          // test hook: the 30 logits of every segment (thread: rows pu and 16 + pu, segment pj)
             dbgl[((size_t)t * Nall + b0g + pj) * C + pu] = get_partial<2>(PW, 0, pu, pj) + b3a;
