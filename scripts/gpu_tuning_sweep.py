@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument('--depths', default='2,4,8'); ap.add_argument('--tunings', default='0'); ap.add_argument('--T', type=int, default=1500)
 ap.add_argument('--reps', type=int, default=2); ap.add_argument('--mode', default='MOL'); ap.add_argument('--algo', default='duo')
-ap.add_argument('--so', default=None); ap.add_argument('--out', default=None)
+ap.add_argument('--so', default=None); ap.add_argument('--out', default=None); ap.add_argument('--stride', type=int, default=64, help='distance of two segments in the conditioning (the corpus: 11550)')
 a = ap.parse_args()
 if a.so:
     from wavernn_amd import _lib as _L
@@ -19,7 +19,7 @@ from wavernn_amd.synthetic import random_state_dict
 dev = torch.device('cuda', 0)
 eng = LoopEngine(random_state_dict(0, mode=a.mode), a.mode, device=dev)
 rs = np.random.RandomState(3)
-hop, stride = 275, 64
+hop, stride = 275, a.stride
 rows = []
 for d in [int(x) for x in a.depths.split(',')]:
     B = 64 * d

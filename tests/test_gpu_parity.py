@@ -121,6 +121,7 @@ def test_device_selftests(gpu):
     print(L.wrnn_last_error().decode())
     _lib.check(L.wrnn_selftest(0, 2), 'all-gather selftest')
     _lib.check(L.wrnn_selftest(0, 3), 'tanh_sel == tanhf selftest')     # the fused stages' branch-free tanh, bit for bit
+    _lib.check(L.wrnn_selftest(0, 4), 'xor_pair == __shfl_xor selftest')  # the RAW sampler's DPP / permlane-swap butterflies, bit for bit
     print(L.wrnn_last_error().decode())
 
 

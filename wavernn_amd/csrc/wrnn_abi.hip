@@ -45,6 +45,7 @@ size_t chain_xbuf_bytes(int G);
 int selftest_mfma(char *msg, size_t n);
 int selftest_allgather(int n_cus, char *msg, size_t n, float *us_per_round);
 int selftest_tanh(char *msg, size_t n);
+int selftest_xor(char *msg, size_t n);
 }  // namespace wrnn
 
 using namespace wrnn;
@@ -999,6 +1000,7 @@ extern "C" int wrnn_selftest(int device, int which)
     if (which == 1) rc = selftest_mfma(msg, sizeof msg);
     else if (which == 2) rc = selftest_allgather(cus, msg, sizeof msg, &g_selftest_metric);
     else if (which == 3) rc = selftest_tanh(msg, sizeof msg);
+    else if (which == 4) rc = selftest_xor(msg, sizeof msg);
     else { set_err("unknown selftest %d", which); return WRNN_ERR_ARG; }
     if (rc != 0) { set_err("selftest %d failed: %s", which, msg); return WRNN_ERR_KERNEL; }
     set_err("selftest %d ok: %s", which, msg);

@@ -193,6 +193,69 @@ __device__ __forceinline__ float gru_update_sel(float gi_r, float gi_z, float gi
     return (h - n) * z + n;
 }
 
+// Butterfly exchanges of a 64-lane wave WITHOUT the LDS crossbar (round 6): the RAW sampler's five 6-level reductions were 30 dependent ds_bpermute_b32 --
+// ~100+ cycles each behind an lgkmcnt wait, on the slot's chain.  xor_pair<M>(v, a, b) leaves {a, b} = {v of this lane, v of lane ^ M} IN UNSPECIFIED ORDER
+// (gfx950's v_permlane32_swap / v_permlane16_swap hand the pair back either way round; M <= 8: DPP row_ror:8, row_shl:4 | row_shr:4 under bank masks,
+// quad_perm) -- for a combine that is symmetric in its operands (IEEE a + b == b + a, max, argmax with an index tie-break) the result is bit-identical
+// to `v op __shfl_xor(v, M, 64)`: the pairing of every level, hence the summation tree, is the same.  wrnn_selftest(device, 4) checks all six against
+// __shfl_xor on the device.
+template <int M> __device__ __forceinline__ void xor_pair_u(unsigned v, unsigned &a, unsigned &b)
+{
+    static_assert(M == 32 || M == 16 || M == 8 || M == 4 || M == 2 || M == 1, "xor_pair: lane mask");
+    if constexpr (M == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        a = r[0]; b = r[1];
+    } else if constexpr (M == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        a = r[0]; b = r[1];
+    } else if constexpr (M == 8) {
+        a = v; b = __builtin_amdgcn_update_dpp(0u, v, 0x128 /* row_ror:8 */, 0xF, 0xF, false);
+    } else if constexpr (M == 4) {
+        unsigned t = __builtin_amdgcn_update_dpp(0u, v, 0x104 /* row_shl:4: lane i <- i + 4 */, 0xF, 0x5 /* banks 0, 2 */, false);
+        t = __builtin_amdgcn_update_dpp(t, v, 0x114 /* row_shr:4: lane i <- i - 4 */, 0xF, 0xA /* banks 1, 3 */, false);
+        a = v; b = t;
+    } else if constexpr (M == 2) {
+        a = v; b = __builtin_amdgcn_update_dpp(0u, v, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false);
+    } else {
+        a = v; b = __builtin_amdgcn_update_dpp(0u, v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+    }
+}
+template <int M> __device__ __forceinline__ void xor_pair(float v, float &a, float &b)
+{
+    unsigned ua, ub;
+    xor_pair_u<M>(__float_as_uint(v), ua, ub);
+    a = __uint_as_float(ua); b = __uint_as_float(ub);
+}
+template <int M> __device__ __forceinline__ float wave_sum_level(float v) { float a, b; xor_pair<M>(v, a, b); return a + b; }
+template <int M> __device__ __forceinline__ float wave_max_level(float v) { float a, b; xor_pair<M>(v, a, b); return fmaxf(a, b); }
+// == for (m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64), bit for bit
+__device__ __forceinline__ float wave_sum64(float v)
+{
+    v = wave_sum_level<32>(v); v = wave_sum_level<16>(v); v = wave_sum_level<8>(v);
+    v = wave_sum_level<4>(v); v = wave_sum_level<2>(v); return wave_sum_level<1>(v);
+}
+__device__ __forceinline__ float wave_max64(float v)
+{
+    v = wave_max_level<32>(v); v = wave_max_level<16>(v); v = wave_max_level<8>(v);
+    v = wave_max_level<4>(v); v = wave_max_level<2>(v); return wave_max_level<1>(v);
+}
+// arg max with the smaller index on a tie (== the shuffle form: `if (ob > best || (ob == best && oi < bidx)) take the other`): every lane ends with the wave's pair
+template <int M> __device__ __forceinline__ void wave_argmax_level(float &best, int &bidx)
+{
+    float va, vb;
+    unsigned ia, ib;
+    xor_pair<M>(best, va, vb);
+    xor_pair_u<M>((unsigned)bidx, ia, ib);
+    const bool take_b = vb > va || (vb == va && (int)ib < (int)ia);
+    best = take_b ? vb : va;
+    bidx = (int)(take_b ? ib : ia);
+}
+__device__ __forceinline__ void wave_argmax64(float &best, int &bidx)
+{
+    wave_argmax_level<32>(best, bidx); wave_argmax_level<16>(best, bidx); wave_argmax_level<8>(best, bidx);
+    wave_argmax_level<4>(best, bidx); wave_argmax_level<2>(best, bidx); wave_argmax_level<1>(best, bidx);
+}
+
 // utils/distribution.py:106-108  logit_probs - log(-log(u))
 __device__ __forceinline__ float mol_gumbel(float lp, float u) { return lp - logf(-logf(u)); }
 

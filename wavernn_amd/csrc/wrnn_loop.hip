@@ -399,9 +399,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                                 for (int e = 0; e < 8; ++e) a.dbg_logits[((size_t)bt * Nall + b0 + 4 * w + s4) * C + lane + 64 * e] = lg[s4][e];
                     }
 #pragma unroll
-                    for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) mx[s4] = fmaxf(mx[s4], __shfl_xor(mx[s4], m, 64));
+                    for (int s4 = 0; s4 < 4; ++s4) mx[s4] = wave_max64(mx[s4]);      // (xor_pair butterflies, wrnn_device.h: == the __shfl_xor form bit for bit)
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
                         sum[s4] = 0.f;
@@ -409,9 +407,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                         for (int e = 0; e < 8; ++e) { lg[s4][e] = expf(lg[s4][e] - mx[s4]); sum[s4] += lg[s4][e]; }
                     }
 #pragma unroll
-                    for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) sum[s4] += __shfl_xor(sum[s4], m, 64);
+                    for (int s4 = 0; s4 < 4; ++s4) sum[s4] = wave_sum64(sum[s4]);
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
                         sum2[s4] = 0.f;
@@ -419,9 +415,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                         for (int e = 0; e < 8; ++e) { lg[s4][e] = lg[s4][e] / sum[s4]; sum2[s4] += lg[s4][e]; }
                     }
 #pragma unroll
-                    for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) sum2[s4] += __shfl_xor(sum2[s4], m, 64);
+                    for (int s4 = 0; s4 < 4; ++s4) sum2[s4] = wave_sum64(sum2[s4]);
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
                         best[s4] = -INFINITY;
@@ -433,13 +427,7 @@ __device__ __forceinline__ void loop_role(const LoopArgs &a, float *smem, int cl
                         }
                     }
 #pragma unroll
-                    for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) {
-                            const float ob = __shfl_xor(best[s4], m, 64);
-                            const int oi = __shfl_xor(bidx[s4], m, 64);
-                            if (ob > best[s4] || (ob == best[s4] && oi < bidx[s4])) { best[s4] = ob; bidx[s4] = oi; }
-                        }
+                    for (int s4 = 0; s4 < 4; ++s4) wave_argmax64(best[s4], bidx[s4]);
                     if (lane == 0) {
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4) {

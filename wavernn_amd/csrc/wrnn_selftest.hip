@@ -4,6 +4,7 @@
 //   2. granule all-gather: NWG co-resident workgroups publish + sweep {tag,value} granules for many rounds,
 //      every word checked, bounded spins; reports microseconds per round.
 //   3. tanh_sel (the branch-free tanh of the fused stages) == tanhf, bit for bit, over a dense sweep of arguments.
+//   4. xor_pair (DPP / v_permlane*_swap butterflies of the RAW sampler's reductions) == __shfl_xor, bit for bit.
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -87,6 +88,53 @@ int selftest_tanh(char *msg, size_t n)
     if (e != hipSuccess) { snprintf(msg, n, "kernel failed: %s", hipGetErrorString(e)); return 1; }
     snprintf(msg, n, "tanh_sel vs tanhf over 2^24 arguments: %u bit mismatches (first at 0x%08x)", h[0], h[1]);
     return h[0] == 0u ? 0 : 1;
+}
+
+// ---- xor_pair / wave_sum64 / wave_max64 / wave_argmax64 == the __shfl_xor forms, bit for bit ----------------------
+template <int M> __device__ __forceinline__ unsigned xor_pair_bad(unsigned v)
+{
+    unsigned a, b;
+    xor_pair_u<M>(v, a, b);
+    const unsigned o = (unsigned)__shfl_xor((int)v, M, 64);
+    return ((a == v && b == o) || (a == o && b == v)) ? 0u : 1u;
+}
+__global__ void selftest_xor_kernel(unsigned *mismatches)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned h = i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    // floats of mixed sign and magnitude (sums that round differently under another tree), every 7th wave small non-negative values with ties
+    float v = __uint_as_float((h & 0x807FFFFFu) | ((100u + (h >> 23 & 31u)) << 23));
+    if ((i >> 6) % 7u == 0u) v = (float)(h & 7u) * 0.125f;
+    unsigned bad = xor_pair_bad<32>(h) + xor_pair_bad<16>(h) + xor_pair_bad<8>(h) + xor_pair_bad<4>(h) + xor_pair_bad<2>(h) + xor_pair_bad<1>(h);
+    float s = v, m = v, best = v;
+    int bidx = (int)(threadIdx.x & 63u) + 64 * (int)(h & 7u);
+    int bi2 = bidx;
+    float b2 = best;
+    for (int k = 32; k >= 1; k >>= 1) {
+        s += __shfl_xor(s, k, 64);
+        m = fmaxf(m, __shfl_xor(m, k, 64));
+        const float ob = __shfl_xor(b2, k, 64);
+        const int oi = __shfl_xor(bi2, k, 64);
+        if (ob > b2 || (ob == b2 && oi < bi2)) { b2 = ob; bi2 = oi; }
+    }
+    wave_argmax64(best, bidx);
+    bad += __float_as_uint(wave_sum64(v)) != __float_as_uint(s);
+    bad += __float_as_uint(wave_max64(v)) != __float_as_uint(m);
+    bad += __float_as_uint(best) != __float_as_uint(b2) || bidx != bi2;
+    if (bad) atomicAdd(mismatches, bad);
+}
+int selftest_xor(char *msg, size_t n)
+{
+    unsigned *d, h = 0u;
+    if (hipMalloc(&d, 4) != hipSuccess) { snprintf(msg, n, "hipMalloc failed"); return 1; }
+    hipMemcpy(d, &h, 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(selftest_xor_kernel, dim3(1u << 12), dim3(256), 0, 0, d);
+    hipError_t e = hipDeviceSynchronize();
+    hipMemcpy(&h, d, 4, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) { snprintf(msg, n, "kernel failed: %s", hipGetErrorString(e)); return 1; }
+    snprintf(msg, n, "xor_pair / wave_sum64 / wave_max64 / wave_argmax64 vs __shfl_xor over 2^14 waves: %u mismatches", h);
+    return h == 0u ? 0 : 1;
 }
 
 // ---- all-gather ------------------------------------------------------------------------------------
