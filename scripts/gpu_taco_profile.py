@@ -6,7 +6,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tests'))
 from wavernn_amd.synthetic import random_tacotron_state_dict
 from wavernn_amd.tacotron import TacotronInference, text_to_ids
-ap = argparse.ArgumentParser(); ap.add_argument('--steps', type=int, default=800); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument('--steps', type=int, default=800); ap.add_argument('--so', default=None); a = ap.parse_args()
+if a.so:
+    from wavernn_amd import _lib as _L
+    _L.SO_PATH = os.path.abspath(a.so)
 dev = torch.device('cuda', 0)
 shapes = json.load(open(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'tacotron_shapes.json')))
 tts = TacotronInference(random_tacotron_state_dict(3, shapes), device=dev)

@@ -18,8 +18,7 @@ constexpr int GNT = 512;
 
 __device__ __forceinline__ float gblock_max(float v, float *buf, int tid)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    v = wave_max64(v);
     __syncthreads();
     if ((tid & 63) == 0) buf[tid >> 6] = v;
     __syncthreads();
@@ -30,8 +29,7 @@ __device__ __forceinline__ float gblock_max(float v, float *buf, int tid)
 }
 __device__ __forceinline__ float gblock_sum(float v, float *buf, int tid)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    v = wave_sum64(v);
     __syncthreads();
     if ((tid & 63) == 0) buf[tid >> 6] = v;
     __syncthreads();

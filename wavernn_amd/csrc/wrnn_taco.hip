@@ -62,12 +62,7 @@ struct TacoArgs {
     float stop_threshold;
 };
 
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum64(v); }      // (DPP / permlane-swap butterflies, wrnn_device.h: the same tree as the __shfl_xor loop, without the LDS crossbar)
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // dot(w[0..K), x[0..K)) with K a multiple of 4: lanes take float4 chunks round-robin; x in LDS.  Result in every lane.
