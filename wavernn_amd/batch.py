@@ -268,14 +268,15 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
                     n_rows = [pre.rows_of(frames[u]) for u in utts] if rows else None
                     mels_up = torch.empty(sum(n_rows) if rows else off, mels[utts[0]].size(1), dtype=torch.float32, device=device)
                     aux = torch.empty(off // hop, 4 * model.aux_dims, dtype=torch.float32, device=device)
-                    r0 = 0
+                    r0, jobs = 0, []
                     for k, u in enumerate(utts):
                         a0 = local_off[u]
                         if rows:
-                            pre.upsample_rows(mels[u].to(device).float(), rows=mels_up[r0:r0 + n_rows[k]], aux=aux[a0 // hop:a0 // hop + frames[u]])
+                            jobs.append((mels[u], mels_up[r0:r0 + n_rows[k]], aux[a0 // hop:a0 // hop + frames[u]]))
                             r0 += n_rows[k]
                         else:
-                            pre.upsample(mels[u].to(device).float(), mels_up=mels_up[a0:a0 + frames[u] * hop], aux=aux[a0 // hop:a0 // hop + frames[u]])
+                            jobs.append((mels[u], mels_up[a0:a0 + frames[u] * hop], aux[a0 // hop:a0 // hop + frames[u]]))
+                    pre.upsample_many(jobs, rows=rows, streams=int(getattr(model, 'pre_streams', 8)))      # (the utterances side by side on side streams)
                     if rows:       # utterance k of the chunk: its rows start 2 * indent * k samples later than its cropped samples do
                         from .engine import MelRows
                         indent, order = pre.pad * hop, {u: k for k, u in enumerate(utts)}
@@ -397,7 +398,15 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
             from .post import unfold_on_device
             wav, sl = unfold_on_device(segs, [first_of(u) for u in us], [int(plan.folds[u]) for u in us],
                                        [(frames[u] - 1) * hop for u in us], overlap, hop, model.n_classes, mu_law, True)
-            wav = wav.cpu().numpy()
+            if getattr(model, 'pinned_output', True):
+                # the finished audio (8 B per sample) into page-locked memory at the link's rate (a pageable copy is staged through bounce buffers);
+                # torch's caching host allocator hands the pages back to the next call; the returned arrays are views that keep the buffer alive
+                host = torch.empty(wav.shape, dtype=wav.dtype, pin_memory=True)
+                host.copy_(wav, non_blocking=True)
+                torch.cuda.current_stream(wav.device).synchronize()
+                wav = host.numpy()
+            else:
+                wav = wav.cpu().numpy()
             for (a, b), u in zip(sl, us):
                 outs[u] = wav[a:b]
             return

@@ -134,6 +134,10 @@ class WaveRNN(nn.Module):
         #: 'native' = the HIP pre-loop kernels (MFMA MelResNet + box-filter up-sampling, wrnn_pre_*);
         #: 'torch' = the nn.Modules below through PyTorch-ROCm (MIOpen)
         self.pre_algo = 'native'
+        #: generate_corpus: the pre-loop kernels of a chunk's utterances run side by side on this many side streams (1 = one after the other on the
+        #: current stream); the finished float64 audio comes back through page-locked memory (False: a pageable copy)
+        self.pre_streams = 8
+        self.pinned_output = True
         #: True = when the call runs on wrnn_duo_kernel / wrnn_sparse_kernel (and the pre-loop stage is 'native' with a last stretch factor of 11),
         #: the LAST up-sampling stage and the crop are formed inside the loop from that stage's input (`engine.MelRows`): the [L, feat]
         #: up-sampled mel is never written.  False = always materialise it (what every other loop kernel reads).  None (default) = by mode:

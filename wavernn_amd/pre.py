@@ -89,11 +89,39 @@ class PreEngine:
             aux = torch.empty(n, self.res_out_dims, dtype=torch.float32, device=self.device)
         assert mels_up.is_contiguous() and aux.is_contiguous() and mels_up.shape == (n_out, self.feat_dims)
         nbytes = int(self.lib.wrnn_pre_workspace_bytes(self._pre, n))
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        # one workspace per stream: `upsample_many` runs several utterances side by side on side streams
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(stream)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[stream] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         fn = self.lib.wrnn_pre_upsample_rows if _rows else self.lib.wrnn_pre_upsample
-        rc = fn(self._pre, mel.data_ptr(), n, mels_up.data_ptr(), aux.data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream)
+        rc = fn(self._pre, mel.data_ptr(), n, mels_up.data_ptr(), aux.data_ptr(), ws.data_ptr(), ws.numel(), stream)
         if rc != 0:
             raise _lib.WrnnError(f'wrnn_pre_upsample failed (rc={rc}): {self.lib.wrnn_pre_last_error().decode()}')
         return mels_up, aux
+
+    def upsample_many(self, jobs, rows=False, streams=8):
+        """jobs: [(mel, mels_up view, aux view)] -- the utterances of a chunk, each into its slice of the concatenated buffers.  An utterance's three
+        kernels fill 41 of the 256 CUs (641 frames) and depend on each other; the utterances do not: they run side by side on up to `streams` side
+        streams (own workspace each), forked from and joined to the current stream by events.  streams <= 1: one after the other on the current stream."""
+        if streams <= 1 or len(jobs) <= 1:
+            for mel, up, aux in jobs:
+                self.upsample(mel, mels_up=up, aux=aux, _rows=rows)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, '_side', None) is None or len(self._side) < streams:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(streams)]
+        mels = [mel[0] if mel.dim() == 3 else mel for mel, _, _ in jobs]
+        mels = [m.to(self.device, torch.float32).contiguous() for m in mels]      # (on the current stream, in front of the fork)
+        fork = cur.record_event()
+        used = self._side[:min(streams, len(jobs))]
+        for s in used:
+            s.wait_event(fork)
+        for k, (m, (_, up, aux)) in enumerate(zip(mels, jobs)):
+            with torch.cuda.stream(used[k % len(used)]):
+                self.upsample(m, mels_up=up, aux=aux, _rows=rows)
+        for s in used:
+            cur.wait_stream(s)                   # (the buffers were allocated on `cur` and are next used there: no record_stream needed)
+
