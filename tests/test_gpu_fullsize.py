@@ -32,14 +32,19 @@ def _model(sd, mode, gpu):
     return model.to(gpu)
 
 
+@pytest.mark.parametrize('mel_in_loop', [None, True], ids=['mel-default', 'mel-in-loop'])
 @pytest.mark.parametrize('name', BIG_CASES)
-def test_generate_full_size_matches_reference(gpu, name, tmp_path):
+def test_generate_full_size_matches_reference(gpu, name, mel_in_loop, tmp_path):
     """`WaveRNN.generate()` (all-HIP path, `auto` kernel) vs the waveform the reference itself returned for the same
-    weights / mel / `torch.manual_seed` -- BASELINE configs 2 and 3 (vocoder side) at T = 12,100."""
+    weights / mel / `torch.manual_seed` -- BASELINE configs 2 and 3 (vocoder side) at T = 12,100.  `mel-in-loop`: the opt-in form without
+    the [L, 80] up-sampled mel (`model.mel_in_loop = True`; MoL cases: RAW is compared class index by class index on the default path)."""
     from wavernn_amd.synthetic import random_state_dict
     cfg, g = load_case(name)
+    if mel_in_loop and cfg['mode'] == 'RAW':
+        pytest.skip('RAW: the materialised mel (model.mel_in_loop doc; the flip-rate measurement covers the in-loop form)')
     sd = random_state_dict(cfg['wseed'], mode=cfg['mode'])
     model = _model(sd, cfg['mode'], gpu)
+    model.mel_in_loop = mel_in_loop
     mel = case_mel(cfg, g)
     torch.manual_seed(cfg['seed'])
     out = model.generate(torch.tensor(mel).unsqueeze(0), tmp_path / 'o.wav', cfg['batched'], cfg['target'], cfg['overlap'], cfg['mu_law'])
@@ -265,19 +270,23 @@ def test_block_sparse_kernel_full_length_matches_oracle(gpu):
             assert np.abs(got - ref).max() <= MOL_TOL, (algo, u, np.abs(got - ref).max())
 
 
+@pytest.mark.parametrize('mel_in_loop', [None, True], ids=['mel-default', 'mel-in-loop'])
 @pytest.mark.parametrize('linear', [True, False], ids=['gru+linear', 'gru'])
-def test_config5_256_segments_matches_oracle(gpu, linear):
+def test_config5_256_segments_matches_oracle(gpu, linear, mel_in_loop):
     """(`linear`: fc1 / fc2 pruned with the GRUs, the notebook's recipe = `config.config5` since round 6 -- the gathered fc stages; else `config5_gru_only`.)
     BASELINE config 5 AS BENCHMARKED (`bench.py` `config.config5`): the GRU matrices 95 % block-sparse (16x1 blocks), 16 x 641-frame
-    utterances = 256 segments x 12,100 steps through `generate_corpus` -- HIP pre-loop kernels, the last up-sampling stage formed inside
-    the loop (wrnn_options.mel_stage = 1), `algo = auto` -> wrnn_sparse_kernel: all 16 clusters, one group each, one round --, parity
-    noise, against the C oracle on the masked dense weights per utterance (round-4 verdict: 256 segments, was 32).  The loop's
-    workspace must not depend on T."""
+    utterances = 256 segments x 12,100 steps through `generate_corpus` -- HIP pre-loop kernels; `mel-default`: the shipped default =
+    what the bench runs (the materialised mel since the last session of round 6), `mel-in-loop`: the last up-sampling stage formed inside
+    the loop (`model.mel_in_loop = True`, wrnn_options.mel_stage = 1: no [L, 80] mel is written) --, `algo = auto` -> wrnn_sparse_kernel: all
+    16 clusters, one group each, one round --, parity noise, against the C oracle on the masked dense weights per utterance (round-4
+    verdict: 256 segments, was 32).  The loop's workspace must not depend on T."""
     from helpers import oracle_utterance, pruned_state_dict
     from wavernn_amd.batch import generate_corpus
     from wavernn_amd.synthetic import random_mel
     sd = pruned_state_dict('MOL', 0, 0.95, linear)
     model = _model(sd, 'MOL', gpu)
+    assert model.mel_in_loop is None                  # the shipped default
+    model.mel_in_loop = mel_in_loop
     NU = 16
     mels = [torch.from_numpy(random_mel(1234 + u, 641)).unsqueeze(0) for u in range(NU)]
     segs, plan = generate_corpus(model, mels, TARGET, OVERLAP, True, [77 + u for u in range(NU)], return_segments=True)
@@ -287,7 +296,7 @@ def test_config5_256_segments_matches_oracle(gpu, linear):
     assert plan.n_segments == 256 and plan.T == 12100
     assert info['kernel'] == 'wrnn_sparse_kernel' and (info['clusters'], info['depth'], info['rounds']) == (16, 1, 1)
     assert (eng.sparse_fc_blocks > 0) == linear
-    assert model.mel_rows_ok(eng, 256, plan.T)
+    assert model.mel_rows_ok(eng, 256, plan.T) == bool(mel_in_loop)
     ws = [eng.workspace_bytes(256, T, 16 * 641) for T in (12100, 121000)]
     assert ws[0] == ws[1] and ws[0] < 300e6, ws
     refs = _pool_map(lambda u: oracle_utterance('MOL', 0, 0.95, 1234 + u, 77 + u, 641, want_cond=False, sd=sd, linear=linear)['ref'], list(range(NU)))
@@ -296,12 +305,13 @@ def test_config5_256_segments_matches_oracle(gpu, linear):
         assert np.abs(got - ref).max() <= MOL_TOL, (u, np.abs(got - ref).max())
 
 
-@pytest.mark.parametrize('mode', ['RAW', 'MOL'])
-def test_bench_legs_as_benchmarked_match_oracle(gpu, mode):
+@pytest.mark.parametrize('mode,mel_in_loop', [('RAW', None), ('MOL', None), ('MOL', True)], ids=['RAW', 'MOL', 'MOL-mel-in-loop'])
+def test_bench_legs_as_benchmarked_match_oracle(gpu, mode, mel_in_loop):
     """The bench's RAW and MoL legs AS BENCHMARKED (round-4 verdict, "What's weak" 1): 16 x 641-frame utterances = 256 segments x
-    12,100 steps through `generate_corpus` with the shipped defaults -- HIP pre-loop kernels; MoL: the loop kernel forms the last
-    up-sampling stage itself (wrnn_options.mel_stage = 1), RAW: the materialised mel (scripts/gpu_raw_flips.py measures both) --,
-    `algo = auto` (wrnn_duo_kernel, 4 clusters x 4 groups in flight), parity noise
+    12,100 steps through `generate_corpus` with the shipped defaults -- HIP pre-loop kernels, the materialised mel (both modes since the
+    last session of round 6; scripts/gpu_raw_flips.py, gpu_corpus_ab.py measure both forms) -- and, `MOL-mel-in-loop`, with the opt-in form
+    in which the loop kernel forms the last up-sampling stage itself (`model.mel_in_loop = True`, wrnn_options.mel_stage = 1; what rounds
+    4-6 benchmarked) --, `algo = auto` (wrnn_duo_kernel, 4 clusters x 4 groups in flight), parity noise
     (per-utterance MT19937 streams, seeds 77 + u) drawn and uploaded in step slices, against the C oracle per utterance.
     RAW: the class indices are BIT-IDENTICAL (3.1 M segment-steps, free-running); MoL: <= MOL_TOL."""
     from helpers import oracle_utterance
@@ -310,7 +320,8 @@ def test_bench_legs_as_benchmarked_match_oracle(gpu, mode):
     sd = random_state_dict(0, mode=mode)
     model = _model(sd, mode, gpu)
     assert model.pre_algo == 'native' and model.mel_in_loop is None and model.loop_algo == 'auto'       # the shipped defaults
-    in_loop = mode == 'MOL'                                       # RAW: the materialised mel by default (wavernn_amd/model.py `mel_in_loop`)
+    model.mel_in_loop = mel_in_loop
+    in_loop = bool(mel_in_loop)                                   # default: the materialised mel (wavernn_amd/model.py `mel_in_loop`)
     NU = 16
     mels = [torch.from_numpy(random_mel(1234 + u, 641)).unsqueeze(0) for u in range(NU)]
     segs, plan = generate_corpus(model, mels, TARGET, OVERLAP, True, [77 + u for u in range(NU)], return_segments=True)
@@ -319,7 +330,7 @@ def test_bench_legs_as_benchmarked_match_oracle(gpu, mode):
     print(f'bench leg [{mode}]: {info}, mel rows in loop: {model.mel_rows_ok(eng, 256, plan.T)}')
     assert plan.n_segments == 256 and plan.T == 12100
     assert info['kernel'] == 'wrnn_duo_kernel' and (info['clusters'], info['depth'], info['rounds']) == (4, 4, 1)
-    assert model.mel_rows_ok(eng, 256, plan.T) == in_loop         # MoL: the call above ran with the mel one up-sampling stage short
+    assert model.mel_rows_ok(eng, 256, plan.T) == in_loop         # in-loop: the call above ran with the mel one up-sampling stage short
     if mode == 'RAW':
         assert info['launches'] > 8                               # the noise went up in several step slices (continued launches)
     refs = _pool_map(lambda u: oracle_utterance(mode, 0, 0.0, 1234 + u, 77 + u, 641, want_cond=False, sd=sd)['ref'], list(range(NU)))

@@ -332,7 +332,7 @@ def generate_corpus(model, mels: Sequence, target: int, overlap: int, mu_law: bo
             steps = T
             if eng.plan(n_seg, T, algo=model.loop_algo)['kernel'] in RESUMABLE_KERNELS:
                 per_step = n_seg * (11 if mode == 'MOL' else model.n_classes) * 4
-                steps = max(1, min(T, getattr(model, 'noise_chunk_bytes', 128 << 20) // per_step))
+                steps = max(1, min(T, getattr(model, 'noise_chunk_bytes', 2 << 30) // per_step))
                 steps = -(-T // (-(-T // steps)))            # equal slices (no short tail slice with its own launches)
             try:
                 for t0 in range(0, T, steps):

@@ -138,20 +138,23 @@ class WaveRNN(nn.Module):
         #: current stream); the finished float64 audio comes back through page-locked memory (False: a pageable copy)
         self.pre_streams = 8
         self.pinned_output = True
-        #: True = when the call runs on wrnn_duo_kernel / wrnn_sparse_kernel (and the pre-loop stage is 'native' with a last stretch factor of 11),
-        #: the LAST up-sampling stage and the crop are formed inside the loop from that stage's input (`engine.MelRows`): the [L, feat]
-        #: up-sampled mel is never written.  False = always materialise it (what every other loop kernel reads).  None (default) = by mode:
-        #: MOL -> True; RAW -> False -- the three-row form of that stage is another float32 rounding of the mel (<= 1e-6), and the 9-bit mode is
-        #: compared class index by class index: against the C oracle the shipped kernel parts ways in 2 of 1,024 segments of 12,100 steps
-        #: with the mel formed in the loop and in 1 with the materialised mel (profiles/r05a_raw_flips.json; no float32
-        #: implementation is flip-free against another -- the oracle itself differs from the reference's own run in 1 of 387,200 samples --
-        #: but the bit-exact mode takes the conservative default; `model.mel_in_loop = True` opts in to the faster path).
+        #: True = when the call runs on wrnn_duo_kernel / wrnn_chain_kernel / wrnn_sparse_kernel (and the pre-loop stage is 'native' with a last stretch
+        #: factor of 11), the LAST up-sampling stage and the crop are formed inside the loop from that stage's input (`engine.MelRows`): the [L, feat]
+        #: up-sampled mel is never written -- 29 B of conditioning per audio sample resident instead of 320 B (a 64-utterance corpus:
+        #: 0.33 GB instead of 3.6 GB).  False = always materialise it (what every other loop kernel reads).  None (default) = False since the last
+        #: session of round 6: forming the stage costs the workgroups that form cI three times the loads and ~60 more VALU instructions per slot and
+        #: step -- 1.6 % of wrnn_duo_kernel's step at 256 segments, 4-5 % of the latency kernels' (one utterance: 9.26 vs 8.80 us per step;
+        #: block-sparse: 8.48 vs 8.15; profiles/r06bo_mel_ab_chain.log, r06be_mel_ab.log) -- and a device with 288 GB of HBM is not short of 0.9 GB per 256
+        #: segments.  (For the 9-bit mode it always was the default: the three-row form of that stage is another float32 rounding of the mel (<= 1e-6),
+        #: and RAW is compared class index by class index -- against the C oracle the kernel parts ways in 2 of 1,024 segments of 12,100 steps with
+        #: the mel formed in the loop and in 1 with the materialised mel, profiles/r05a_raw_flips.json)  `model.mel_in_loop = True`
+        #: opts in to the memory-saving form; both are parity-tested at full size.
         self.mel_in_loop = None
         #: 'native' = cross-fade / unfold / mu-law / tail fade on the device in float64 (wrnn_post_unfold);
         #: 'numpy' = the host helpers of fold.py
         self.post_algo = 'native'
         #: upper bound on the sampling noise resident at once (bytes); longer runs draw it slice by slice
-        self.noise_chunk_bytes = 128 << 20
+        self.noise_chunk_bytes = 2 << 30          # (round 6: 2 GB, was 128 MB -- every slice boundary is a relaunch of the loop kernel behind a draw; 9-bit RAW on 256 segments: 48 -> 9 launches, 369.8 -> 351.0 ms per pass, profiles/r06br_noise_chunk.log)
         #: optional `f(steps_done, T, n_segments, seconds)` called after every noise slice of generate() (row a17: the
         #: reference's gen_display read-out, :241/:267-271); None = silent, no extra synchronisation
         self.progress_callback = None
@@ -226,7 +229,7 @@ class WaveRNN(nn.Module):
         """Whether a run over this many segments takes the mel one up-sampling stage short (`mel_in_loop`): it runs on wrnn_duo_kernel / wrnn_sparse_kernel and
         the HIP pre-loop stage ends with the stretch factor that kernel is built for."""
         device = next(self.parameters()).device
-        in_loop = (self.mode == 'MOL') if self.mel_in_loop is None else bool(self.mel_in_loop)
+        in_loop = bool(self.mel_in_loop)                    # (None = the default = materialised, both modes: see `mel_in_loop`)
         if not (in_loop and self.pre_algo == 'native' and device.type == 'cuda'):
             return False
         if eng.plan(n_segments, T, algo=self.loop_algo)['kernel'] not in MEL_STAGE_KERNELS:
