@@ -725,8 +725,7 @@ __device__ __forceinline__ void duo_hh(const LoopArgs &a, float *smem, const int
                     const int j = p + SEGT[i * 48 + 2 * SEG + fi];
                     const int row = j / LAST_SCALE;
                     v = cond_tile_rows(ct, mels_up + (size_t)(row - 1) * MEL, mel_coef + 3 * (j - row * LAST_SCALE), aux_fr + (size_t)fr * (4 * AUX), valid, lane);
-                } else if constexpr ((DUO_ABLATE & 64) != 0) v = f32x4{ct.bias[0], ct.bias[1], ct.bias[2], ct.bias[3]};      // (timing only: what would hoisting cI out of the loop buy?)
-                else v = cond_tile(ct, mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane);
+                } else v = cond_tile(ct, mels_up + (size_t)p * MEL, aux_fr + (size_t)fr * (4 * AUX), valid, lane);
                 const u32x4 q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                 const int so = cbase + i * (MAXCL * DSLOTB) + 4 * DLAYERB + (tt & (DRING - 1)) * XTB;
                 if (loc_h) __builtin_amdgcn_raw_buffer_store_b128(q, xrs, J * 1024 + lane * 16, so, 0);
