@@ -776,6 +776,36 @@ def test_config1_raw_unbatched_one_second(gpu, tmp_path):
 
 
 @pytest.mark.parametrize('mode', ['MOL', 'RAW'])
+def test_host_side_settings_of_a_pass_do_not_change_the_audio(gpu, mode):
+    """Round 6 (last session): the shipped host-side settings of `generate_corpus` -- the pre-loop kernels of the utterances side by side on
+    side streams (`model.pre_streams`, `PreEngine.upsample_many`), the finished audio through page-locked memory (`model.pinned_output`), noise
+    slices of 2 GB (`model.noise_chunk_bytes`) -- against one utterance after the other on the current stream, a pageable copy and ~40-step
+    noise slices (continued launches): the same samples, bit for bit, in both modes; and the mel formed in the loop (`model.mel_in_loop =
+    True`: another float32 rounding of the conditioning) within MOL_TOL / with identical class indices on this short run."""
+    from wavernn_amd.batch import generate_corpus
+    from wavernn_amd.model import WaveRNN
+    from wavernn_amd.synthetic import random_state_dict, random_mel, SHIPPED
+    sd = random_state_dict(53, mode=mode)
+    model = WaveRNN(**SHIPPED, mode=mode)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(gpu)
+    assert (model.pre_streams, model.pinned_output, model.mel_in_loop, model.noise_chunk_bytes) == (8, True, None, 2 << 30)      # the shipped defaults
+    frames, seeds = [23, 40, 31, 26, 55, 37, 29, 44, 33, 52], list(range(920, 930))     # more utterances than side streams
+    mels = [torch.from_numpy(random_mel(630 + u, n)).unsqueeze(0) for u, n in enumerate(frames)]
+    ref = generate_corpus(model, mels, 550, 55, True, seeds)
+    model.pre_streams, model.pinned_output = 1, False
+    model.noise_chunk_bytes = 40 * (11 if mode == 'MOL' else 512) * 4 * sum(-(-((n - 1) * 275 - 55) // 605) for n in frames)
+    plain = generate_corpus(model, mels, 550, 55, True, seeds)
+    assert model._loop_engine().last_run_info()['launches'] > 4
+    for u in range(len(frames)):
+        assert np.array_equal(ref[u], plain[u]), (u, np.abs(ref[u] - plain[u]).max())
+    model.pre_streams, model.pinned_output, model.noise_chunk_bytes, model.mel_in_loop = 8, True, 2 << 30, True
+    rows = generate_corpus(model, mels, 550, 55, True, seeds)
+    for u in range(len(frames)):
+        assert np.abs(ref[u] - rows[u]).max() <= MOL_TOL, (u, np.abs(ref[u] - rows[u]).max())
+
+
+@pytest.mark.parametrize('mode', ['MOL', 'RAW'])
 def test_generate_corpus_equals_per_utterance_generate(gpu, mode, tmp_path):
     """`generate_corpus` (one launch for several utterances, single process) == one `generate()` call per utterance with
     `torch.manual_seed(seed_u)` before each -- the reference's usage (gen_wavernn.py:26-35)."""
